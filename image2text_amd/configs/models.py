@@ -1,0 +1,167 @@
+"""Model-side configuration schema.
+
+Mirror of the reference's YAML/pydantic surface (reference: configs/models.py:9-135) so that every shipped
+``training_configs/*.yaml`` parses into these classes unchanged.  The schema is plain data: class and field
+names and their defaults are the on-disk format and therefore identical to the reference; everything else
+(validation helpers, ``hot_path_supported``) is ours.
+
+Only the dense from-scratch families are executed by the HIP hot path; the other
+families parse fine but ``Encoder.from_config`` / ``Decoder.from_config`` refuse them loudly.
+"""
+from enum import Enum
+from typing import List, Optional, Tuple, Union
+
+from pydantic import BaseModel
+
+
+class LoraSpec(BaseModel):
+    """LoRA adapter request (reference configs/models.py:9-14). Parsed, never executed on the hot path."""
+    r: int = 16
+    lora_alpha: int = 64
+    lora_dropout: float = 0.1
+    target_modules: Optional[List[str]] = None
+    force_enable_update_modules: Optional[List[str]] = None
+
+
+class MLPConfig(BaseModel):
+    """Dense GELU-MLP rotator: d -> ff_mult*d -> d (reference configs/models.py:17-18)."""
+    ff_mult: float
+
+
+class MoEConfig(BaseModel):
+    """Mixture-of-experts rotator (reference configs/models.py:21-26). Out of hot-path scope."""
+    num_experts: int
+    proj_features: int
+    ff_mult_factor: float
+    gate_sizes: Optional[Tuple[int, ...]] = None
+    top_k: int = 1
+
+
+class SelfAttentionType(Enum):
+    MULTI_HEAD = 'multi_head'
+    MULTI_QUERY = 'multi_query'
+
+
+class SelfAttentionConfig(BaseModel):
+    """reference configs/models.py:34-40"""
+    attn_dropout: float = 0.1
+    bias: bool = True
+    dropout: float = 0.1
+    n_head: int = 12
+    n_embd: int = 768
+    attn_type: SelfAttentionType
+
+
+class TransformerConfig(BaseModel):
+    """reference configs/models.py:43-50"""
+    rotator_config: Union[MoEConfig, MLPConfig]
+    is_causal: bool = False
+    is_cross_attn: bool = False
+    max_block_size: Optional[int] = None
+    is_sparse_attn: bool = False
+    sparsity_factor: float = 0.5
+    attn_config: SelfAttentionConfig
+
+    def hot_path_unsupported_reason(self) -> Optional[str]:
+        """None when the dense HIP path can run this block, else a human-readable reason."""
+        if not isinstance(self.rotator_config, MLPConfig):
+            return 'MoE rotator (SURVEY.md 8(f) next #2)'
+        if self.attn_config.attn_type != SelfAttentionType.MULTI_HEAD:
+            return 'multi-query attention (SURVEY.md 8(f) next #2)'
+        if self.is_sparse_attn:
+            return 'sparse token-subset attention (SURVEY.md 8(f) next #2)'
+        if self.attn_config.n_embd % self.attn_config.n_head != 0:
+            return 'n_embd not divisible by n_head'
+        if self.attn_config.n_embd // self.attn_config.n_head != 64:
+            return 'head_dim != 64 (the gfx950 attention kernels are built for 64-wide heads)'
+        return None
+
+
+class ImageInputSpec(BaseModel):
+    n_channels: int = 3
+    width: int
+    height: int
+
+
+class LshConfig(BaseModel):
+    num_bins: Tuple[int, ...]
+    num_proj: int
+    learnable: bool
+
+
+class PeerConfig(BaseModel):
+    num_units_sqrt: int
+    topk: int
+    nhead: int
+    query_dim: Optional[int] = None
+
+
+class EncoderConfig(BaseModel):
+    n_cls: int
+    lora_spec: Optional[LoraSpec] = None
+
+
+class VisionTransformerEncoderConfig(EncoderConfig):
+    """From-scratch ViT (reference configs/models.py:80-88, models/encoder.py:130-195)."""
+    transformer_config: TransformerConfig
+    enable_gradient_checkpointing: bool = False
+    input: ImageInputSpec
+    n_layer: int = 12
+    num_patches: int
+    n_channels: int
+    feature_extractor_gate_sizes: Optional[Tuple[int, ...]] = None
+    feature_extractor_kernel_size: Tuple[int, int] = (4, 4)
+
+
+class PretrainedViTConfig(EncoderConfig):
+    """torchvision ViT-B/16 backbone + heads (reference configs/models.py:91-96). Out of hot-path scope."""
+    refine_base_model: bool = True
+    n_embd_out_vit: int
+    peer_config: Optional[PeerConfig] = None
+    lsh_config: Optional[LshConfig] = None
+    gate_sizes: Optional[Tuple[int, ...]] = None
+
+
+class ModelType(Enum):
+    GPT2 = 'gpt2'
+    GPT2_MEDIUM = 'gpt2-medium'
+    GPT2_LARGE = 'gpt2-large'
+    GPT2_XL = 'gpt2-xl'
+
+
+class DecoderConfig(BaseModel):
+    lora_spec: Optional[LoraSpec] = None
+    enable_gradient_checkpointing: bool = False
+    vocab_size: int
+
+
+class TransformerDecoderConfig(DecoderConfig):
+    """nanoGPT-style decoder (reference configs/models.py:112-119, models/decoder.py:161-282)."""
+    transformer_config: TransformerConfig
+    use_advanced_pos_emb: bool = False
+    advanced_pos_emb_gate_sizes: Optional[Tuple[int, ...]] = None
+    pretrained_model: Optional[ModelType] = None
+    n_layer: int
+    skip_alternate_cross_attn: bool = True
+    block_size: int
+
+
+class HuggingfaceDecoderConfig(DecoderConfig):
+    """HF causal-LM decoders (reference configs/models.py:122-128). Out of hot-path scope."""
+    use_cross_attn: bool
+    model_str: str
+    extra_tokens: int
+    load_in_4bit: bool
+    prepare_for_kbit_training: bool
+    use_auth_token: bool = False
+
+
+class VisionEncoderDecoderConfig(BaseModel):
+    """reference configs/models.py:131-138"""
+    vision_encoder_config: Union[VisionTransformerEncoderConfig, PretrainedViTConfig]
+    decoder_config: Union[TransformerDecoderConfig, HuggingfaceDecoderConfig]
+    loose_match_decoder_state_dict: bool = False
+    chkpt_path: Optional[str] = None
+    use_cross_attn: bool = False
+    use_soft_prompting: bool = True
+    no_repeat_n_grams: Tuple[int, ...] = (2, 3, 4, 5)

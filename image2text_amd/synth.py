@@ -1,0 +1,150 @@
+"""Named hot-path configurations, synthetic batches and a machine-independent weight initialiser.
+
+Nothing here computes the model; it only describes workloads:
+
+* ``nano224_config``  -- the benchmark configuration of SURVEY.md 8(d): reference
+  ``training_configs/local/nano.yaml:76-97`` decoder with ``pretrained_model`` removed + the commented
+  from-scratch encoder block ``nano.yaml:46-75`` made dense (224x224, 14x14 patches, multi_head, MLP ff 4).
+* ``tiny_config``     -- same topology at toy sizes (2+2 layers, 64/128 wide) for the committed golden fixtures.
+* ``synthetic_batch`` -- Flickr30K-shaped inputs: normalised-image-like ``randn`` and captions with EOS at a random
+  length and ``ignore_index`` after it, i.e. what reference ``training/utils.py:16-20`` (normalize_label) emits.
+* ``det_init_``       -- fills every parameter from a per-name seeded CPU generator so that the container that
+  generated the goldens and the GPU box hold bit-identical weights without shipping them.
+"""
+import zlib
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+from .configs.models import (
+    ImageInputSpec,
+    MLPConfig,
+    SelfAttentionConfig,
+    SelfAttentionType,
+    TransformerConfig,
+    TransformerDecoderConfig,
+    VisionEncoderDecoderConfig,
+    VisionTransformerEncoderConfig,
+)
+
+GPT2_VOCAB = 50257
+GPT2_EOS = 50256
+
+
+def _model_config(*, img: int, num_patches: int, conv_gates, conv_out: int, kernel: int,
+                  enc_layers: int, enc_d: int, enc_heads: int, n_cls: int, enc_bias: bool,
+                  dec_layers: int, dec_d: int, dec_heads: int, block_size: int, vocab: int,
+                  dropout: float, use_cross_attn: bool = True, use_soft_prompting: bool = True,
+                  no_repeat_n_grams=(2, 3, 4, 5)) -> VisionEncoderDecoderConfig:
+    enc_tf = TransformerConfig(
+        rotator_config=MLPConfig(ff_mult=4),
+        is_causal=False,
+        is_cross_attn=False,
+        attn_config=SelfAttentionConfig(attn_dropout=dropout, bias=enc_bias, dropout=dropout, n_head=enc_heads,
+                                        n_embd=enc_d, attn_type=SelfAttentionType.MULTI_HEAD),
+    )
+    enc = VisionTransformerEncoderConfig(
+        transformer_config=enc_tf,
+        enable_gradient_checkpointing=False,
+        input=ImageInputSpec(n_channels=3, width=img, height=img),
+        n_layer=enc_layers,
+        n_cls=n_cls,
+        num_patches=num_patches,
+        n_channels=conv_out,
+        feature_extractor_gate_sizes=tuple(conv_gates),
+        feature_extractor_kernel_size=(kernel, kernel),
+    )
+    dec_tf = TransformerConfig(
+        rotator_config=MLPConfig(ff_mult=4),
+        is_causal=True,
+        is_cross_attn=True,
+        attn_config=SelfAttentionConfig(attn_dropout=dropout, bias=True, dropout=dropout, n_head=dec_heads,
+                                        n_embd=dec_d, attn_type=SelfAttentionType.MULTI_HEAD),
+    )
+    dec = TransformerDecoderConfig(
+        transformer_config=dec_tf,
+        n_layer=dec_layers,
+        block_size=block_size,
+        vocab_size=vocab,
+        enable_gradient_checkpointing=False,
+    )
+    return VisionEncoderDecoderConfig(
+        vision_encoder_config=enc,
+        decoder_config=dec,
+        use_cross_attn=use_cross_attn,
+        use_soft_prompting=use_soft_prompting,
+        no_repeat_n_grams=tuple(no_repeat_n_grams),
+    )
+
+
+def nano224_config(dropout: float = 0.0) -> VisionEncoderDecoderConfig:
+    """SURVEY.md 8(d) "nano-224": 6x512 ViT (8 heads, 196 flat patches of 8192, 64 CLS) + 12x768 nanoGPT decoder."""
+    return _model_config(img=224, num_patches=14, conv_gates=(8, 16), conv_out=32, kernel=6,
+                         enc_layers=6, enc_d=512, enc_heads=8, n_cls=64, enc_bias=False,
+                         dec_layers=12, dec_d=768, dec_heads=12, block_size=256, vocab=GPT2_VOCAB,
+                         dropout=dropout)
+
+
+def tiny_config(dropout: float = 0.0, **overrides) -> VisionEncoderDecoderConfig:
+    """Same topology as nano-224 at fixture size: 32x32 images, 16 flat patches of 512, 8 CLS, vocab 384."""
+    kw = dict(img=32, num_patches=4, conv_gates=(4, 8), conv_out=8, kernel=6,
+              enc_layers=2, enc_d=64, enc_heads=1, n_cls=8, enc_bias=False,
+              dec_layers=2, dec_d=128, dec_heads=2, block_size=48, vocab=384,
+              dropout=dropout)
+    kw.update(overrides)
+    return _model_config(**kw)
+
+
+def fake_tokenizer(vocab_size: int, eos: Optional[int] = None):
+    """The four attributes ModelTrainerWrapper reads from a tokenizer (reference training/wrapper.py:88,157,173,188)."""
+    eos = vocab_size - 1 if eos is None else eos
+    return SimpleNamespace(eos_token_id=eos, bos_token_id=eos, mask_token_id=None, vocab_size=vocab_size)
+
+
+def synthetic_batch(batch: int, img: int, caption_len: int, vocab: int, seed: int = 1, eos: Optional[int] = None,
+                    ignore_index: int = -100, min_len: int = 8):
+    """images (B,3,img,img) fp32 ~ N(0,1); labels (B,caption_len) int64 = ids, EOS at a random length, ignore after."""
+    eos = vocab - 1 if eos is None else eos
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(batch, 3, img, img, generator=g)
+    min_len = min(min_len, caption_len - 1)
+    lens = torch.randint(min_len, caption_len, (batch,), generator=g)
+    ids = torch.randint(0, eos, (batch, caption_len), generator=g)
+    pos = torch.arange(caption_len).unsqueeze(0)
+    labels = torch.where(pos < lens.unsqueeze(1), ids, torch.full_like(ids, eos))
+    labels = torch.where(pos <= lens.unsqueeze(1), labels, torch.full_like(ids, ignore_index))
+    return images, labels
+
+
+@torch.no_grad()
+def det_init_(module: torch.nn.Module, seed: int = 0) -> torch.nn.Module:
+    """Overwrite every parameter from ``Generator(seed ^ crc32(name))`` on the CPU, then copy to the param's device.
+
+    Scales are chosen so that nothing is hidden by a trivial value: matrices ~N(0, 0.02^2) (projection matrices
+    N(0, fan_in^-1/2 * 0.5)), LayerNorm gains 1 + 0.1 N, biases 0.02 N, CLS tokens N(0, 1/d).
+    Tied parameters are visited once (``named_parameters`` de-duplicates).
+    """
+    for name, p in module.named_parameters():
+        g = torch.Generator().manual_seed((seed * 1000003) ^ zlib.crc32(name.encode()))
+        x = torch.randn(p.shape, generator=g, dtype=torch.float32)
+        leaf = name.rsplit('.', 1)[-1]
+        if p.dim() >= 2 and ('ln_' in name or 'ln_input' in name) and leaf == 'weight':
+            x = 1.0 + 0.1 * x                      # LayerNormND gain (2-D)
+        elif p.dim() == 1 and leaf == 'weight':
+            x = 1.0 + 0.1 * x                      # LayerNorm gain
+        elif leaf in ('bias', 'in_proj_bias'):
+            x = 0.02 * x
+        elif 'cls_token' in name:
+            x = x / (p.shape[-1] ** 0.5)
+        elif p.dim() == 4:                         # conv kernels: keep activations O(1)
+            fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+            x = x / (fan_in ** 0.5)
+        elif '.wte.' in name or '.wpe.' in name or name.startswith('lm_head') or '.lm_head.' in name:
+            x = 0.02 * x                           # embeddings / tied head: reference decoder.py:206-212 scale
+        elif p.dim() == 2:
+            x = 0.7 * x / (p.shape[1] ** 0.5)      # linear maps: O(1) activations, non-flat attention softmax
+        else:
+            x = 0.02 * x
+        p.copy_(x.to(p.device, p.dtype))
+    return module

@@ -1,0 +1,337 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A plain-PyTorch fp32 restatement of the reference's captioning hot path, written as pure functions over a
+state-dict (``{name: tensor}``) so that it cannot be mistaken for, or imported by, the product modules.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against fixtures produced by
+running the reference itself in the build container (``tools/gen_goldens.py`` -> ``tests/golden/*.npz``): forward
+outputs for four mask forms and three prompt/cross-attention modes, the train-step loss and the gradient of every
+parameter, and greedy token ids -- all to <= 1e-5 (fp32) / token-exact.
+
+Each function cites the reference lines it restates (paths relative to the reference repo).
+"""
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+NEG_INF = float('-inf')
+SD = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# gradient normaliser (models/functions.py:4-27): identity forward, g / (||g||_2 + 1e-6) backward over the tensor
+# --------------------------------------------------------------------------------------------------------------
+class _UnitNormGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g / (torch.linalg.vector_norm(g) + 1e-6)
+
+
+def _get(sd: SD, name: str) -> Optional[torch.Tensor]:
+    return sd.get(name)
+
+
+def _drop(x, p, training):
+    return F.dropout(x, p, training) if (training and p > 0) else x
+
+
+# --------------------------------------------------------------------------------------------------------------
+# blocks (models/layers.py)
+# --------------------------------------------------------------------------------------------------------------
+def layer_norm(x, w, b):
+    """layers.py:349-370 -- LayerNorm / LayerNormND: normalise over the trailing dims covered by ``w``, eps 1e-5."""
+    return F.layer_norm(x, tuple(w.shape), w, b, 1e-5)
+
+
+def conv_stack(sd: SD, prefix: str, x):
+    """layers.py:258-282 -- Conv2d('same') [-> GELU(tanh) -> Conv2d('same')]*.
+
+    Sequential indices are 0,2,4,... (GELUs sit at the odd slots).  Even kernels pad asymmetrically:
+    (k-1)//2 before and k//2 after, which is what torch's padding='same' does.
+    """
+    i = 0
+    while f'{prefix}.model.{i}.weight' in sd:
+        if i > 0:
+            x = F.gelu(x, approximate='tanh')
+        w = sd[f'{prefix}.model.{i}.weight']
+        kh, kw = w.shape[-2:]
+        x = F.pad(x, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2))
+        x = F.conv2d(x, w, sd[f'{prefix}.model.{i}.bias'])
+        i += 2
+    return x
+
+
+def softmax_attention(q, k, v, add_mask, dropout_p=0.0, training=False):
+    """F.scaled_dot_product_attention semantics as used at layers.py:465 and inside nn.MultiheadAttention:
+    softmax(q k^T / sqrt(dh) + mask) v with the torch>=2.5 'safe softmax' rule: a fully masked row yields zeros."""
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(q.size(-1))
+    if add_mask is not None:
+        s = s + add_mask
+    m = s.amax(dim=-1, keepdim=True)
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+    p = torch.exp(s - m)
+    z = p.sum(dim=-1, keepdim=True)
+    p = p / torch.where(z == 0, torch.ones_like(z), z)
+    p = _drop(p, dropout_p, training)
+    return p @ v
+
+
+def self_attention(sd: SD, p: str, x, n_head: int, add_mask, dropout=0.0, attn_dropout=0.0, training=False):
+    """layers.py:433-470 MultiHeadAttention: fused c_attn, per-token dropout multipliers, SDPA, c_proj."""
+    B, T, C = x.shape
+    qkv = F.linear(x, sd[f'{p}.c_attn.weight'], _get(sd, f'{p}.c_attn.bias'))
+    q, k, v = qkv.split(C, dim=2)
+    ones = torch.ones((B, 1, T, 1), dtype=x.dtype)
+    k_do, q_do, v_do = (_drop(ones, attn_dropout, training) for _ in range(3))   # layers.py:454-457 order
+    heads = lambda t: t.view(B, T, n_head, C // n_head).transpose(1, 2)
+    y = softmax_attention(q_do * heads(q), k_do * heads(k), v_do * heads(v), add_mask, dropout, training)
+    y = y.transpose(1, 2).contiguous().view(B, T, C)
+    return _drop(F.linear(y, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias')), dropout, training)
+
+
+def cross_attention(sd: SD, p: str, x, mem, n_head: int, dropout=0.0, training=False):
+    """layers.py:537-542,600-605 -- nn.MultiheadAttention(batch_first) with packed in_proj (3d,d), always biased:
+    q from x, k/v from the encoder output, no mask, dropout on the attention weights, out_proj."""
+    B, T, C = x.shape
+    S = mem.size(1)
+    w, b = sd[f'{p}.in_proj_weight'], sd[f'{p}.in_proj_bias']
+    q = F.linear(x, w[:C], b[:C])
+    k = F.linear(mem, w[C:2 * C], b[C:2 * C])
+    v = F.linear(mem, w[2 * C:], b[2 * C:])
+    hq = q.view(B, T, n_head, C // n_head).transpose(1, 2)
+    hk = k.view(B, S, n_head, C // n_head).transpose(1, 2)
+    hv = v.view(B, S, n_head, C // n_head).transpose(1, 2)
+    y = softmax_attention(hq, hk, hv, None, dropout, training).transpose(1, 2).contiguous().view(B, T, C)
+    return F.linear(y, sd[f'{p}.out_proj.weight'], sd[f'{p}.out_proj.bias'])
+
+
+def gelu_mlp(sd: SD, p: str, x, dropout=0.0, training=False):
+    """layers.py:473-486 -- Linear d->4d, GELU(tanh), Linear 4d->d, dropout."""
+    h = F.gelu(F.linear(x, sd[f'{p}.c_fc.weight'], _get(sd, f'{p}.c_fc.bias')), approximate='tanh')
+    return _drop(F.linear(h, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias')), dropout, training)
+
+
+def transformer_block(sd: SD, p: str, x, n_head: int, causal: bool, mem, add_mask, dropout=0.0, attn_dropout=0.0,
+                      training=False):
+    """layers.py:565-608 dense branch: pre-LN residual wiring attn -> (cross) -> mlp, then the gradient normaliser."""
+    if causal:
+        L = x.size(-2)
+        tri = torch.ones((L, L), dtype=torch.bool).tril()
+        cm = torch.zeros((L, L), dtype=x.dtype).masked_fill(~tri, NEG_INF)[None, None]
+        add_mask = cm if add_mask is None else add_mask + cm
+    x = x + self_attention(sd, f'{p}.attn', layer_norm(x, sd[f'{p}.ln_1.weight'], _get(sd, f'{p}.ln_1.bias')),
+                           n_head, add_mask, dropout, attn_dropout, training)
+    if mem is not None:
+        if f'{p}.cross_attn.in_proj_weight' not in sd:
+            raise ValueError('Model not configured for cross attn inputs!!!')        # layers.py:598-599
+        x = x + cross_attention(sd, f'{p}.cross_attn',
+                                layer_norm(x, sd[f'{p}.ln_3.weight'], _get(sd, f'{p}.ln_3.bias')), mem, n_head,
+                                dropout, training)
+    x = x + gelu_mlp(sd, f'{p}.mlp', layer_norm(x, sd[f'{p}.ln_2.weight'], _get(sd, f'{p}.ln_2.bias')), dropout,
+                     training)
+    return _UnitNormGrad.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# encoder (models/encoder.py:130-195) and decoder (models/decoder.py:161-282)
+# --------------------------------------------------------------------------------------------------------------
+def _sub(sd: SD, prefix: str) -> SD:
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def vit_encoder(sd: SD, cfg, images, training=False):
+    """encoder.py:163-178.  ``sd`` keys are relative to the VisionTransformerEncoder module.
+
+    conv stack -> FLAT reshape to (n, P^2, C*ph*pw) (a chunking of the contiguous CHW buffer, not spatial patches,
+    encoder.py:166) -> projector -> LayerNormND -> +wpe -> the SAME LayerNormND again -> prepend CLS -> blocks ->
+    ln_f on the CLS rows only.
+    """
+    ac = cfg.transformer_config.attn_config
+    P2 = cfg.num_patches ** 2
+    x = conv_stack(sd, 'feature_extractor', images)
+    n = x.size(0)
+    x = x.reshape(n, P2, -1)
+    x = F.linear(x, sd['projector.weight'], _get(sd, 'projector.bias'))
+    x = layer_norm(x, sd['ln_input.weight'], _get(sd, 'ln_input.bias'))
+    x = x + sd['transformer.wpe.weight'][:P2].unsqueeze(0)
+    x = layer_norm(x, sd['ln_input.weight'], _get(sd, 'ln_input.bias'))
+    x = torch.cat((sd['cls_token'].expand(n, -1, -1), x), dim=1)
+    x = _drop(x, ac.dropout, training)
+    for i in range(cfg.n_layer):
+        x = transformer_block(sd, f'transformer.h.{i}', x, ac.n_head, cfg.transformer_config.is_causal, None, None,
+                              ac.dropout, ac.attn_dropout, training)
+    return layer_norm(x[:, :cfg.n_cls].contiguous(), sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
+
+
+def encode(sd: SD, cfg, images, training=False):
+    """vision_encoder_decoder.py:26-39,58-59: encoder, then the bias-free bridge Linear when the widths differ
+    (state-dict keys then carry the nn.Sequential prefixes ``encoder.0.`` / ``encoder.1.``)."""
+    if 'encoder.1.weight' in sd:
+        y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training)
+        return F.linear(y, sd['encoder.1.weight'])
+    return vit_encoder(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images, training)
+
+
+def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=None, attn_msk=None, training=False):
+    """decoder.py:214-256.  ``sd`` keys relative to TransformerDecoder.  Returns (logits, hidden)."""
+    assert (idx is None) != (inputs_embeds is None)
+    ac = cfg.transformer_config.attn_config
+    if inputs_embeds is None:
+        inputs_embeds = sd['transformer.wte.weight'][idx]
+    t = inputs_embeds.size(1)
+    assert t <= cfg.block_size, f'Cannot forward sequence of length {t}, block size is only {cfg.block_size}'
+    x = _drop(inputs_embeds + sd['transformer.wpe.weight'][:t], ac.dropout, training)
+    for depth in range(cfg.n_layer):
+        mem = cross_attn_embeds if (depth % 2 == 0 or not cfg.skip_alternate_cross_attn) else None
+        x = transformer_block(sd, f'transformer.h.{depth}', x, ac.n_head, cfg.transformer_config.is_causal, mem,
+                              attn_msk, ac.dropout, ac.attn_dropout, training)
+    x = layer_norm(x, sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
+    return F.linear(x, sd['transformer.wte.weight']), x          # lm_head is tied to wte (decoder.py:189-204)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# glue (models/vision_encoder_decoder.py:51-134)
+# --------------------------------------------------------------------------------------------------------------
+def expand_user_mask(attn_msk, bs: int):
+    """vision_encoder_decoder.py:61-72: bool mask -> (bs|1, h|1, s, l).  A 2-D (bs, s) mask is broadcast along the
+    KEY axis, i.e. it masks query rows."""
+    if attn_msk is None:
+        return None
+    if attn_msk.dim() == 2:
+        s = attn_msk.size(1)
+        if attn_msk.size(0) == bs:
+            return attn_msk[:, None, :, None].expand(bs, 1, s, s)
+        return attn_msk[None, None].expand(bs, 1, *attn_msk.shape)
+    if attn_msk.dim() == 3:
+        if attn_msk.size(0) == bs:
+            return attn_msk[:, None]
+        return attn_msk[None].expand(bs, *attn_msk.shape)
+    return attn_msk
+
+
+def _mask_to_additive(allowed):
+    """vision_encoder_decoder.py:97-98 / 118-119 as they actually execute: ``bool_mask.masked_fill(~bool_mask, -inf)``
+    fills a BOOL tensor, so -inf is cast to True; after ``.float()`` every entry is 1.0 and the next line rewrites
+    1 -> 0.  The additive image of the (user AND causal) mask is therefore ALL ZEROS: user masks are shape-checked
+    but numerically inert (golden fixtures row_mask/sl_mask/bsl_mask == nomask bit for bit), and causality comes
+    only from TransformerBlock (layers.py:581-595)."""
+    filled = allowed.masked_fill(~allowed, NEG_INF).float()      # bool fill: all True -> all 1.0
+    filled[filled == 1] = 0
+    return filled
+
+
+def forward(sd: SD, cfg, images, ids, attn_msk=None, encoder_output=None, training=False):
+    """VisionEncoderDecoder.forward -> (encoder_output, logits, hidden_state)."""
+    dcfg = cfg.decoder_config
+    if encoder_output is None:
+        encoder_output = encode(sd, cfg, images, training)
+    bs, ncls, _ = encoder_output.shape
+    L = ids.size(-1)
+    allowed = torch.ones((L, L), dtype=torch.bool).tril()[None, None]
+    user = expand_user_mask(attn_msk, bs)
+    if user is not None:
+        allowed = torch.logical_and(user, allowed)
+    dsd = _sub(sd, 'decoder.')
+    if cfg.use_soft_prompting:
+        emb = torch.cat((encoder_output, dsd['transformer.wte.weight'][ids]), dim=-2)[..., :dcfg.block_size, :]
+        h, s = allowed.size(1), L
+        add = torch.full((bs, h, ncls + s, ncls + s), NEG_INF)
+        add[..., :ncls, :] = 0                                  # prompt rows see every column (:93-95)
+        add[..., ncls:, ncls:] = _mask_to_additive(allowed)     # (:96-99)
+        add = add[..., :dcfg.block_size, :dcfg.block_size]      # text rows never see prompt columns
+        logits, hidden = gpt_decoder(dsd, dcfg, inputs_embeds=emb,
+                                     cross_attn_embeds=encoder_output if cfg.use_cross_attn else None,
+                                     attn_msk=add, training=training)
+        return encoder_output, logits[..., ncls:, :], hidden
+    add = _mask_to_additive(allowed)                            # (:117-119)
+    logits, hidden = gpt_decoder(dsd, dcfg, idx=ids,
+                                 cross_attn_embeds=encoder_output if cfg.use_cross_attn else None,
+                                 attn_msk=add, training=training)
+    return encoder_output, logits, hidden
+
+
+# --------------------------------------------------------------------------------------------------------------
+# training step (training/wrapper.py:80-96,120-151,153-214; default ``trainer: {}`` path = weighted CE only)
+# --------------------------------------------------------------------------------------------------------------
+def loss_weights(labels, ignore_index=-100, weight_fn='constant', eos_token_id=None, eos_token_weight=None):
+    """wrapper.py:80-96: per-token weights, normalised per sequence (1e-3 in the denominator) and divided by B."""
+    if weight_fn == 'constant':
+        w = torch.ones_like(labels, dtype=torch.float)
+    elif weight_fn == 'inverse_sqrt_position':
+        w = (1.0 / torch.sqrt(torch.arange(1, labels.size(1) + 1, dtype=torch.float))).expand(labels.size(0), -1).clone()
+    else:
+        raise ValueError(f'unknown weight_fn: {weight_fn}')
+    if eos_token_weight is not None:
+        w[labels == eos_token_id] = eos_token_weight
+    w[labels == ignore_index] = 0.0
+    return (w / (1e-3 + w.sum(dim=-1, keepdim=True))) / w.size(0)
+
+
+def shifted_inputs(labels, bos: int, eos: int, ignore_index=-100):
+    """wrapper.py:154-159,185-196: ids = labels with ignore->EOS, BOS prepended, last dropped; same for the mask."""
+    ids = torch.where(labels != ignore_index, labels, torch.full_like(labels, eos))
+    msk = labels != ignore_index
+    bs, sl = ids.shape
+    ids = torch.cat((torch.full((bs, 1), bos, dtype=torch.long), ids), dim=1)[:, :sl]
+    msk = torch.cat((torch.ones((bs, 1), dtype=torch.bool), msk), dim=1)[:, :sl]
+    return ids, msk
+
+
+def lm_step(sd: SD, cfg, images, labels, tokenizer, training: bool, ignore_index=-100, temperature=1.0,
+            weight_fn='constant', eos_token_weight=None):
+    """ModelTrainerWrapper.train_step / val_step for the default trainer config -> scalar loss."""
+    ids, msk = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
+    _, logits, _ = forward(sd, cfg, images, ids, msk, training=training)
+    labels = labels[..., :logits.size(-2)]
+    logits = logits[..., :labels.size(-1), :]
+    w = loss_weights(labels, ignore_index, weight_fn, tokenizer.eos_token_id, eos_token_weight)
+    ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)) / temperature, labels.reshape(-1),
+                         ignore_index=ignore_index, reduction='none')
+    return (ce * w.reshape(-1)).sum()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# greedy decode = generate(top_k=1, temperature=1) (vision_encoder_decoder.py:136-182) with the HF
+# NoRepeatNGramLogitsProcessor (transformers 5.15.0 logits_process.py:1021-1070) restated
+# --------------------------------------------------------------------------------------------------------------
+def banned_next_tokens(row: Sequence[int], n: int):
+    """Tokens t such that (last n-1 ids)+(t,) already occurs in ``row``; nothing is banned while len+1 < n."""
+    cur = len(row)
+    if cur + 1 < n:
+        return []
+    tail = tuple(row[cur + 1 - n:])
+    return [row[i + n - 1] for i in range(cur - n + 1) if tuple(row[i:i + n - 1]) == tail]
+
+
+def apply_ngram_ban(ids, logits, ngram_sizes):
+    for b, row in enumerate(ids.tolist()):
+        for n in ngram_sizes:
+            banned = banned_next_tokens(row, n)
+            if banned:
+                logits[b, banned] = NEG_INF
+    return logits
+
+
+@torch.no_grad()
+def generate_greedy(sd: SD, cfg, images, prompt_ids, max_new_tokens: int, return_margins=False):
+    """Cache-free loop exactly as the reference runs it: full re-forward per token, ban, argmax, append."""
+    blk = cfg.decoder_config.block_size - (cfg.vision_encoder_config.n_cls if cfg.use_soft_prompting else 0)
+    assert max_new_tokens <= blk - prompt_ids.size(-1)
+    enc, ids, margins = None, prompt_ids, []
+    for _ in range(max_new_tokens):
+        cond = ids if ids.size(-1) <= blk else ids[..., -blk:]
+        enc, logits, _ = forward(sd, cfg, images, cond, None, encoder_output=enc)
+        last = apply_ngram_ban(ids, logits[..., -1, :].clone(), cfg.no_repeat_n_grams)
+        if return_margins:
+            t2 = torch.topk(last, 2, dim=-1).values
+            margins.append(t2[:, 0] - t2[:, 1])
+        ids = torch.cat((ids, last.argmax(dim=-1, keepdim=True)), dim=-1)
+    return (ids, torch.stack(margins, dim=1)) if return_margins else ids
