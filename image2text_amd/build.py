@@ -1,0 +1,47 @@
+"""Build libi2t_hip.so (gfx950) in-tree with hipcc.  ``python -m image2text_amd.build`` or ``build_library()``."""
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB = os.path.join(CSRC, 'libi2t_hip.so')
+SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'decode.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'),
+                                                      os.path.join(CSRC, '..', '..', 'include', 'i2t.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')
+        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out.decode()}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-o', LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout.decode()}')
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,399 @@
+// Fused attention forward / backward for gfx950, head_dim 64, bf16 operands, fp32 softmax and accumulation.
+//
+// Problem sizes on this path are short (Tk <= a few hundred), so the structure optimises for few, fully coalesced
+// passes rather than deep pipelines: a workgroup = 4 waves = one 64-row tile of one (batch, head); 64-key tiles are
+// staged into LDS once per workgroup and shared by the 4 waves.
+//
+// LDS image ("P160"): every 64 x 64 bf16 tile is stored [row][64] with a 160-byte row stride (128 B data + 32 B pad).
+// With that stride BOTH access kinds this kernel needs are bank-conflict free on the 64-bank LDS:
+//   * row reads  (ds_read_b128: 16 lanes read 16 consecutive rows at one 16-B column) for operands whose MFMA
+//     reduction index runs along the row (Q.K^T over head_dim, dO.V^T over head_dim);
+//   * transposed reads (ds_read_b64_tr_b16: 4 rows x 16 columns per 16 lanes) for operands whose reduction index is
+//     the ROW (P.V over keys, dS.K over keys, dS^T.Q / P^T.dO over queries).
+//
+// MFMA orientation: scores are produced TRANSPOSED (D[key][q] = K . Q^T) so that a lane owns one query column
+// (q = lane & 15) and 4 consecutive keys per 16-key subtile (rows 4*(lane>>4) + r).  Row max / row sum then need
+// only 2 xor-shuffles (16, 32), and the exponentiated tile is directly the B operand of the next product
+// (O^T[d][q] = V^T[d][key] . P^T[key][q]) with the key order permuted identically on the V^T side (the transposed
+// LDS read takes any 4-row set) -- cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand".
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 160;                         // tile row stride in bytes
+constexpr int TILE_BYTES = 64 * TS;             // 10240
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float SCALE = 0.125f;                 // 1/sqrt(64)
+
+struct AttnPtr {
+    const bf16_t* p;
+    long bs;   // batch stride (elements)
+    int rs;    // row stride (elements)
+};
+
+// stage rows [r0, r0+64) x 64 columns of one (b, h) slice into a P160 tile; rows >= nrows are zero-filled
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, int rs, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int c = tid + 256 * u;
+        int r = c >> 3, kc = c & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)(r0 + r) * rs + kc * 8);
+        *reinterpret_cast<u32x4*>(lds + r * TS + kc * 16) = v;
+    }
+}
+
+// row fragment: lane (g, i) <- tile[r0 + i][32 ks + 8 g .. +7]
+__device__ __forceinline__ bf16x8 tile_row_frag(const unsigned char* lds, int r0, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    u32x4 v = *reinterpret_cast<const u32x4*>(lds + (r0 + i) * TS + (ks * 4 + g) * 16);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// transposed fragment for k-step s2 (32 rows) and column subtile c0 (16 cols): lane (g, i) <- tile[row(g,j)][c0 + i],
+// row(g, j) = 32 s2 + 16 (j >> 2) + 4 g + (j & 3)   -- the row order produced by a transposed-score accumulator
+__device__ __forceinline__ bf16x8 tile_tr_frag(const unsigned char* lds, int s2, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned char* a = lds + (32 * s2 + 4 * g + (i >> 2)) * TS + (c0 + 4 * (i & 3)) * 2;
+    s16x4 lo = lds_read_tr16(a);
+    s16x4 hi = lds_read_tr16(a + 16 * TS);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// global row fragment: lane (g, i) <- M[row0 + i][32 ks + 8 g .. +7], zeros beyond nrows
+__device__ __forceinline__ bf16x8 global_row_frag(const bf16_t* base, int rs, int row0, int nrows, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + i < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + i) * rs + ks * 32 + g * 8);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+    u32x4 v = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float quad_max(float v) {   // across the 4 lanes that share a query column
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ================================================================================================== forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O,
+                                                       long o_bs, int o_rs, float* __restrict__ lse, int H, int Tq,
+                                                       int Tk, int causal) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    unsigned char* kt_lds = smem;
+    unsigned char* vt_lds = smem + TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
+    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
+    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
+    const int q0 = qt * 64 + w * 16;
+    const int qrow = q0 + li;                       // this lane's query row
+    const int shift = Tk - Tq;                      // causal: key j visible iff j <= q + shift
+    const bf16x8 qf0 = global_row_frag(qb, Q.rs, q0, Tq, 0, lane);
+    const bf16x8 qf1 = global_row_frag(qb, Q.rs, q0, Tq, 1, lane);
+
+    int last_key = Tk - 1;
+    if (causal) last_key = min(last_key, qt * 64 + 63 + shift);
+    const int nkt = last_key / 64 + 1;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;                   // running max (log2 domain) and this lane's partial row sum
+    const int qlim = causal ? (min(qrow, Tq - 1) + shift) : (Tk - 1);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile(kt_lds, kb, K.rs, kt * 64, Tk, tid);
+        stage_tile(vt_lds, vb, V.rs, kt * 64, Tk, tid);
+        __syncthreads();
+        f32x4 s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kt * 64 + kj * 16 + 4 * g + r;
+                float v = (key <= qlim && key < Tk) ? a[r] * (SCALE * LOG2E) : -INFINITY;
+                a[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            s[kj] = a;
+        }
+        mx = quad_max(mx);
+        const float m_new = fmaxf(m, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m - m_safe);      // m = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = exp2f(s[kj][r] - m_safe);
+                s[kj][r] = p;
+                rs += p;
+            }
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        const bf16x8 p0 = pack_frag(s[0], s[1]);
+        const bf16x8 p1 = pack_frag(s[2], s[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(vt_lds, 0, dt * 16, lane), p0, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(vt_lds, 1, dt * 16, lane), p1, o[dt], 0, 0, 0);
+        }
+    }
+    l = quad_sum(l);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qrow < Tq) {
+        bf16_t* op = O + (size_t)b * o_bs + (size_t)qrow * o_rs + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+            *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = pk;
+        }
+        if (g == 0 && lse) lse[((size_t)b * H + h) * Tq + qrow] = (m + log2f(l)) * LN2;
+    }
+}
+
+// ================================================================================================== backward
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, long o_bs, int o_rs,
+                                                         const bf16_t* __restrict__ dO, long do_bs, int do_rs,
+                                                         float* __restrict__ delta, int H, int Tq, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // (b, q, h) with h fastest -> adjacent 128-B segments
+    if (idx >= total) return;
+    const int h = idx % H, q = (idx / H) % Tq, b = idx / (H * Tq);
+    const u32x4* po = reinterpret_cast<const u32x4*>(O + (size_t)b * o_bs + (size_t)q * o_rs + h * 64);
+    const u32x4* pd = reinterpret_cast<const u32x4*>(dO + (size_t)b * do_bs + (size_t)q * do_rs + h * 64);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        u32x4 a = po[c], d = pd[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(d[e]) + bf16hi(a[e]) * bf16hi(d[e]);
+    }
+    delta[((size_t)b * H + h) * Tq + q] = s;
+}
+
+// dQ: one workgroup per (q tile, h, b); loops over key tiles.  Scores transposed (lane owns a query column).
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int Tq,
+                                                          int Tk, int causal) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    unsigned char* kt_lds = smem;
+    unsigned char* vt_lds = smem + TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
+    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
+    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
+    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    const int q0 = qt * 64 + w * 16;
+    const int qrow = q0 + li;
+    const int shift = Tk - Tq;
+    const bf16x8 qf0 = global_row_frag(qb, Q.rs, q0, Tq, 0, lane);
+    const bf16x8 qf1 = global_row_frag(qb, Q.rs, q0, Tq, 1, lane);
+    const bf16x8 df0 = global_row_frag(dob, dO.rs, q0, Tq, 0, lane);
+    const bf16x8 df1 = global_row_frag(dob, dO.rs, q0, Tq, 1, lane);
+    const int qc = min(qrow, Tq - 1);
+    const float lse2 = lse[((size_t)b * H + h) * Tq + qc] * LOG2E;
+    const float dl = delta[((size_t)b * H + h) * Tq + qc];
+    int last_key = Tk - 1;
+    if (causal) last_key = min(last_key, qt * 64 + 63 + shift);
+    const int nkt = last_key / 64 + 1;
+    const int qlim = causal ? (qc + shift) : (Tk - 1);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile(kt_lds, kb, K.rs, kt * 64, Tk, tid);
+        stage_tile(vt_lds, vb, V.rs, kt * 64, Tk, tid);
+        __syncthreads();
+        f32x4 ds[4];
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 0, lane), df0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 1, lane), df1, dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kt * 64 + kj * 16 + 4 * g + r;
+                float p = (key <= qlim && key < Tk) ? exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
+                ds[kj][r] = p * (dp[r] - dl) * SCALE;
+            }
+        }
+        const bf16x8 s0 = pack_frag(ds[0], ds[1]);
+        const bf16x8 s1 = pack_frag(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {   // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(kt_lds, 0, dt * 16, lane), s0, acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(kt_lds, 1, dt * 16, lane), s1, acc[dt], 0, 0, 0);
+        }
+    }
+    if (qrow < Tq) {
+        bf16_t* op = dQ + (size_t)b * dq_bs + (size_t)qrow * dq_rs + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 pk = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+            *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = pk;
+        }
+    }
+}
+
+// dK, dV: one workgroup per (key tile, h, b); each wave owns 16 keys and loops over 64-row query tiles.
+// Scores NOT transposed here (D[q][key]: lane owns a key column), so P / dS are the B operands of
+// dV^T[d][key] = dO^T[d][q] . P[q][key] and dK^T[d][key] = Q^T[d][q] . dS[q][key].
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dK, long dk_bs, int dk_rs,
+                                                           bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq,
+                                                           int Tk, int causal) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * 64 * 4];
+    unsigned char* q_lds = smem;
+    unsigned char* do_lds = smem + TILE_BYTES;
+    float* lse_lds = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    float* dl_lds = lse_lds + 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
+    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
+    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
+    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    const int k0 = kt * 64 + w * 16;
+    const int key = k0 + li;                         // this lane's key column
+    const int shift = Tk - Tq;
+    const bf16x8 kf0 = global_row_frag(kb, K.rs, k0, Tk, 0, lane);
+    const bf16x8 kf1 = global_row_frag(kb, K.rs, k0, Tk, 1, lane);
+    const bf16x8 vf0 = global_row_frag(vb, V.rs, k0, Tk, 0, lane);
+    const bf16x8 vf1 = global_row_frag(vb, V.rs, k0, Tk, 1, lane);
+    int first_q = 0;
+    if (causal) first_q = max(0, kt * 64 - shift);   // first query row that can see any key of this tile
+    const int qt0 = first_q / 64, nqt = (Tq + 63) / 64;
+
+    f32x4 adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) adk[dt] = adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int qt = qt0; qt < nqt; ++qt) {
+        __syncthreads();
+        stage_tile(q_lds, qb, Q.rs, qt * 64, Tq, tid);
+        stage_tile(do_lds, dob, dO.rs, qt * 64, Tq, tid);
+        if (tid < 64) {
+            int q = min(qt * 64 + tid, Tq - 1);
+            lse_lds[tid] = lse[((size_t)b * H + h) * Tq + q] * LOG2E;
+            dl_lds[tid] = delta[((size_t)b * H + h) * Tq + q];
+        }
+        __syncthreads();
+        f32x4 p[4], ds[4];
+#pragma unroll
+        for (int qj = 0; qj < 4; ++qj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            // swapped issue: D[q][key] with rows = q (from the LDS tile), cols = key (this lane's register fragment)
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(q_lds, qj * 16, 0, lane), kf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(q_lds, qj * 16, 1, lane), kf1, a, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(do_lds, qj * 16, 0, lane), vf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(do_lds, qj * 16, 1, lane), vf1, dp, 0, 0, 0);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_lds + qj * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_lds + qj * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int q = qt * 64 + qj * 16 + 4 * g + r;
+                bool vis = (q < Tq) && (key < Tk) && (!causal || key <= q + shift);
+                float pv = vis ? exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
+                p[qj][r] = pv;
+                ds[qj][r] = pv * (dp[r] - d4[r]) * SCALE;
+            }
+        }
+        const bf16x8 p0 = pack_frag(p[0], p[1]), p1 = pack_frag(p[2], p[3]);
+        const bf16x8 s0 = pack_frag(ds[0], ds[1]), s1 = pack_frag(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 0, dt * 16, lane), p0, adv[dt], 0, 0, 0);
+            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 1, dt * 16, lane), p1, adv[dt], 0, 0, 0);
+            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 0, dt * 16, lane), s0, adk[dt], 0, 0, 0);
+            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 1, dt * 16, lane), s1, adk[dt], 0, 0, 0);
+        }
+    }
+    if (key < Tk) {
+        bf16_t* pk_ = dK + (size_t)b * dk_bs + (size_t)key * dk_rs + h * 64;
+        bf16_t* pv_ = dV + (size_t)b * dv_bs + (size_t)key * dv_rs + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 a = {pack_bf16x2(adk[dt][0], adk[dt][1]), pack_bf16x2(adk[dt][2], adk[dt][3])};
+            u32x2 c = {pack_bf16x2(adv[dt][0], adv[dt][1]), pack_bf16x2(adv[dt][2], adv[dt][3])};
+            *reinterpret_cast<u32x2*>(pk_ + dt * 16 + 4 * g) = a;
+            *reinterpret_cast<u32x2*>(pv_ + dt * 16 + 4 * g) = c;
+        }
+    }
+}
+
+bool strides_ok(const void* p, long bs, int rs) { return p && ALIGNED16(p) && (bs % 8 == 0) && (rs % 8 == 0) && rs >= 64; }
+
+}  // namespace
+
+extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                                 const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse, int B,
+                                 int H, int Tq, int Tk, int causal) {
+    I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "i2t_attention_fwd: empty problem");
+    I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
+                    strides_ok(o, o_bs, o_rs),
+                "i2t_attention_fwd: operands must be 16-byte aligned with strides that are multiples of 8");
+    I2T_REQUIRE(!causal || Tk >= Tq, "i2t_attention_fwd: causal needs Tk >= Tq");
+    I2T_REQUIRE(H <= 65535 && B <= 65535, "i2t_attention_fwd: grid too large");
+    AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
+    dim3 grid((Tq + 63) / 64, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
+                       Tq, Tk, causal);
+    I2T_CHECK_LAUNCH("i2t_attention_fwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                                 const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
+                                 const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws, void* dq,
+                                 long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs, void* dv, long dv_bs, int dv_rs,
+                                 int B, int H, int Tq, int Tk, int causal) {
+    I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && lse && delta_ws, "i2t_attention_bwd: bad args");
+    I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
+                    strides_ok(o, o_bs, o_rs) && strides_ok(d_o, do_bs, do_rs) && strides_ok(dq, dq_bs, dq_rs) &&
+                    strides_ok(dk, dk_bs, dk_rs) && strides_ok(dv, dv_bs, dv_rs),
+                "i2t_attention_bwd: operands must be 16-byte aligned with strides that are multiples of 8");
+    I2T_REQUIRE(!causal || Tk >= Tq, "i2t_attention_bwd: causal needs Tk >= Tq");
+    hipStream_t s = (hipStream_t)stream;
+    AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
+    AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
+    const int total = B * H * Tq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)o, o_bs, o_rs,
+                       (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
+                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
+                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal);
+    I2T_CHECK_LAUNCH("i2t_attention_bwd");
+    return I2T_OK;
+}

@@ -1,0 +1,216 @@
+// Greedy-decode step kernels: everything position-dependent reads its position from DEVICE memory, so one captured
+// hipGraph replays unchanged for every generated token (static KV cache, no host round trip per token).
+#include "common.h"
+
+namespace {
+
+// x[b][:] = wte[ids[b][len-1]] + wpe[len-1+pos_offset]
+__global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restrict__ ids, int ids_ld,
+                                                         const int* __restrict__ len_ptr, const float* __restrict__ wte,
+                                                         const float* __restrict__ wpe, float* __restrict__ x, int d,
+                                                         int pos_offset, int vocab) {
+    const int b = blockIdx.x;
+    const int t = *len_ptr - 1;
+    long id = ids[(size_t)b * ids_ld + t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4* e = reinterpret_cast<const f32x4*>(wte + (size_t)id * d);
+    const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
+    f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)b * d);
+    for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c] + p[c];
+}
+
+// kcache[b][pos][:] = qkv[b][d:2d], vcache[b][pos][:] = qkv[b][2d:3d]
+__global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict__ qkv, int qkv_rs, bf16_t* __restrict__ kc,
+                                                        bf16_t* __restrict__ vc, long cache_bs, int cache_rs,
+                                                        const int* __restrict__ pos_ptr, int d) {
+    const int b = blockIdx.x, pos = *pos_ptr;
+    const u32x4* src = reinterpret_cast<const u32x4*>(qkv + (size_t)b * qkv_rs + d);
+    u32x4* kd = reinterpret_cast<u32x4*>(kc + (size_t)b * cache_bs + (size_t)pos * cache_rs);
+    u32x4* vd = reinterpret_cast<u32x4*>(vc + (size_t)b * cache_bs + (size_t)pos * cache_rs);
+    const int d8 = d >> 3;
+    for (int c = threadIdx.x; c < d8; c += 256) {
+        kd[c] = src[c];
+        vd[c] = src[d8 + c];
+    }
+}
+
+// one wave per (b, h): keys strided over lanes for the scores, head dims over lanes for the output
+constexpr int DEC_MAX_KEYS = 1024;
+__global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __restrict__ q, int q_rs,
+                                                              const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                              long cache_bs, int cache_rs, bf16_t* __restrict__ o, int o_rs,
+                                                              const int* __restrict__ pos_ptr, int n_keys_fixed) {
+    __shared__ float qs[64];
+    __shared__ float ps[DEC_MAX_KEYS];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int n = pos_ptr ? (*pos_ptr + 1) : n_keys_fixed;
+    qs[lane] = bf16_to_f32(q[(size_t)b * q_rs + h * 64 + lane]);
+    __syncthreads();
+    const bf16_t* kb = kc + (size_t)b * cache_bs + h * 64;
+    const bf16_t* vb = vc + (size_t)b * cache_bs + h * 64;
+    float mx = -INFINITY;
+    for (int key = lane; key < n; key += 64) {
+        const u32x4* kr = reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u32x4 kk = kr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(kk[e]) * qs[c * 8 + 2 * e] + bf16hi(kk[e]) * qs[c * 8 + 2 * e + 1];
+        }
+        s *= 0.125f;
+        ps[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int key = lane; key < n; key += 64) {
+        float p = __expf(ps[key] - mx);
+        ps[key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float acc = 0.f;
+    for (int key = 0; key < n; ++key) acc += ps[key] * bf16_to_f32(vb[(size_t)key * cache_rs + lane]);
+    o[(size_t)b * o_rs + h * 64 + lane] = f32_to_bf16(acc / sum);
+}
+
+// HF NoRepeatNGramLogitsProcessor + argmax for one caption per workgroup
+constexpr int BAN_THREADS = 1024;
+constexpr int MAX_BANNED = 1024;
+template <bool F32>
+__global__ __launch_bounds__(BAN_THREADS) void ngram_ban_argmax_kernel(const void* __restrict__ logits, int ld,
+                                                                       int64_t* __restrict__ ids, int ids_ld,
+                                                                       const int* __restrict__ len_ptr,
+                                                                       const int* __restrict__ ngram_sizes, int n_sizes,
+                                                                       int V, float* __restrict__ margin_out) {
+    __shared__ int banned[MAX_BANNED];
+    __shared__ int n_banned;
+    __shared__ float rv[BAN_THREADS / 64], rv2[BAN_THREADS / 64];
+    __shared__ int ri[BAN_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = *len_ptr;
+    int64_t* row = ids + (size_t)b * ids_ld;
+    if (tid == 0) n_banned = 0;
+    __syncthreads();
+    for (int si = 0; si < n_sizes; ++si) {
+        const int n = ngram_sizes[si];
+        if (n < 1 || len + 1 < n) continue;              // block-uniform
+        // candidate n-gram starts i in [0, len - n]; it repeats the current (n-1)-token tail iff ids[i+j] == ids[len-n+1+j]
+        for (int i = tid; i <= len - n; i += BAN_THREADS) {
+            bool same = true;
+            for (int j = 0; j < n - 1; ++j) same = same && (row[i + j] == row[len - n + 1 + j]);
+            if (same) {
+                int slot = atomicAdd(&n_banned, 1);
+                if (slot < MAX_BANNED) banned[slot] = (int)row[i + n - 1];
+            }
+        }
+    }
+    __syncthreads();
+    const int nb = min(n_banned, MAX_BANNED);
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < V; c += BAN_THREADS) {
+        float v = F32 ? reinterpret_cast<const float*>(logits)[(size_t)b * ld + c]
+                      : bf16_to_f32(reinterpret_cast<const bf16_t*>(logits)[(size_t)b * ld + c]);
+        for (int k = 0; k < nb; ++k)
+            if (banned[k] == c) v = -INFINITY;
+        if (v > best) {                                   // strided ascending scan: first index wins ties
+            second = best;
+            best = v;
+            bi = c;
+        } else if (v > second) {
+            second = v;
+        }
+    }
+    // wave reduce (value desc, index asc), tracking the runner-up for the margin
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            second = fmaxf(best, os);
+            best = ov;
+            bi = oi;
+        } else {
+            second = fmaxf(second, ov);
+        }
+    }
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) {
+        rv[w] = best;
+        rv2[w] = second;
+        ri[w] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < BAN_THREADS / 64; ++k) {
+            if (rv[k] > best || (rv[k] == best && ri[k] < bi)) {
+                second = fmaxf(best, rv2[k]);
+                best = rv[k];
+                bi = ri[k];
+            } else {
+                second = fmaxf(second, rv[k]);
+            }
+        }
+        row[len] = bi;
+        if (margin_out) margin_out[b] = best - second;
+    }
+}
+
+__global__ void advance_kernel(int* counter, int delta) { *counter += delta; }
+
+}  // namespace
+
+extern "C" int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
+                              const float* wpe, float* x, int B, int d, int pos_offset, int vocab) {
+    I2T_REQUIRE(ids && len_ptr && wte && wpe && x && B > 0 && d % 4 == 0, "i2t_embed_step: bad args");
+    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, ids_ld, len_ptr, wte, wpe, x, d,
+                       pos_offset, vocab);
+    I2T_CHECK_LAUNCH("i2t_embed_step");
+    return I2T_OK;
+}
+
+extern "C" int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kcache, void* vcache, long cache_bs,
+                             int cache_rs, const int* pos_ptr, int B, int d) {
+    I2T_REQUIRE(qkv && kcache && vcache && pos_ptr && B > 0 && d % 8 == 0 && qkv_rs % 8 == 0 && cache_rs % 8 == 0 &&
+                    cache_bs % 8 == 0,
+                "i2t_kv_append: bad args");
+    hipLaunchKernelGGL(kv_append_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qkv_rs,
+                       (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, pos_ptr, d);
+    I2T_CHECK_LAUNCH("i2t_kv_append");
+    return I2T_OK;
+}
+
+extern "C" int i2t_decode_attention(void* stream, const void* q, int q_rs, const void* kcache, const void* vcache,
+                                    long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
+                                    int B, int H) {
+    I2T_REQUIRE(q && kcache && vcache && o && B > 0 && H > 0, "i2t_decode_attention: bad args");
+    I2T_REQUIRE(pos_ptr || (n_keys_fixed > 0 && n_keys_fixed <= DEC_MAX_KEYS), "i2t_decode_attention: key count out of range");
+    I2T_REQUIRE(cache_rs % 8 == 0 && cache_bs % 8 == 0 && ALIGNED16(kcache) && ALIGNED16(vcache), "i2t_decode_attention: cache misaligned");
+    hipLaunchKernelGGL(decode_attention_kernel, dim3(H, B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed);
+    I2T_CHECK_LAUNCH("i2t_decode_attention");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, int logits_is_f32, int64_t* ids, int ids_ld,
+                                    int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V, float* margin_out) {
+    I2T_REQUIRE(logits && ids && len_ptr && B > 0 && V > 0 && (n_sizes == 0 || ngram_sizes), "i2t_ngram_ban_argmax: bad args");
+    if (logits_is_f32)
+        hipLaunchKernelGGL(ngram_ban_argmax_kernel<true>, dim3(B), dim3(BAN_THREADS), 0, (hipStream_t)stream, logits, ld, ids,
+                           ids_ld, len_ptr, ngram_sizes, n_sizes, V, margin_out);
+    else
+        hipLaunchKernelGGL(ngram_ban_argmax_kernel<false>, dim3(B), dim3(BAN_THREADS), 0, (hipStream_t)stream, logits, ld, ids,
+                           ids_ld, len_ptr, ngram_sizes, n_sizes, V, margin_out);
+    I2T_CHECK_LAUNCH("i2t_ngram_ban_argmax");
+    return I2T_OK;
+}
+
+extern "C" int i2t_advance(void* stream, int* counter, int delta) {
+    I2T_REQUIRE(counter, "i2t_advance: null counter");
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    I2T_CHECK_LAUNCH("i2t_advance");
+    return I2T_OK;
+}

@@ -1,0 +1,346 @@
+// HBM-bound pieces of the path: embeddings, weighted cross-entropy over bf16 logits, the gradient normaliser,
+// fused AdamW over a flat arena, casts and small strided copies.  All use 16-byte accesses per lane and
+// 64-lane shuffle reductions; cross-workgroup sums use one float atomic per workgroup (cdna guide, Guideline 12).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- embeddings
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ wte,
+                                                        const float* __restrict__ wpe, float* __restrict__ x, int T,
+                                                        int d, int pos_offset, int vocab, int rows) {
+    const int d4 = d >> 2;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int t = row % T;
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4* e = reinterpret_cast<const f32x4*>(wte + (size_t)id * d);
+        const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
+        f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)row * d);
+        for (int c = threadIdx.x; c < d4; c += 256) o[c] = e[c] + p[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                            float* __restrict__ dwte, int d, int vocab, int rows) {
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float* g = dx + (size_t)row * d;
+        float* o = dwte + (size_t)id * d;
+        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);   // 256 contiguous bytes per wave-instr
+    }
+}
+
+// dst[r][:] (+)= sum_b x[b][r][:]   (one thread per float4 column chunk of a row; loops over the batch)
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __restrict__ x, long x_bs,
+                                                             float* __restrict__ dst, int B, int rows, int d,
+                                                             int accumulate) {
+    const int d4 = d >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * d4) return;
+    const int r = (int)(idx / d4), c = (int)(idx % d4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) s += reinterpret_cast<const f32x4*>(x + (size_t)b * x_bs + (size_t)r * d)[c];
+    f32x4* o = reinterpret_cast<f32x4*>(dst + (size_t)r * d) + c;
+    if (accumulate) s += *o;
+    *o = s;
+}
+
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ src, float* __restrict__ y, long y_bs,
+                                                         int rows, int d) {
+    const int d4 = d >> 2;
+    const int b = blockIdx.y;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * d4; idx += (long)gridDim.x * 256)
+        reinterpret_cast<f32x4*>(y + (size_t)b * y_bs)[idx] = reinterpret_cast<const f32x4*>(src)[idx];
+}
+
+template <bool Y_BF16>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ x, long x_bs, void* __restrict__ y,
+                                                        long y_bs, int rows, int d) {
+    const int d4 = d >> 2;
+    const int b = blockIdx.y;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * d4; idx += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)b * x_bs)[idx];
+        if (Y_BF16) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + (size_t)b * y_bs)[idx] = pk;
+        } else {
+            reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + (size_t)b * y_bs)[idx] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        reinterpret_cast<f32x4*>(dst)[i] += reinterpret_cast<const f32x4*>(src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] += src[n4 * 4 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        u32x4 pk = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+        reinterpret_cast<u32x4*>(dst)[i] = pk;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f32_to_bf16(src[n8 * 8 + threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------- cross entropy
+// one workgroup per row; V bf16 logits are read once with an online (max, sum) per thread, combined across the block
+constexpr int CE_THREADS = 512;
+
+__device__ __forceinline__ void online_add(float& m, float& s, float v) {
+    if (v > m) {
+        s = s * __expf(m - v) + 1.f;
+        m = v;
+    } else {
+        s += __expf(v - m);
+    }
+}
+
+__device__ __forceinline__ float row_lse(const bf16_t* row, int V, float inv_temp, float* red) {
+    float m = -INFINITY, s = 0.f;
+    const int v8 = V >> 3;
+    for (int c = threadIdx.x; c < v8; c += CE_THREADS) {
+        u32x4 pk = reinterpret_cast<const u32x4*>(row)[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            online_add(m, s, bf16lo(pk[e]) * inv_temp);
+            online_add(m, s, bf16hi(pk[e]) * inv_temp);
+        }
+    }
+    for (int c = v8 * 8 + threadIdx.x; c < V; c += CE_THREADS) online_add(m, s, bf16_to_f32(row[c]) * inv_temp);
+    const float bm = block_max(m, red);
+    const float part = (m == -INFINITY) ? 0.f : s * __expf(m - bm);
+    const float bs = block_sum(part, red);
+    return bm + __logf(bs);
+}
+
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const bf16_t* __restrict__ logits, int ld,
+                                                            const int64_t* __restrict__ labels, const float* __restrict__ w,
+                                                            float inv_temp, int64_t ignore_index, float* __restrict__ lse,
+                                                            float* __restrict__ loss, int V) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int64_t lab = labels[row];
+    if (lab == ignore_index || lab < 0 || lab >= V) {   // block-uniform
+        if (threadIdx.x == 0) lse[row] = 0.f;
+        return;
+    }
+    const bf16_t* r = logits + (size_t)row * ld;
+    const float l = row_lse(r, V, inv_temp, red);
+    if (threadIdx.x == 0) {
+        lse[row] = l;
+        atomicAdd(loss, w[row] * (l - bf16_to_f32(r[lab]) * inv_temp));
+    }
+}
+
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(bf16_t* __restrict__ logits, int ld,
+                                                            const int64_t* __restrict__ labels, const float* __restrict__ w,
+                                                            float inv_temp, int64_t ignore_index, const float* __restrict__ lse,
+                                                            const float* __restrict__ gscale_ptr, int V) {
+    const int row = blockIdx.x;
+    const int64_t lab = labels[row];
+    bf16_t* r = logits + (size_t)row * ld;
+    const bool live = !(lab == ignore_index || lab < 0 || lab >= V);
+    const float coef = live ? (*gscale_ptr) * w[row] * inv_temp : 0.f;
+    const float l = live ? lse[row] : 0.f;
+    const int v8 = V >> 3;
+    for (int c = threadIdx.x; c < v8; c += CE_THREADS) {
+        u32x4 pk = reinterpret_cast<u32x4*>(r)[c];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = c * 8 + 2 * e;
+            float a = coef * (__expf(bf16lo(pk[e]) * inv_temp - l) - (col == lab ? 1.f : 0.f));
+            float b = coef * (__expf(bf16hi(pk[e]) * inv_temp - l) - (col + 1 == lab ? 1.f : 0.f));
+            o[e] = live ? pack_bf16x2(a, b) : 0u;
+        }
+        reinterpret_cast<u32x4*>(r)[c] = o;
+    }
+    for (int c = v8 * 8 + threadIdx.x; c < V; c += CE_THREADS) {
+        float a = coef * (__expf(bf16_to_f32(r[c]) * inv_temp - l) - (c == lab ? 1.f : 0.f));
+        r[c] = live ? f32_to_bf16(a) : (bf16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- gradient normaliser
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ ws) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float t = g[n4 * 4 + threadIdx.x];
+        s += t * t;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(ws, s);
+}
+
+__global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ g, long n4, long n, const float* __restrict__ ws) {
+    const float inv = 1.0f / (sqrtf(*ws) + 1e-6f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(g)[i] *= inv;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[n4 * 4 + threadIdx.x] *= inv;
+}
+
+// ---------------------------------------------------------------------------------------------- AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ pb, long n, const long* __restrict__ seg_end,
+                                                    const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
+                                                    int nseg, float beta1, float beta2, float eps, float bc1, float bc2s,
+                                                    float grad_scale) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e0 = i * 4;
+        int lo = 0, hi = nseg - 1;            // first segment whose end > e0 (segments are 4-element aligned)
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (seg_end[mid] > e0) hi = mid; else lo = mid + 1;
+        }
+        const float lr = seg_lr[lo], wd = seg_wd[lo];
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gv[e] * grad_scale;
+            pv[e] *= (1.f - lr * wd);
+            mv[e] = beta1 * mv[e] + (1.f - beta1) * gr;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2s + eps;
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (pb) {
+            u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+            reinterpret_cast<u32x2*>(pb)[i] = pk;
+        }
+    }
+}
+
+int grid_for(long work_items, int cap = 2048) {
+    long b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte, const float* wpe, float* x, int B, int T,
+                             int d, int pos_offset, int vocab) {
+    I2T_REQUIRE(ids && wte && wpe && x && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_fwd: bad args");
+    const int rows = B * T;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, ids, wte, wpe, x,
+                       T, d, pos_offset, vocab, rows);
+    I2T_CHECK_LAUNCH("i2t_embed_fwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dwte, float* dwpe, int B, int T,
+                             int d, int pos_offset, int vocab) {
+    I2T_REQUIRE(ids && dx && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_bwd: bad args");
+    const int rows = B * T;
+    hipStream_t s = (hipStream_t)stream;
+    if (dwte)
+        hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, ids, dx, dwte, d, vocab, rows);
+    if (dwpe) {
+        const long items = (long)T * (d >> 2);
+        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((items + 255) / 256), dim3(256), 0, s, dx, (long)T * d,
+                           dwpe + (size_t)pos_offset * d, B, T, d, 1);
+    }
+    I2T_CHECK_LAUNCH("i2t_embed_bwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_sum_over_batch(void* stream, const float* x, long x_batch_stride, float* dst, int B, int rows, int d,
+                                  int accumulate) {
+    I2T_REQUIRE(x && dst && B > 0 && rows > 0 && d % 4 == 0 && x_batch_stride % 4 == 0, "i2t_sum_over_batch: bad args");
+    const long items = (long)rows * (d >> 2);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride,
+                       dst, B, rows, d, accumulate);
+    I2T_CHECK_LAUNCH("i2t_sum_over_batch");
+    return I2T_OK;
+}
+
+extern "C" int i2t_bcast_rows(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d) {
+    I2T_REQUIRE(src && y && B > 0 && rows > 0 && d % 4 == 0 && y_batch_stride % 4 == 0, "i2t_bcast_rows: bad args");
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for((long)rows * (d >> 2), 64), B), dim3(256), 0, (hipStream_t)stream, src,
+                       y, y_batch_stride, rows, d);
+    I2T_CHECK_LAUNCH("i2t_bcast_rows");
+    return I2T_OK;
+}
+
+extern "C" int i2t_copy_rows(void* stream, const float* x, long x_bs, void* y, long y_bs, int y_is_bf16, int B, int rows,
+                             int d) {
+    I2T_REQUIRE(x && y && B > 0 && rows > 0 && d % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0, "i2t_copy_rows: bad args");
+    dim3 grid(grid_for((long)rows * (d >> 2), 64), B);
+    if (y_is_bf16) hipLaunchKernelGGL(copy_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, y, y_bs, rows, d);
+    else hipLaunchKernelGGL(copy_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, y, y_bs, rows, d);
+    I2T_CHECK_LAUNCH("i2t_copy_rows");
+    return I2T_OK;
+}
+
+extern "C" int i2t_add_f32(void* stream, float* dst, const float* src, long n) {
+    I2T_REQUIRE(dst && src && n > 0 && ALIGNED16(dst) && ALIGNED16(src), "i2t_add_f32: bad args");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, dst, src, n >> 2, n);
+    I2T_CHECK_LAUNCH("i2t_add_f32");
+    return I2T_OK;
+}
+
+extern "C" int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n) {
+    I2T_REQUIRE(src && dst && n > 0 && ALIGNED16(src) && ALIGNED16(dst), "i2t_cast_f32_bf16: bad args");
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    I2T_CHECK_LAUNCH("i2t_cast_f32_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ce_fwd(void* stream, const void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+                          int64_t ignore_index, float* lse, float* loss, int M, int V) {
+    I2T_REQUIRE(logits && labels && w && lse && loss && M > 0 && V > 0, "i2t_ce_fwd: bad args");
+    I2T_REQUIRE(ld % 8 == 0 && ld >= V && ALIGNED16(logits), "i2t_ce_fwd: ld=%d must be a multiple of 8 and >= V", ld);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, labels, w,
+                       inv_temp, ignore_index, lse, loss, V);
+    I2T_CHECK_LAUNCH("i2t_ce_fwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+                          int64_t ignore_index, const float* lse, const float* gscale_ptr, int M, int V) {
+    I2T_REQUIRE(logits && labels && w && lse && gscale_ptr && M > 0 && V > 0, "i2t_ce_bwd: bad args");
+    I2T_REQUIRE(ld % 8 == 0 && ld >= V && ALIGNED16(logits), "i2t_ce_bwd: ld=%d must be a multiple of 8 and >= V", ld);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, w,
+                       inv_temp, ignore_index, lse, gscale_ptr, V);
+    I2T_CHECK_LAUNCH("i2t_ce_bwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws) {
+    I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_grad_normalize: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
+    if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+    const int grid = grid_for(n >> 2, 1024);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
+    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws);
+    I2T_CHECK_LAUNCH("i2t_grad_normalize");
+    return I2T_OK;
+}
+
+extern "C" int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+                              const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
+                              float beta2, float eps, int step, float grad_scale) {
+    I2T_REQUIRE(p && g && m && v && seg_end && seg_lr && seg_wd && nseg > 0 && n > 0 && step > 0, "i2t_adamw_step: bad args");
+    I2T_REQUIRE(n % 4 == 0 && ALIGNED16(p) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v), "i2t_adamw_step: arena must be 16-byte aligned, n %% 4 == 0");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                       n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    I2T_CHECK_LAUNCH("i2t_adamw_step");
+    return I2T_OK;
+}

@@ -1,0 +1,316 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues (bias, GELU / GELU', residual, accumulate, bf16|f32 store).
+//
+//   C[M,N] = epilogue(alpha * op(A)[M,K] . op(B)[K,N])
+//
+// Tile 128 x 128 x 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x 64 = 4x4 MFMA 16x16x32 tiles
+// (64 accumulator VGPRs).  Operands are staged global -> VGPR -> LDS (issue-early / write-late, double-buffered
+// LDS, one barrier per K-step) in one of two LDS images:
+//   R  image (reduction index contiguous in memory):  tile[r][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by
+//            (r & 7); fragments are one ds_read_b128 each (conflict-free: cdna_hip_programming.md T2).
+//   Cf image (reduction index is the row index):       tile[64 k][128 r] bf16, 288-B rows (32-B pad = 8 banks per
+//            k-row, so the 8 k-rows x 4 column quads a half-wave touches cover 64 distinct banks); fragments are
+//            two ds_read_b64_tr_b16 each (T10) -- this is what lets dX = dY.W and dW = dY^T.X run without any
+//            transposed copy of weights or activations in HBM.
+// The MFMA is issued "swapped" (weight-side fragment as the A operand, activation-side as B) so that a lane ends
+// up holding 4 CONSECUTIVE output columns of one output row: the epilogue reads bias/residual and stores C as one
+// 8-/16-byte vector per lane.
+// Block -> tile map is XCD-aware (8 XCDs, private L2s): blocks that share an XCD walk consecutive M-tiles of the
+// same N panel, so a weight panel is fetched into one L2 instead of eight.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int R_ROW_BYTES = 128;                 // 64 bf16
+constexpr int CF_ROW_BYTES = 288;                // 128 bf16 + 32 B pad
+constexpr int OPERAND_BYTES = 64 * CF_ROW_BYTES; // 18432 >= 128 * 128 (R image 16384)
+constexpr int STAGE_BYTES = 2 * OPERAND_BYTES;   // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // double buffer: 73728
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    float alpha;
+    const float* bias;
+    int act;
+    const bf16_t* aux_in;
+    int ld_aux_in;
+    bf16_t* aux_out;
+    int ld_aux_out;
+    const float* residual;
+    int ldr;
+    int c_is_f32;
+    int accumulate;
+    int tiles_m, tiles_n;
+};
+
+// One operand's staging registers: 4 x 16-byte chunks per thread per K-step.
+struct Stage {
+    u32x4 v[4];
+};
+
+// KMAJOR=false: memory is [rows][K] (K contiguous);  KMAJOR=true: memory is [K][rows] (rows contiguous)
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_load(Stage& s, const bf16_t* __restrict__ base, int ld, int row0, int rows,
+                                           int k0, int K, int tid) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int c = tid + 256 * u;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (!KMAJOR) {
+            int r = c >> 3, kc = c & 7;
+            int gr = row0 + r, gk = k0 + kc * 8;
+            if (gr < rows && gk < K) val = *reinterpret_cast<const u32x4*>(base + (size_t)gr * ld + gk);
+        } else {
+            int kr = c >> 4, rc = c & 15;
+            int gk = k0 + kr, gr = row0 + rc * 8;
+            if (gk < K && gr < rows) val = *reinterpret_cast<const u32x4*>(base + (size_t)gk * ld + gr);
+        }
+        s.v[u] = val;
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_store(const Stage& s, unsigned char* lds, int tid) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int c = tid + 256 * u;
+        int off;
+        if (!KMAJOR) {
+            int r = c >> 3, kc = c & 7;
+            off = r * R_ROW_BYTES + ((kc ^ (r & 7)) << 4);
+        } else {
+            int kr = c >> 4, rc = c & 15;
+            off = kr * CF_ROW_BYTES + (rc << 4);
+        }
+        *reinterpret_cast<u32x4*>(lds + off) = s.v[u];
+    }
+}
+
+// Fragment of 16 rows starting at r0 for k-substep ks (32 wide): lane (g = lane>>4, i = lane&15) gets
+// tile[r0 + i][32 ks + 8 g + 0..7].
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!KMAJOR) {
+        int r = r0 + i;
+        int kc = ks * 4 + g;
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * R_ROW_BYTES + ((kc ^ (r & 7)) << 4));
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        const int q = i >> 2, p = i & 3;
+        const unsigned char* a0 = lds + (ks * 32 + 8 * g + q) * CF_ROW_BYTES + (r0 + 4 * p) * 2;
+        s16x4 lo = lds_read_tr16(a0);
+        s16x4 hi = lds_read_tr16(a0 + 4 * CF_ROW_BYTES);
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware, bijective remap of the 1-D grid (cdna_hip_programming.md 5, "XCD swizzle must be bijective")
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // rows of an M/N-contiguous (k-major) operand may be read up to the next multiple of 8 (inside ld)
+    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
+    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
+    const int nk = (p.K + BK - 1) / BK;
+
+    Stage sa, sb;
+    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, 0, p.K, tid);
+    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, 0, p.K, tid);
+    stage_store<A_KMAJOR>(sa, smem, tid);
+    stage_store<B_KMAJOR>(sb, smem + OPERAND_BYTES, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* la = smem + (t & 1) * STAGE_BYTES;
+        const unsigned char* lb = la + OPERAND_BYTES;
+        const bool more = (t + 1) < nk;
+        if (more) {   // issue the next tile's global loads before the MFMA phase (T14)
+            stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, (t + 1) * BK, p.K, tid);
+            stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, (t + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KMAJOR>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KMAJOR>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            unsigned char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
+            stage_store<A_KMAJOR>(sa, na, tid);
+            stage_store<B_KMAJOR>(sb, na + OPERAND_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
+    const int g = lane >> 4, li = lane & 15;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n4 >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nv) v[r] += p.bias[n4 + r];
+            }
+            if (p.aux_out) {
+                bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
+                if (nv == 4 && (p.ld_aux_out & 3) == 0) {
+                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(ao) = pk;
+                } else {
+                    for (int r = 0; r < nv; ++r) ao[r] = f32_to_bf16(v[r]);
+                }
+            }
+            if (p.act == I2T_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+            } else if (p.act == I2T_ACT_DGELU) {
+                const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
+            }
+            if (p.residual) {
+                const float* rr = p.residual + (size_t)m * p.ldr + n4;
+                if (nv == 4 && vec_ok) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += t[r];
+                } else {
+                    for (int r = 0; r < nv; ++r) v[r] += rr[r];
+                }
+            }
+            if (p.c_is_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n4;
+                if (nv == 4 && vec_ok) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(c);
+                        o += t;
+                    }
+                    *reinterpret_cast<f32x4*>(c) = o;
+                } else {
+                    for (int r = 0; r < nv; ++r) c[r] = p.accumulate ? c[r] + v[r] : v[r];
+                }
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n4;
+                if (nv == 4 && vec_ok) {
+                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(c) = pk;
+                } else {
+                    for (int r = 0; r < nv; ++r) c[r] = f32_to_bf16(v[r]);
+                }
+            }
+        }
+    }
+}
+
+// out[n] (+)= sum_m X[m][n]; one block per 64 columns, 4 waves stride the rows, lanes own columns
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
+                                                     float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    if (n < N)
+        for (int m = r0 + w; m < r1; m += 4) s += bf16_to_f32(X[(size_t)m * ld + n]);
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N) {
+        float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (gridDim.y == 1 && !accumulate) out[n] = t;
+        else atomicAdd(out + n, t);
+    }
+}
+
+}  // namespace
+
+extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor, const void* B, int ldb,
+                             int b_kmajor, void* C, int ldc, int c_is_f32, int M, int N, int K, float alpha,
+                             const float* bias, int act, const void* aux_in, int ld_aux_in, void* aux_out,
+                             int ld_aux_out, const float* residual, int ldr, int accumulate) {
+    I2T_REQUIRE(A && B && C, "i2t_gemm_bf16: null operand");
+    I2T_REQUIRE(M > 0 && N > 0 && K > 0, "i2t_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+    // K need not be a multiple of 8, but an operand whose reduction index is contiguous is then read up to the
+    // next multiple of 8 inside its leading dimension: the caller keeps those pad elements ZERO.
+    I2T_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "i2t_gemm_bf16: lda=%d ldb=%d must be multiples of 8", lda, ldb);
+    I2T_REQUIRE(ALIGNED16(A) && ALIGNED16(B), "i2t_gemm_bf16: A/B must be 16-byte aligned");
+    I2T_REQUIRE(lda >= (a_kmajor ? ((M + 7) & ~7) : ((K + 7) & ~7)), "i2t_gemm_bf16: lda=%d too small", lda);
+    I2T_REQUIRE(ldb >= (b_kmajor ? ((N + 7) & ~7) : ((K + 7) & ~7)), "i2t_gemm_bf16: ldb=%d too small", ldb);
+    I2T_REQUIRE(ldc >= N, "i2t_gemm_bf16: ldc=%d < N=%d", ldc, N);
+    I2T_REQUIRE(!accumulate || c_is_f32, "i2t_gemm_bf16: accumulate needs an f32 C");
+    I2T_REQUIRE(act != I2T_ACT_DGELU || aux_in, "i2t_gemm_bf16: DGELU needs aux_in");
+    I2T_REQUIRE(((uintptr_t)C & (c_is_f32 ? 15 : 7)) == 0, "i2t_gemm_bf16: C misaligned");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.bias = bias; p.act = act;
+    p.aux_in = (const bf16_t*)aux_in; p.ld_aux_in = ld_aux_in;
+    p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
+    p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+    I2T_CHECK_LAUNCH("i2t_gemm_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate) {
+    I2T_REQUIRE(X && out && M > 0 && N > 0, "i2t_colsum_bf16: bad args");
+    int splits = M >= 4096 ? 16 : (M >= 512 ? 4 : 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (splits > 1 && !accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+        if (e != hipSuccess) { i2t_set_error("i2t_colsum_bf16: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+    }
+    dim3 grid((N + 63) / 64, splits);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out, accumulate);
+    I2T_CHECK_LAUNCH("i2t_colsum_bf16");
+    return I2T_OK;
+}

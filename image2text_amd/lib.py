@@ -1,0 +1,82 @@
+"""ctypes binding of libi2t_hip.so (include/i2t.h).  Loading fails loudly: there is no fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libi2t_hip.so')
+
+P, I, L, F, I64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64
+
+# name -> argtypes, in the order of include/i2t.h
+SIGNATURES = {
+    'i2t_abi_version': [],
+    'i2t_last_error': [C.c_char_p, C.c_size_t],
+    'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I],
+    'i2t_colsum_bf16': [P, P, I, I, I, P, I],
+    'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
+    'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, I, I],
+    'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
+    'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
+    'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I],
+    'i2t_attention_bwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I],
+    'i2t_embed_fwd': [P, P, P, P, P, I, I, I, I, I],
+    'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I],
+    'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
+    'i2t_ce_bwd': [P, P, I, P, P, F, I64, P, P, I, I],
+    'i2t_grad_normalize': [P, P, L, P],
+    'i2t_conv_fwd': [P, P, I, I, P, P, P, P, I, I, I, I, I, I],
+    'i2t_conv_bwd_data': [P, P, P, P, I, P, P, I, I, I, I, I, I],
+    'i2t_conv_bwd_weight': [P, P, P, I, I, P, P, I, I, I, I, I, I],
+    'i2t_cast_f32_bf16': [P, P, P, L],
+    'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
+    'i2t_bcast_rows': [P, P, P, L, I, I, I],
+    'i2t_sum_over_batch': [P, P, L, P, I, I, I, I],
+    'i2t_copy_rows': [P, P, L, P, L, I, I, I, I],
+    'i2t_add_f32': [P, P, P, L],
+    'i2t_decode_attention': [P, P, I, P, P, L, I, P, I, P, I, I, I],
+    'i2t_kv_append': [P, P, I, P, P, L, I, P, I, I],
+    'i2t_ngram_ban_argmax': [P, P, I, I, P, I, P, P, I, I, I, P],
+    'i2t_embed_step': [P, P, I, P, P, P, P, I, I, I, I],
+    'i2t_advance': [P, P, I],
+    'i2t_graph_capture_begin': [P],
+    'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
+    'i2t_graph_launch': [P, P],
+    'i2t_graph_destroy': [P],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class I2TError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise if it is missing (build with ``python -m image2text_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise I2TError(f'{LIB_PATH} not found: the HIP extension is required (python -m image2text_amd.build); '
+                       'there is no CPU or eager fallback for the hot path')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.i2t_abi_version() != ABI_VERSION:
+        raise I2TError(f'ABI version mismatch: library {lib.i2t_abi_version()} vs binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().i2t_last_error(buf, 512)
+    return buf.value.decode(errors='replace')
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        raise I2TError(f'{what or "i2t call"} failed (rc={rc}): {last_error()}')

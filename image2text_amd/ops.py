@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI: pointer/stride marshalling only, one function per entry point.
+
+PyTorch supplies device memory and the current HIP stream; every op below launches hand-written gfx950 kernels
+through ``libi2t_hip.so`` and raises ``I2TError`` on any failure (no fallback).
+"""
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _lib():
+    return _l.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.I2TError('image2text_amd ops need tensors on the MI355X (cuda) device; there is no CPU path')
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
+         lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
+         ldr=None, accumulate=False):
+    """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16."""
+    _need_cuda(a, b, out)
+    assert a.dtype == BF16 and b.dtype == BF16 and out.dtype in (BF16, F32)
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    ld_ai = aux_in.stride(0) if aux_in is not None else 0
+    ld_ao = aux_out.stride(0) if aux_out is not None else 0
+    ldr = (residual.stride(0) if residual is not None else 0) if ldr is None else ldr
+    _l.check(_lib().i2t_gemm_bf16(_stream(), _p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc,
+                                  int(out.dtype == F32), M, N, K, float(alpha), _p(bias), int(act), _p(aux_in), ld_ai,
+                                  _p(aux_out), ld_ao, _p(residual), ldr, int(accumulate)), 'i2t_gemm_bf16')
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumulate=False):
+    _need_cuda(x, out)
+    _l.check(_lib().i2t_colsum_bf16(_stream(), _p(x), x.stride(0) if ld is None else ld, M, N, _p(out), int(accumulate)),
+             'i2t_colsum_bf16')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d):
+    _need_cuda(x, y)
+    _l.check(_lib().i2t_layernorm_fwd(_stream(), _p(x), _p(gamma), _p(beta), _p(y), int(y.dtype == F32), _p(mean), _p(rstd),
+                                      M, d), 'i2t_layernorm_fwd')
+    return y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False):
+    _need_cuda(dy, x, dx)
+    _l.check(_lib().i2t_layernorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
+                                      int(dx_accumulate), _p(dgamma), _p(dbeta), M, d), 'i2t_layernorm_bwd')
+    return dx
+
+
+LNND_STATS_STRIDE = 34
+
+
+def layernorm_nd_fwd(x, add, gamma, beta, y, y_batch_stride, stats, B, rows, d):
+    _need_cuda(x, y, stats)
+    _l.check(_lib().i2t_layernorm_nd_fwd(_stream(), _p(x), _p(add), _p(gamma), _p(beta), _p(y), y_batch_stride, _p(stats), B,
+                                         rows, d), 'i2t_layernorm_nd_fwd')
+    return y
+
+
+def layernorm_nd_bwd(dy, dy_batch_stride, x, add, gamma, stats, dx, dgamma, dbeta, dadd, B, rows, d):
+    _need_cuda(dy, x, dx)
+    _l.check(_lib().i2t_layernorm_nd_bwd(_stream(), _p(dy), dy_batch_stride, _p(x), _p(add), _p(gamma), _p(stats), _p(dx),
+                                         _p(dgamma), _p(dbeta), _p(dadd), B, rows, d), 'i2t_layernorm_nd_bwd')
+    return dx
+
+
+def _bs_rs(t: torch.Tensor):
+    """(batch stride, row stride) in elements of a [B, T, *] view whose last dim is contiguous."""
+    assert t.stride(-1) == 1
+    return t.stride(0), t.stride(1)
+
+
+def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal):
+    """q,k,v,o: bf16 [B, T, >=64H] views (last dim contiguous; heads at 64-column steps)."""
+    _need_cuda(q, k, v, o)
+    qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o)
+    _l.check(_lib().i2t_attention_fwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(lse), B, H, Tq,
+                                      Tk, int(causal)), 'i2t_attention_fwd')
+    return o
+
+
+def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal):
+    _need_cuda(q, k, v, o, do, dq, dk, dv)
+    qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
+    dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
+    _l.check(_lib().i2t_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
+                                      _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
+                                      int(causal)), 'i2t_attention_bwd')
+
+
+def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab):
+    _need_cuda(ids, wte, x)
+    _l.check(_lib().i2t_embed_fwd(_stream(), _p(ids), _p(wte), _p(wpe), _p(x), B, T, d, pos_offset, vocab), 'i2t_embed_fwd')
+    return x
+
+
+def embed_bwd(ids, dx, dwte, dwpe, B, T, d, pos_offset, vocab):
+    _need_cuda(ids, dx)
+    _l.check(_lib().i2t_embed_bwd(_stream(), _p(ids), _p(dx), _p(dwte), _p(dwpe), B, T, d, pos_offset, vocab), 'i2t_embed_bwd')
+
+
+def ce_fwd(logits, ld, labels, w, inv_temp, ignore_index, lse, loss, M, V):
+    _need_cuda(logits, labels, w, lse, loss)
+    _l.check(_lib().i2t_ce_fwd(_stream(), _p(logits), ld, _p(labels), _p(w), float(inv_temp), int(ignore_index), _p(lse),
+                               _p(loss), M, V), 'i2t_ce_fwd')
+
+
+def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
+    _need_cuda(logits, labels, w, lse, gscale)
+    _l.check(_lib().i2t_ce_bwd(_stream(), _p(logits), ld, _p(labels), _p(w), float(inv_temp), int(ignore_index), _p(lse),
+                               _p(gscale), M, V), 'i2t_ce_bwd')
+
+
+def grad_normalize(g: torch.Tensor, ws: torch.Tensor):
+    _need_cuda(g, ws)
+    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws)), 'i2t_grad_normalize')
+    return g
+
+
+def conv_fwd(x, in_gelu, w, bias, y, w_ws, B, Cin, Cout, H, W, k):
+    _need_cuda(x, w, y, w_ws)
+    _l.check(_lib().i2t_conv_fwd(_stream(), _p(x), int(x.dtype == F32), int(in_gelu), _p(w), _p(bias), _p(y), _p(w_ws), B, Cin,
+                                 Cout, H, W, k), 'i2t_conv_fwd')
+    return y
+
+
+def conv_bwd_data(dy, w, x_pre, in_gelu, dx, w_ws, B, Cin, Cout, H, W, k):
+    _need_cuda(dy, w, dx, w_ws)
+    _l.check(_lib().i2t_conv_bwd_data(_stream(), _p(dy), _p(w), _p(x_pre), int(in_gelu), _p(dx), _p(w_ws), B, Cin, Cout, H, W,
+                                      k), 'i2t_conv_bwd_data')
+    return dx
+
+
+def conv_bwd_weight(dy, x, in_gelu, dw, db, B, Cin, Cout, H, W, k):
+    _need_cuda(dy, x, dw)
+    _l.check(_lib().i2t_conv_bwd_weight(_stream(), _p(dy), _p(x), int(x.dtype == F32), int(in_gelu), _p(dw), _p(db), B, Cin,
+                                        Cout, H, W, k), 'i2t_conv_bwd_weight')
+
+
+def cast_f32_bf16(src, dst, n=None):
+    _need_cuda(src, dst)
+    _l.check(_lib().i2t_cast_f32_bf16(_stream(), _p(src), _p(dst), src.numel() if n is None else n), 'i2t_cast_f32_bf16')
+    return dst
+
+
+def adamw_step(p, g, m, v, p_bf16, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale=1.0):
+    _need_cuda(p, g, m, v)
+    _l.check(_lib().i2t_adamw_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(seg_end), _p(seg_lr), _p(seg_wd),
+                                   nseg, float(beta1), float(beta2), float(eps), int(step), float(grad_scale)),
+             'i2t_adamw_step')
+
+
+def bcast_rows(src, y, y_batch_stride, B, rows, d):
+    _l.check(_lib().i2t_bcast_rows(_stream(), _p(src), _p(y), y_batch_stride, B, rows, d), 'i2t_bcast_rows')
+
+
+def sum_over_batch(x, x_batch_stride, dst, B, rows, d, accumulate=False):
+    _l.check(_lib().i2t_sum_over_batch(_stream(), _p(x), x_batch_stride, _p(dst), B, rows, d, int(accumulate)),
+             'i2t_sum_over_batch')
+
+
+def copy_rows(x, x_bs, y, y_bs, B, rows, d):
+    _l.check(_lib().i2t_copy_rows(_stream(), _p(x), x_bs, _p(y), y_bs, int(y.dtype == BF16), B, rows, d), 'i2t_copy_rows')
+
+
+def add_(dst, src):
+    _l.check(_lib().i2t_add_f32(_stream(), _p(dst), _p(src), dst.numel()), 'i2t_add_f32')
+    return dst
+
+
+def decode_attention(q, q_rs, kcache, vcache, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H):
+    _l.check(_lib().i2t_decode_attention(_stream(), _p(q), q_rs, _p(kcache), _p(vcache), cache_bs, cache_rs, _p(o), o_rs,
+                                         _p(pos), n_keys_fixed, B, H), 'i2t_decode_attention')
+
+
+def kv_append(qkv, qkv_rs, kcache, vcache, cache_bs, cache_rs, pos, B, d):
+    _l.check(_lib().i2t_kv_append(_stream(), _p(qkv), qkv_rs, _p(kcache), _p(vcache), cache_bs, cache_rs, _p(pos), B, d),
+             'i2t_kv_append')
+
+
+def ngram_ban_argmax(logits, ld, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, V, margin_out=None):
+    _l.check(_lib().i2t_ngram_ban_argmax(_stream(), _p(logits), ld, int(logits.dtype == F32), _p(ids), ids_ld, _p(len_ptr),
+                                         _p(ngram_sizes), n_sizes, B, V, _p(margin_out)), 'i2t_ngram_ban_argmax')
+
+
+def embed_step(ids, ids_ld, len_ptr, wte, wpe, x, B, d, pos_offset, vocab):
+    _l.check(_lib().i2t_embed_step(_stream(), _p(ids), ids_ld, _p(len_ptr), _p(wte), _p(wpe), _p(x), B, d, pos_offset, vocab),
+             'i2t_embed_step')
+
+
+def advance(counter, delta=1):
+    _l.check(_lib().i2t_advance(_stream(), _p(counter), delta), 'i2t_advance')
+
+
+class Graph:
+    """hipGraph captured from the launches issued between ``begin()`` and ``end()`` on the current stream."""
+
+    def __init__(self):
+        self._exec = None
+        self._stream = None
+
+    def begin(self):
+        self._stream = torch.cuda.current_stream().cuda_stream
+        _l.check(_lib().i2t_graph_capture_begin(self._stream), 'i2t_graph_capture_begin')
+
+    def end(self):
+        import ctypes as C
+        h = C.c_void_p()
+        _l.check(_lib().i2t_graph_capture_end(self._stream, C.byref(h)), 'i2t_graph_capture_end')
+        self._exec = h
+
+    def launch(self):
+        _l.check(_lib().i2t_graph_launch(self._exec, torch.cuda.current_stream().cuda_stream), 'i2t_graph_launch')
+
+    def __del__(self):
+        if self._exec is not None:
+            try:
+                _lib().i2t_graph_destroy(self._exec)
+            except Exception:
+                pass

@@ -1,0 +1,201 @@
+/*
+ * i2t.h -- C ABI of libi2t_hip.so: the gfx950 (MI355X) kernels under the image-captioning hot path.
+ *
+ * The reference (iitmdinesh/image2text) is pure Python over torch ops; it has no FFI of its own.  Each entry
+ * point below replaces the torch dispatch site cited next to it (paths relative to the reference repo), and is
+ * what a reference-side ctypes binding would call (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (the PyTorch caching allocator);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden allocation, no host sync,
+ *     so every call is legal inside hipGraph stream capture;
+ *   - return 0 on success, negative I2T_E* otherwise; never throws.  i2t_last_error() gives the message;
+ *   - bf16 tensors are raw uint16 bit patterns; "f32" = IEEE float; row-major with an explicit leading dimension
+ *     (elements).  bf16 leading dimensions and base pointers must be multiples of 8 elements / 16 bytes;
+ *   - all arithmetic accumulates in fp32.
+ */
+#ifndef I2T_H
+#define I2T_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2T_OK 0
+#define I2T_EINVAL (-1)   /* bad argument (shape/alignment/unsupported size) */
+#define I2T_EHIP (-2)     /* a HIP runtime call failed */
+
+#define I2T_ABI_VERSION 1
+
+int i2t_abi_version(void);
+/* copies the last error message of the calling thread into buf (NUL-terminated); returns its length */
+int i2t_last_error(char* buf, size_t n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue(alpha * op(A)[M,K] . op(B)[K,N])           bf16 MFMA 16x16x32, fp32 accumulate
+ *   replaces: every nn.Linear on the path -- layers.py:437-439,452,469 (c_attn/c_proj), :476-485 (MLP),
+ *   :537-542 (cross-attn in/out proj), encoder.py:147-149 (projector), vision_encoder_decoder.py:34-37 (bridge),
+ *   decoder.py:189,256 (tied lm_head) -- and their autograd backward (dX = dY.W, dW = dY^T.X).
+ *   a_kmajor = 0: A stored [M][K] (K contiguous)      a_kmajor = 1: A stored [K][M] (M contiguous)
+ *   b_kmajor = 0: B stored [N][K] (K contiguous)      b_kmajor = 1: B stored [K][N] (N contiguous)
+ *   epilogue order: v = alpha*acc; v += bias[n]; if aux_out: aux_out[m][n] = bf16(v)  (pre-activation)
+ *                   act 1: v = gelu_tanh(v);  act 2: v *= gelu_tanh'(aux_in[m][n])
+ *                   v += residual[m][n] (f32);  accumulate: v += C[m][n] (f32 C only);  store C as f32 or bf16.
+ *   K must be a multiple of 8.  Columns [N, ldc) of C are never written.
+ * --------------------------------------------------------------------------------------------------------- */
+#define I2T_ACT_NONE 0
+#define I2T_ACT_GELU 1
+#define I2T_ACT_DGELU 2
+int i2t_gemm_bf16(void* stream,
+                  const void* A, int lda, int a_kmajor,
+                  const void* B, int ldb, int b_kmajor,
+                  void* C, int ldc, int c_is_f32,
+                  int M, int N, int K, float alpha,
+                  const float* bias, int act,
+                  const void* aux_in, int ld_aux_in,
+                  void* aux_out, int ld_aux_out,
+                  const float* residual, int ldr,
+                  int accumulate);
+
+/* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients; X bf16 [M][ld]) */
+int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (layers.py:349-358, F.layer_norm eps 1e-5, optional bias)
+ *   fwd: x f32 [M][d] -> y (bf16 or f32) [M][d]; saves mean/rstd f32 [M] when non-null
+ *   bwd: dx[M][d] (f32) (+)= LN'(dy); dgamma/dbeta f32 [d] are ACCUMULATED (atomics); dy bf16 or f32
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta,
+                      void* y, int y_is_f32, float* mean, float* rstd, int M, int d);
+int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
+                      const float* mean, const float* rstd,
+                      float* dx, int dx_accumulate, float* dgamma, float* dbeta, int M, int d);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNormND (layers.py:361-370 via encoder.py:150,166,170): one normalisation per image over the joint
+ *   (rows x d) slab, affine (rows, d).   y[b] = LN(x[b] + add) * gamma + beta   (add = wpe or NULL)
+ *   x,add,gamma,beta f32; y f32 with its own batch stride (lets the 2nd call write behind the CLS rows);
+ *   stats = workspace f32 [B][I2T_LNND_STATS_STRIDE]: (mean, rstd) then per-split partials; written by fwd,
+ *   read (and its partial slots reused) by bwd.  Each LayerNormND application needs its own stats buffer.
+ *   bwd: dx[b] (f32, own batch stride, overwritten) ; dgamma/dbeta (+ dadd when non-null) accumulated.
+ * --------------------------------------------------------------------------------------------------------- */
+#define I2T_LNND_STATS_STRIDE 34
+int i2t_layernorm_nd_fwd(void* stream, const float* x, const float* add, const float* gamma, const float* beta,
+                         float* y, long y_batch_stride, float* stats, int B, int rows, int d);
+int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch_stride, const float* x, const float* add,
+                         const float* gamma, const float* stats, float* dx, float* dgamma, float* dbeta,
+                         float* dadd, int B, int rows, int d);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Attention, head_dim 64 (F.scaled_dot_product_attention at layers.py:465 and inside nn.MultiheadAttention
+ *   layers.py:537-542).  softmax(q k^T / 8 [+ causal]) v per (batch, head).
+ *   q/k/v/o are bf16 with element strides: batch stride, row (token) stride; head h starts at column 64*h.
+ *   Packed c_attn output: q=base, k=base+d, v=base+2d, row stride 3d.  lse f32 [B][H][Tq] (natural log).
+ *   causal: key j visible to query i iff j <= i + (Tk - Tq)   (Tk == Tq in training; Tk > Tq with a KV cache)
+ *   bwd: dq/dk/dv written (not accumulated), same strides convention as their forward operands.
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                      const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
+                      int B, int H, int Tq, int Tk, int causal);
+int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                      const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
+                      const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,
+                      void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
+                      void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Token + position embedding (decoder.py:231-243): x[b][t] = wte[ids[b][t]] + wpe[t + pos_offset]  (f32)
+ *   bwd: dwte[ids] += dx (atomics), dwpe[t+pos_offset] += sum_b dx[b][t]
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte, const float* wpe, float* x,
+                  int B, int T, int d, int pos_offset, int vocab);
+int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dwte, float* dwpe,
+                  int B, int T, int d, int pos_offset, int vocab);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Weighted cross-entropy over bf16 logits (wrapper.py:147-151: F.cross_entropy(logits/T, labels, ignore_index,
+ *   'none') * weights, summed).  logits [M][ld] bf16, V valid columns; labels int64 [M] (ignore_index rows skip);
+ *   fwd: lse[m] = logsumexp(logits[m]/T); loss += sum_m w[m]*(lse[m] - logits[m][label]/T)   (atomic into *loss)
+ *   bwd: logits[m][:] <- bf16( gscale * w[m]/T * (softmax(logits[m]/T) - onehot) ), in place;  gscale read
+ *        from device memory (*gscale_ptr) so the upstream gradient never needs a host sync.
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_ce_fwd(void* stream, const void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+               int64_t ignore_index, float* lse, float* loss, int M, int V);
+int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+               int64_t ignore_index, const float* lse, const float* gscale_ptr, int M, int V);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Gradient normaliser (functions.py:19-24): g <- g / (||g||_2 + 1e-6) over the whole f32 tensor, in place.
+ *   ws = 1 float of zero-initialised-by-the-call scratch.
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_grad_normalize(void* stream, float* g, long n, float* ws);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * ConvMLP feature extractor (layers.py:258-282): Conv2d(k x k, padding='same', k even => pad (k-1)/2 before,
+ *   k/2 after), GELU(tanh) applied to the INPUT when in_gelu (the previous layer stores pre-activations).
+ *   x: in_is_f32 ? f32 : bf16 [B][Cin][H][W];  w f32 [Cout][Cin][k][k];  y bf16 [B][Cout][H][W] (pre-activation)
+ *   bwd_data:  dx[B][Cin][H][W] bf16 = convT(dy) * (in_gelu ? gelu'(x) : 1)     (skipped for the first layer)
+ *   bwd_weight: dw f32 [Cout][Cin][k][k], db f32 [Cout] accumulated (atomics)
+ *   w_ws: f32 scratch of Cout*Cin*k*k elements (weights repacked tap-major for scalar loads)
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_conv_fwd(void* stream, const void* x, int in_is_f32, int in_gelu, const float* w, const float* bias,
+                 void* y, float* w_ws, int B, int Cin, int Cout, int H, int W, int k);
+int i2t_conv_bwd_data(void* stream, const void* dy, const float* w, const void* x, int in_gelu, void* dx,
+                      float* w_ws, int B, int Cin, int Cout, int H, int W, int k);
+int i2t_conv_bwd_weight(void* stream, const void* dy, const void* x, int in_is_f32, int in_gelu,
+                        float* dw, float* db, int B, int Cin, int Cout, int H, int W, int k);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Elementwise / arena utilities
+ *   cast:  dst bf16[n] = src f32[n]                     (bf16 weight shadows after an optimizer step)
+ *   adamw: torch.optim.AdamW semantics (decoupled decay, bias correction from `step`), one launch over a flat
+ *          f32 arena; also refreshes the bf16 shadow of every parameter.  lr/wd are per-element-range tables:
+ *          seg_end[i] = exclusive end of segment i, seg_lr[i], seg_wd[i] (nseg small; device arrays).
+ *   add_rows / cls concat helpers for the encoder token buffer.
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n);
+int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+                   const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
+                   float beta1, float beta2, float eps, int step, float grad_scale);
+/* y[b][r][:] = src[r][:] for r < rows (broadcast a (rows,d) f32 block into a strided batch buffer) */
+int i2t_bcast_rows(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d);
+/* dst[r][:] (+)= sum_b x[b][r][:] */
+int i2t_sum_over_batch(void* stream, const float* x, long x_batch_stride, float* dst, int B, int rows, int d,
+                       int accumulate);
+/* strided f32 row copy with optional bf16 output: y[b][r][:] = x[b][r][:] for r < rows */
+int i2t_copy_rows(void* stream, const float* x, long x_bs, void* y, long y_bs, int y_is_bf16, int B, int rows,
+                  int d);
+int i2t_add_f32(void* stream, float* dst, const float* src, long n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Greedy decode step pieces (vision_encoder_decoder.py:136-182 with top_k=1, temperature=1):
+ *   decode_attention: one new query token per caption against the self K/V cache (keys 0..*pos) -- cache layout
+ *     [B][Tmax][d] bf16 for K and for V; also used for cross-attention with fixed n_keys (pos_ptr NULL);
+ *   ngram_ban_argmax: HF NoRepeatNGramLogitsProcessor for every size in ngram_sizes (prompt included), then argmax
+ *     (first index on ties); appends the token at ids[b][*len] and (block 0) bumps *len / *pos after the grid.
+ *   Positions live in device memory so that a captured hipGraph replays the same launch for every step.
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_decode_attention(void* stream, const void* q, int q_rs, const void* kcache, const void* vcache,
+                         long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
+                         int B, int H);
+int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kcache, void* vcache, long cache_bs,
+                  int cache_rs, const int* pos_ptr, int B, int d);
+int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, int logits_is_f32, int64_t* ids, int ids_ld,
+                         int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V, float* margin_out);
+int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
+                   const float* wpe, float* x, int B, int d, int pos_offset, int vocab);
+int i2t_advance(void* stream, int* counter, int delta);
+
+/* hipGraph capture around any sequence of the calls above (replaces the Python loop of
+ * vision_encoder_decoder.py:143-180 with one replayed launch per token) */
+int i2t_graph_capture_begin(void* stream);
+int i2t_graph_capture_end(void* stream, void** graph_exec_out);
+int i2t_graph_launch(void* graph_exec, void* stream);
+int i2t_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2T_H */

@@ -1,0 +1,420 @@
+"""Per-kernel numerics on the MI355X: every C-ABI entry point against a plain PyTorch fp32/fp64 statement of the same
+op, computed from the SAME bf16-rounded inputs (so the tolerance only has to cover fp32 accumulation order and the
+final bf16 store: rtol 2^-7 for bf16 outputs, 2e-3 for f32 outputs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from image2text_amd import ops as _ops
+    from image2text_amd.build import build_library
+    build_library()
+    return _ops
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=F32):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def check(name, got, ref, atol, rtol):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f'{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    assert torch.isfinite(got).all(), f'{name}: non-finite output'
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = np.unravel_index(int((err - tol).argmax()), tuple(got.shape))
+        raise AssertionError(f'{name}: {int(bad.sum())}/{bad.numel()} out of tolerance; worst at {idx}: got {got[idx].item():.6g} '
+                             f'ref {ref[idx].item():.6g} (max abs err {err.max().item():.3g}, ref absmax {ref.abs().max().item():.3g})')
+
+
+def gelu_grad(x):
+    x = x.detach().clone().requires_grad_(True)
+    F.gelu(x, approximate='tanh').sum().backward()
+    return x.grad
+
+
+# ------------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 192), (1024, 768, 512), (64, 2304, 768), (300, 72, 8192)])
+@pytest.mark.parametrize('a_km,b_km', [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_layouts(ops, M, N, K, a_km, b_km):
+    a = rnd(M, K, dtype=BF16, seed=1)
+    b = rnd(N, K, dtype=BF16, seed=2)
+    ref = a.float() @ b.float().t()
+    a_in = a.t().contiguous() if a_km else a
+    b_in = b.t().contiguous() if b_km else b
+    if (a_km and M % 8) or (b_km and N % 8):
+        pytest.skip('k-major operand needs a leading dimension padded to 8')
+    out = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a_in, b_in, out, M, N, K, a_kmajor=a_km, b_kmajor=b_km)
+    check(f'gemm f32 {M}x{N}x{K} a_km={a_km} b_km={b_km}', out, ref, 2e-3 * math.sqrt(K) / 8, 2e-3)
+    outb = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a_in, b_in, outb, M, N, K, a_kmajor=a_km, b_kmajor=b_km)
+    check('gemm bf16 out', outb, ref, 2e-2 * math.sqrt(K) / 8, 1 / 128)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 260, 512, 256
+    a, b = rnd(M, K, dtype=BF16, seed=3), rnd(N, K, dtype=BF16, seed=4, scale=0.1)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    base = a.float() @ b.float().t()
+    # bias + gelu with pre-activation side output, bf16 result
+    out = torch.empty(M, N, dtype=BF16, device=dev())
+    pre = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M, N, K, bias=bias, act=1, aux_out=pre)
+    check('pre-activation', pre, base + bias, 1e-2, 1 / 128)
+    check('gelu(bias + ab)', out, F.gelu(base + bias, approximate='tanh'), 1e-2, 1 / 128)
+    # residual + bias, f32 result, alpha
+    o32 = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a, b, o32, M, N, K, alpha=0.5, bias=bias, residual=res)
+    check('alpha/bias/residual', o32, 0.5 * base + bias + res, 2e-3, 2e-3)
+    # accumulate into f32
+    acc = res.clone()
+    ops.gemm(a, b, acc, M, N, K, accumulate=True)
+    check('accumulate', acc, base + res, 2e-3, 2e-3)
+    # dgelu: out = (a b^T) * gelu'(aux)
+    aux = rnd(M, N, dtype=BF16, seed=7)
+    od = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, od, M, N, K, act=2, aux_in=aux)
+    check('dgelu', od, base * gelu_grad(aux.float()), 2e-2, 1 / 128)
+
+
+def test_gemm_vocab_shapes(ops):
+    """lm_head shapes: N = 50257 (odd) with ldc padded to 50264; K = 50257 reduction with zero pads; dW over M."""
+    V, Vp, d, M = 50257, 50264, 768, 192
+    h = rnd(M, d, dtype=BF16, seed=8)
+    wte = rnd(V, d, dtype=BF16, seed=9, scale=0.05)
+    logits = torch.zeros(M, Vp, dtype=BF16, device=dev())
+    ops.gemm(h, wte, logits, M, V, d)
+    ref = h.float() @ wte.float().t()
+    check('logits', logits[:, :V], ref, 2e-2, 1 / 128)
+    assert float(logits[:, V:].abs().max()) == 0.0, 'pad columns must stay untouched'
+    dl = torch.zeros(M, Vp, dtype=BF16, device=dev())
+    dl[:, :V] = rnd(M, V, dtype=BF16, seed=10, scale=0.01)
+    dh = torch.empty(M, d, dtype=F32, device=dev())
+    ops.gemm(dl, wte, dh, M, d, V, b_kmajor=True)                       # dH = dL . W       (K = V, pads are zero)
+    check('dH', dh, dl[:, :V].float() @ wte.float(), 5e-3, 3e-3)
+    dw = torch.empty(V, d, dtype=F32, device=dev())
+    ops.gemm(dl, h, dw, V, d, M, a_kmajor=True, b_kmajor=True)          # dW = dL^T . H     (reduction over M)
+    check('dW', dw, dl[:, :V].float().t() @ h.float(), 2e-3, 3e-3)
+
+
+def test_colsum(ops):
+    x = rnd(5000, 200, dtype=BF16, seed=11)
+    out = torch.zeros(200, device=dev())
+    ops.colsum(x, out, 5000, 200)
+    check('colsum', out, x.float().sum(0), 2e-2, 2e-3)
+    ops.colsum(x[:100], out, 100, 200, accumulate=True)
+    check('colsum acc', out, x.float().sum(0) + x[:100].float().sum(0), 2e-2, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize('M,d,bias', [(1000, 768, True), (777, 512, False), (64, 64, False), (33, 128, True), (16, 1024, True)])
+def test_layernorm(ops, M, d, bias):
+    x = rnd(M, d, seed=12) * 2 + 0.5
+    g = 1 + 0.1 * rnd(d, seed=13)
+    b = 0.1 * rnd(d, seed=14) if bias else None
+    ref = F.layer_norm(x, (d,), g, b, 1e-5)
+    y = torch.empty(M, d, dtype=BF16, device=dev())
+    mean, rstd = torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, M, d)
+    check('ln fwd bf16', y, ref, 1e-2, 1 / 128)
+    y32 = torch.empty(M, d, dtype=F32, device=dev())
+    ops.layernorm_fwd(x, g, b, y32, mean, rstd, M, d)
+    check('ln fwd f32', y32, ref, 1e-5, 1e-5)
+    check('ln mean', mean, x.mean(-1), 1e-5, 1e-5)
+    # backward
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    dy = rnd(M, d, seed=15)
+    F.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy)
+    for dy_in, tol in ((dy, 1e-4), (dy.to(BF16), 2e-2)):
+        dx = torch.full((M, d), 0.25, device=dev())
+        dg, db = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
+        ops.layernorm_bwd(dy_in, x, g, mean, rstd, dx, dg, db if bias else None, M, d, dx_accumulate=True)
+        check('ln dx (+accumulate)', dx, xr.grad + 0.25, tol, tol)
+        check('ln dgamma', dg, gr.grad, tol * math.sqrt(M), tol)
+        if bias:
+            check('ln dbeta', db, br.grad, tol * math.sqrt(M), tol)
+
+
+@pytest.mark.parametrize('B,rows,d,bias', [(3, 16, 64, False), (2, 196, 512, False), (2, 16, 64, True)])
+def test_layernorm_nd(ops, B, rows, d, bias):
+    x = rnd(B, rows, d, seed=16) * 1.5 + 0.3
+    add = rnd(rows, d, seed=17)
+    g = 1 + 0.1 * rnd(rows, d, seed=18)
+    b = 0.1 * rnd(rows, d, seed=19) if bias else None
+    ncls = 8
+    for use_add in (False, True):
+        xin = x + add if use_add else x
+        ref = F.layer_norm(xin, (rows, d), g, b, 1e-5)
+        ybuf = torch.zeros(B, ncls + rows, d, device=dev())
+        stats = torch.zeros(B, ops.LNND_STATS_STRIDE, device=dev())
+        ops.layernorm_nd_fwd(x, add if use_add else None, g, b, ybuf[:, ncls:], (ncls + rows) * d, stats, B, rows, d)
+        check('lnnd fwd', ybuf[:, ncls:], ref, 2e-5, 2e-5)
+        assert float(ybuf[:, :ncls].abs().max()) == 0.0
+        xr = x.clone().requires_grad_(True)
+        ar = add.clone().requires_grad_(True)
+        gr = g.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if bias else None
+        dyb = torch.zeros(B, ncls + rows, d, device=dev())
+        dyb[:, ncls:] = rnd(B, rows, d, seed=20)
+        F.layer_norm(xr + ar if use_add else xr, (rows, d), gr, br, 1e-5).backward(dyb[:, ncls:])
+        dx = torch.empty(B, rows, d, device=dev())
+        dg, db, da = torch.zeros(rows, d, device=dev()), torch.zeros(rows, d, device=dev()), torch.zeros(rows, d, device=dev())
+        ops.layernorm_nd_bwd(dyb[:, ncls:], (ncls + rows) * d, x, add if use_add else None, g, stats, dx, dg,
+                             db if bias else None, da if use_add else None, B, rows, d)
+        check('lnnd dx', dx, xr.grad, 1e-4, 1e-4)
+        check('lnnd dgamma', dg, gr.grad, 1e-4, 1e-4)
+        if bias:
+            check('lnnd dbeta', db, br.grad, 1e-4, 1e-4)
+        if use_add:
+            check('lnnd dadd', da, ar.grad, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, causal):
+    B, Tq, H, _ = q.shape
+    Tk = k.shape[1]
+    qh, kh, vh = (t.permute(0, 2, 1, 3).double() for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / 8.0
+    if causal:
+        i = torch.arange(Tq, device=q.device)[:, None]
+        j = torch.arange(Tk, device=q.device)[None, :]
+        s = s.masked_fill(j > i + (Tk - Tq), float('-inf'))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize('B,H,Tq,Tk,causal,packed', [
+    (2, 3, 64, 64, True, True), (2, 8, 260, 260, False, True), (3, 12, 128, 64, False, False), (2, 2, 37, 37, True, True),
+    (1, 4, 200, 200, True, True), (2, 2, 16, 16, True, True), (2, 1, 24, 24, False, True), (2, 2, 1, 50, True, False)])
+def test_attention_fwd_bwd(ops, B, H, Tq, Tk, causal, packed):
+    d = 64 * H
+    if packed:
+        qkv = rnd(B, Tq, 3 * d, dtype=BF16, seed=21)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    else:
+        q = rnd(B, Tq, d, dtype=BF16, seed=22)
+        kv = rnd(B, Tk, 2 * d, dtype=BF16, seed=23)
+        k, v = kv[..., :d], kv[..., d:]
+    qr, kr, vr = (t.float().reshape(B, -1, H, 64).requires_grad_(True) for t in (q, k, v))
+    o_ref, lse_ref = ref_attention(qr, kr, vr, causal)
+    o = torch.empty(B, Tq, d, dtype=BF16, device=dev())
+    lse = torch.empty(B, H, Tq, device=dev())
+    ops.attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal)
+    check('attn out', o.reshape(B, Tq, H, 64), o_ref, 1e-2, 1 / 128)
+    check('attn lse', lse, lse_ref, 2e-3, 2e-3)
+    do = rnd(B, Tq, d, dtype=BF16, seed=24)
+    o_ref.backward(do.double().reshape(B, Tq, H, 64))
+    if packed:
+        dqkv = torch.zeros(B, Tq, 3 * d, dtype=BF16, device=dev())
+        dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+    else:
+        dq = torch.zeros(B, Tq, d, dtype=BF16, device=dev())
+        dkv = torch.zeros(B, Tk, 2 * d, dtype=BF16, device=dev())
+        dk, dv = dkv[..., :d], dkv[..., d:]
+    ws = torch.empty(B, H, Tq, device=dev())
+    ops.attention_bwd(q, k, v, o, do, lse, ws, dq, dk, dv, B, H, Tq, Tk, causal)
+    scale = float(do.float().abs().max())
+    check('attn dq', dq.reshape(B, Tq, H, 64), qr.grad, 3e-2 * scale, 1 / 32)
+    check('attn dk', dk.reshape(B, Tk, H, 64), kr.grad, 3e-2 * scale, 1 / 32)
+    check('attn dv', dv.reshape(B, Tk, H, 64), vr.grad, 3e-2 * scale, 1 / 32)
+
+
+# ------------------------------------------------------------------------------------------------------ embed / CE / norm
+def test_embed(ops):
+    B, T, d, V, off = 3, 20, 128, 384, 8
+    ids = torch.randint(0, V, (B, T), device=dev())
+    ids[0, :3] = 7                                             # repeated ids -> atomics must accumulate
+    wte, wpe = rnd(V, d, seed=25), rnd(48, d, seed=26)
+    x = torch.empty(B, T, d, device=dev())
+    ops.embed_fwd(ids, wte, wpe, x, B, T, d, off, V)
+    check('embed fwd', x, wte[ids] + wpe[off:off + T], 0, 0)
+    dx = rnd(B, T, d, seed=27)
+    dwte, dwpe = torch.ones(V, d, device=dev()), torch.ones(48, d, device=dev())
+    ops.embed_bwd(ids, dx, dwte, dwpe, B, T, d, off, V)
+    ref_te = torch.ones(V, d, device=dev()).index_add_(0, ids.reshape(-1), dx.reshape(-1, d))
+    ref_pe = torch.ones(48, d, device=dev())
+    ref_pe[off:off + T] += dx.sum(0)
+    check('embed dwte', dwte, ref_te, 1e-5, 1e-5)
+    check('embed dwpe', dwpe, ref_pe, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize('M,V,ld,temp', [(64, 50257, 50264, 1.0), (48, 384, 384, 0.7), (5, 1000, 1008, 1.0)])
+def test_cross_entropy(ops, M, V, ld, temp):
+    logits = torch.zeros(M, ld, dtype=BF16, device=dev())
+    logits[:, :V] = rnd(M, V, dtype=BF16, seed=28, scale=2.0)
+    labels = torch.randint(0, V, (M,), device=dev())
+    labels[::5] = -100
+    w = torch.rand(M, device=dev())
+    w[labels == -100] = 0
+    lr = logits[:, :V].float().requires_grad_(True)
+    ce = F.cross_entropy(lr / temp, labels, ignore_index=-100, reduction='none')
+    ref_loss = (ce * w).sum()
+    (ref_loss * 0.5).backward()
+    lse, loss = torch.empty(M, device=dev()), torch.zeros(1, device=dev())
+    ops.ce_fwd(logits, ld, labels, w, 1.0 / temp, -100, lse, loss, M, V)
+    check('ce loss', loss[0], ref_loss, 1e-4, 1e-4)
+    gscale = torch.full((1,), 0.5, device=dev())
+    ops.ce_bwd(logits, ld, labels, w, 1.0 / temp, -100, lse, gscale, M, V)
+    check('ce dlogits', logits[:, :V], lr.grad, 1e-6, 1 / 128)
+    if ld > V:
+        assert float(logits[:, V:].float().abs().max()) == 0.0
+
+
+def test_grad_normalize(ops):
+    for n in (1000, 64 * 128 * 768 + 3):
+        g = rnd(n, seed=29) * 3
+        ref = g / (torch.linalg.vector_norm(g.double()).float() + 1e-6)
+        ws = torch.empty(1, device=dev())
+        ops.grad_normalize(g, ws)
+        check('grad_normalize', g, ref, 1e-7, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------ conv stack
+@pytest.mark.parametrize('B,H,W,chans,k', [(2, 32, 32, (3, 4, 8, 8), 6), (2, 64, 96, (3, 8, 16, 32), 6), (1, 40, 40, (3, 8, 16), 4)])
+def test_conv_stack(ops, B, H, W, chans, k):
+    x0 = rnd(B, chans[0], H, W, seed=30)
+    ws = [rnd(chans[i + 1], chans[i], k, k, seed=31 + i) / math.sqrt(chans[i] * k * k) for i in range(len(chans) - 1)]
+    bs = [0.1 * rnd(chans[i + 1], seed=41 + i) for i in range(len(chans) - 1)]
+    # reference chain with the same bf16 rounding of stored pre-activations
+    pres, inp = [], x0
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    ref_in = []
+    for i, (w, b) in enumerate(zip(wr, br)):
+        a = inp if i == 0 else F.gelu(inp, approximate='tanh')
+        ref_in.append(a)
+        pre = F.conv2d(F.pad(a, ((k - 1) // 2, k // 2, (k - 1) // 2, k // 2)), w, b)
+        pres.append(pre)
+        inp = pre.detach().to(BF16).float().requires_grad_(True)     # what the kernel chain stores / re-reads
+        pres[-1] = (pre, inp)
+    w_ws = torch.empty(max(w.numel() for w in ws), device=dev())
+    ys, cur = [], x0
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        y = torch.empty(B, chans[i + 1], H, W, dtype=BF16, device=dev())
+        ops.conv_fwd(cur, i > 0, w, b, y, w_ws, B, chans[i], chans[i + 1], H, W, k)
+        check(f'conv{i} fwd', y, pres[i][0], 2e-2, 1 / 64)
+        ys.append(y)
+        cur = y
+    # backward through the chain, layer by layer against autograd on the reference layer
+    dy = rnd(B, chans[-1], H, W, dtype=BF16, seed=50)
+    for i in reversed(range(len(ws))):
+        pre, _ = pres[i]
+        xin = x0 if i == 0 else ys[i - 1]
+        a_ref = ref_in[i] if i == 0 else F.gelu(ys[i - 1].float(), approximate='tanh')
+        a_ref = a_ref.detach().requires_grad_(True)
+        wi, bi = ws[i].clone().requires_grad_(True), bs[i].clone().requires_grad_(True)
+        F.conv2d(F.pad(a_ref, ((k - 1) // 2, k // 2, (k - 1) // 2, k // 2)), wi, bi).backward(dy.float())
+        dw, db = torch.zeros_like(ws[i]), torch.zeros_like(bs[i])
+        ops.conv_bwd_weight(dy, xin, i > 0, dw, db, B, chans[i], chans[i + 1], H, W, k)
+        sc = float(wi.grad.abs().max())
+        check(f'conv{i} dW', dw, wi.grad, 2e-3 * sc, 5e-3)
+        check(f'conv{i} db', db, bi.grad, 2e-3 * float(bi.grad.abs().max()), 5e-3)
+        if i > 0:
+            dx = torch.empty(B, chans[i], H, W, dtype=BF16, device=dev())
+            ops.conv_bwd_data(dy, ws[i], ys[i - 1], True, dx, w_ws, B, chans[i], chans[i + 1], H, W, k)
+            ref_dx = a_ref.grad * gelu_grad(ys[i - 1].float())
+            check(f'conv{i} dX', dx, ref_dx, 2e-2 * float(ref_dx.abs().max()), 1 / 64)
+            dy = dx
+
+
+# ------------------------------------------------------------------------------------------------------ optimiser / misc
+def test_adamw_matches_torch(ops):
+    n1, n2 = 1000, 2048
+    p = rnd(n1 + n2, seed=60)
+    ref_p = [p[:n1].clone().requires_grad_(True), p[n1:].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([{'params': [ref_p[0]], 'lr': 1e-2, 'weight_decay': 0.1},
+                             {'params': [ref_p[1]], 'lr': 3e-3, 'weight_decay': 0.0}], betas=(0.9, 0.95), eps=1e-8)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.empty(n1 + n2, dtype=BF16, device=dev())
+    seg_end = torch.tensor([n1, n1 + n2], dtype=torch.long, device=dev())
+    seg_lr = torch.tensor([1e-2, 3e-3], device=dev())
+    seg_wd = torch.tensor([0.1, 0.0], device=dev())
+    for step in range(1, 4):
+        g = rnd(n1 + n2, seed=61 + step)
+        ref_p[0].grad, ref_p[1].grad = g[:n1].clone(), g[n1:].clone()
+        opt.step()
+        ops.adamw_step(p, g, m, v, pb, n1 + n2, seg_end, seg_lr, seg_wd, 2, 0.9, 0.95, 1e-8, step)
+        check(f'adamw step {step}', p, torch.cat([ref_p[0], ref_p[1]]).detach(), 1e-6, 1e-5)
+    check('adamw bf16 shadow', pb, p, 0, 1 / 128)
+
+
+def test_small_helpers(ops):
+    B, rows, d, ncls = 3, 5, 64, 2
+    src = rnd(rows, d, seed=70)
+    y = torch.zeros(B, ncls + rows, d, device=dev())
+    ops.bcast_rows(src, y[:, ncls:], (ncls + rows) * d, B, rows, d)
+    check('bcast_rows', y[:, ncls:], src.expand(B, rows, d), 0, 0)
+    dst = torch.ones(rows, d, device=dev())
+    ops.sum_over_batch(y[:, ncls:], (ncls + rows) * d, dst, B, rows, d, accumulate=True)
+    check('sum_over_batch', dst, 1 + B * src, 1e-6, 1e-6)
+    out = torch.zeros(B, rows, d, dtype=BF16, device=dev())
+    ops.copy_rows(y[:, ncls:], (ncls + rows) * d, out, rows * d, B, rows, d)
+    check('copy_rows', out, src.expand(B, rows, d), 0, 1 / 128)
+    a, b = rnd(1003, seed=71), rnd(1003, seed=72)
+    ref = a + b
+    ops.add_(a, b)
+    check('add', a, ref, 0, 0)
+    c = torch.empty(1003, dtype=BF16, device=dev())
+    ops.cast_f32_bf16(b, c)
+    check('cast', c, b, 0, 1 / 128)
+
+
+# ------------------------------------------------------------------------------------------------------ decode pieces
+def test_ngram_ban_argmax_vs_oracle(ops):
+    from oracle import reference_model as orc
+    B, V, L = 6, 384, 40
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 6, (B, L), generator=g)            # tiny alphabet -> many repeated n-grams
+    sizes = (2, 3, 4, 5)
+    for cur in (1, 2, 5, 17, 39):
+        logits = torch.randn(B, V, generator=g)
+        ref = orc.apply_ngram_ban(ids[:, :cur], logits.clone(), sizes)
+        t2 = torch.topk(ref, 2, dim=-1).values
+        dev_ids = torch.zeros(B, L, dtype=torch.long, device=dev())
+        dev_ids[:, :cur] = ids[:, :cur].to(dev())
+        len_ptr = torch.tensor([cur], dtype=torch.int32, device=dev())
+        margin = torch.zeros(B, device=dev())
+        ops.ngram_ban_argmax(logits.to(dev()), V, dev_ids, L, len_ptr, torch.tensor(sizes, dtype=torch.int32, device=dev()),
+                             len(sizes), B, V, margin)
+        assert torch.equal(dev_ids[:, cur].cpu(), ref.argmax(-1)), f'cur={cur}'
+        check('margin', margin, t2[:, 0] - t2[:, 1], 1e-6, 1e-6)
+        ops.advance(len_ptr, 1)
+        assert int(len_ptr.item()) == cur + 1
+
+
+def test_decode_attention_and_kv_append(ops):
+    B, H, Tmax = 3, 2, 32
+    d = 64 * H
+    kc, vc = rnd(B, Tmax, d, dtype=BF16, seed=80), rnd(B, Tmax, d, dtype=BF16, seed=81)
+    qkv = rnd(B, 3 * d, dtype=BF16, seed=82)
+    pos = torch.tensor([9], dtype=torch.int32, device=dev())
+    ops.kv_append(qkv, 3 * d, kc, vc, Tmax * d, d, pos, B, d)
+    assert torch.equal(kc[:, 9], qkv[:, d:2 * d]) and torch.equal(vc[:, 9], qkv[:, 2 * d:])
+    o = torch.empty(B, d, dtype=BF16, device=dev())
+    ops.decode_attention(qkv, 3 * d, kc, vc, Tmax * d, d, o, d, pos, 0, B, H)
+    q = qkv[:, :d].float().reshape(B, 1, H, 64)
+    ref, _ = ref_attention(q, kc[:, :10].float().reshape(B, 10, H, 64), vc[:, :10].float().reshape(B, 10, H, 64), False)
+    check('decode attention (cache)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
+    ops.decode_attention(qkv, 3 * d, kc, vc, Tmax * d, d, o, d, None, 20, B, H)
+    ref, _ = ref_attention(q, kc[:, :20].float().reshape(B, 20, H, 64), vc[:, :20].float().reshape(B, 20, H, 64), False)
+    check('decode attention (fixed keys)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
