@@ -182,10 +182,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(ws, s);
 }
 
-__global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ g, long n4, long n, const float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ g, long n4, long n, const float* __restrict__ ws,
+                                                            bf16_t* __restrict__ gb) {
     const float inv = 1.0f / (sqrtf(*ws) + 1e-6f);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(g)[i] *= inv;
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[n4 * 4 + threadIdx.x] *= inv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<f32x4*>(g)[i] * inv;
+        reinterpret_cast<f32x4*>(g)[i] = v;
+        if (gb) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            reinterpret_cast<u32x2*>(gb)[i] = pk;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float v = g[n4 * 4 + threadIdx.x] * inv;
+        g[n4 * 4 + threadIdx.x] = v;
+        if (gb) gb[n4 * 4 + threadIdx.x] = f32_to_bf16(v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- AdamW
@@ -320,14 +332,14 @@ extern "C" int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* lab
     return I2T_OK;
 }
 
-extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws) {
+extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16) {
     I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_grad_normalize: bad args");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
     if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
     const int grid = grid_for(n >> 2, 1024);
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
-    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws);
+    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16);
     I2T_CHECK_LAUNCH("i2t_grad_normalize");
     return I2T_OK;
 }

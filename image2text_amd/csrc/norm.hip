@@ -72,8 +72,9 @@ template <bool DY_F32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
-                                                     int dx_accumulate, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int d) {
+                                                     int dx_accumulate, bf16_t* __restrict__ dx_bf16,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                     int d) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = d >> 2;
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                 if (dx_accumulate) o += *dxp;
                 *dxp = o;
+                if (dx_bf16) {
+                    u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * d)[c] = pk;
+                }
             }
         }
     }
@@ -323,18 +328,18 @@ extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamm
 }
 
 extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
-                                 const float* mean, const float* rstd, float* dx, int dx_accumulate, float* dgamma,
-                                 float* dbeta, int M, int d) {
+                                 const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
+                                 float* dgamma, float* dbeta, int M, int d) {
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
     int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
     hipStream_t s = (hipStream_t)stream;
     if (dy_is_f32)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           dgamma, dbeta, M, d);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           dgamma, dbeta, M, d);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d);
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
 }

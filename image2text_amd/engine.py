@@ -1,0 +1,419 @@
+"""Host-side orchestration of the captioning hot path over the HIP kernels (train step + forward).
+
+This is the MI355X replacement for what torch autograd + ATen do under the reference's
+``VisionEncoderDecoder.forward`` (models/vision_encoder_decoder.py:51-134), ``VisionTransformerEncoder.forward``
+(models/encoder.py:163-178), ``TransformerDecoder.forward`` (models/decoder.py:214-256) and
+``TransformerBlock.forward`` (models/layers.py:565-608): an explicit forward and a hand-written backward that
+launch the C-ABI kernels (``ops``) on the current HIP stream.
+
+Data layout in HBM
+  * parameters: one flat fp32 arena (the ``nn.Parameter``s are views into it, so ``state_dict`` /
+    ``load_state_dict`` / any torch optimizer keep working), one flat fp32 gradient arena (``p.grad`` are views),
+    one flat bf16 shadow of the parameters (the MFMA operands), refreshed by the fused AdamW kernel or by one cast
+    launch whenever torch-side code changed a parameter (tracked through ``Tensor._version``);
+  * residual stream fp32 [B*T, d]; every GEMM operand bf16; LayerNorm reads fp32 and writes bf16 straight into the
+    next GEMM's A operand; GEMM epilogues fold bias, GELU(+pre-activation for backward) and the residual add;
+  * no transposed copies of weights or activations exist: dX = dY.W and dW = dY^T.X use the k-major operand paths
+    of the GEMM kernel (LDS transposed reads).
+
+Reference quirks reproduced on purpose (each pinned by a golden fixture):
+  * user attention masks are numerically inert (oracle/_mask_to_additive): self-attention is causal-only in the
+    decoder and unmasked in the encoder;
+  * with soft prompting text rows never see prompt columns and prompt-row logits are sliced off, so the prompt rows
+    and the text rows are two independent causal segments; the training path runs only the text segment
+    (positions offset by n_cls), ``forward`` also runs the prompt segment to return the full ``hidden_state``;
+  * LayerNormND is applied twice with shared weights; "patches" are a flat chunking of the CHW conv output;
+  * ``normalize_gradients`` (models/functions.py:19-24) rescales the residual-stream gradient to unit L2 norm at
+    every block output, per replica.
+"""
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .lib import I2TError
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ParamArena:
+    """Flat fp32 parameters + fp32 gradients + bf16 shadow; parameters of ``module`` become views into it."""
+
+    def __init__(self, module: torch.nn.Module, device: torch.device):
+        self.device = device
+        self.entries: Dict[str, Tuple[int, int, torch.Size]] = {}
+        self.params: Dict[str, torch.nn.Parameter] = {}
+        off = 0
+        for name, p in module.named_parameters():          # de-duplicates tied parameters
+            self.entries[name] = (off, p.numel(), p.shape)
+            self.params[name] = p
+            off += _round_up(p.numel(), 8)
+        self.total = off
+        self.p32 = torch.zeros(off, dtype=F32, device=device)
+        self.g32 = torch.zeros(off, dtype=F32, device=device)
+        self.pbf = torch.zeros(off, dtype=BF16, device=device)
+        with torch.no_grad():
+            for name, p in self.params.items():
+                o, n, shape = self.entries[name]
+                view = self.p32[o:o + n].view(shape)
+                view.copy_(p.data.to(device=device, dtype=F32))
+                p.data = view
+        self._versions = None
+        self.grads_attached = False
+
+    def valid(self) -> bool:
+        for name, p in self.params.items():
+            o, n, _ = self.entries[name]
+            if p.data_ptr() != self.p32.data_ptr() + 4 * o or p.device != self.device:
+                return False
+        return True
+
+    def refresh_shadow(self):
+        """Re-cast fp32 -> bf16 if any parameter was modified by torch-side code since the last cast."""
+        v = tuple(p._version for p in self.params.values())
+        if v != self._versions:
+            ops.cast_f32_bf16(self.p32, self.pbf, self.total)
+            self._versions = v
+
+    def P(self, name: str) -> Optional[torch.Tensor]:
+        e = self.entries.get(name)
+        return None if e is None else self.p32[e[0]:e[0] + e[1]].view(e[2])
+
+    def W(self, name: str) -> torch.Tensor:
+        o, n, shape = self.entries[name]
+        return self.pbf[o:o + n].view(shape)
+
+    def G(self, name: str) -> Optional[torch.Tensor]:
+        e = self.entries.get(name)
+        return None if e is None else self.g32[e[0]:e[0] + e[1]].view(e[2])
+
+    def begin_backward(self):
+        """Zero the gradient arena when this is a fresh accumulation window (every p.grad is None)."""
+        fresh = all(p.grad is None for p in self.params.values())
+        if fresh:
+            self.g32.zero_()
+        else:
+            for name, p in self.params.items():
+                if p.grad is not None and p.grad.data_ptr() != self.G(name).data_ptr():
+                    raise I2TError(f'{name}.grad was replaced by a foreign tensor; call zero_grad(set_to_none=True)')
+
+    def attach_grads(self):
+        for name, p in self.params.items():
+            if p.requires_grad and p.grad is None:
+                p.grad = self.G(name)
+
+
+class HotPath:
+    """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.model = model
+        self.cfg = model.config
+        self.arena: Optional[ParamArena] = None
+        ecfg, dcfg = self.cfg.vision_encoder_config, self.cfg.decoder_config
+        self.has_bridge = model.has_bridge
+        self.ep = 'encoder.0.' if self.has_bridge else 'encoder.'
+        self.dp = 'decoder.'
+        eac, dac = ecfg.transformer_config.attn_config, dcfg.transformer_config.attn_config
+        self.enc = SimpleNamespace(d=eac.n_embd, H=eac.n_head, L=ecfg.n_layer, ncls=ecfg.n_cls,
+                                   P2=ecfg.num_patches ** 2, causal=ecfg.transformer_config.is_causal,
+                                   ff=int(ecfg.transformer_config.rotator_config.ff_mult * eac.n_embd),
+                                   dropout=eac.dropout, attn_dropout=eac.attn_dropout,
+                                   k=ecfg.feature_extractor_kernel_size[0])
+        self.dec = SimpleNamespace(d=dac.n_embd, H=dac.n_head, L=dcfg.n_layer, V=dcfg.vocab_size,
+                                   Vp=_round_up(dcfg.vocab_size, 8), block=dcfg.block_size,
+                                   causal=dcfg.transformer_config.is_causal,
+                                   ff=int(dcfg.transformer_config.rotator_config.ff_mult * dac.n_embd),
+                                   dropout=dac.dropout, attn_dropout=dac.attn_dropout)
+        gates = list(ecfg.feature_extractor_gate_sizes or [])
+        chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
+        self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]
+        self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
+        self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
+        self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
+                          for l in range(dcfg.n_layer)]
+        self._logits_cache: Dict[int, torch.Tensor] = {}
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def prepare(self, training: bool):
+        dev = next(self.model.parameters()).device
+        if dev.type != 'cuda':
+            raise I2TError('the image2text_amd hot path runs on the MI355X only: move the model to cuda (no CPU path)')
+        if self.arena is None or self.arena.device != dev or not self.arena.valid():
+            self.arena = ParamArena(self.model, dev)
+            self._ws = torch.zeros(4, dtype=F32, device=dev)
+            self._conv_ws = torch.empty(max(self.arena.entries[f'{n}.weight'][1] for n, _, _ in self.conv), dtype=F32, device=dev)
+            self._logits_cache.clear()
+        self.arena.refresh_shadow()
+        if training and (self.enc.dropout > 0 or self.dec.dropout > 0 or self.enc.attn_dropout > 0 or self.dec.attn_dropout > 0):
+            raise NotImplementedError('dropout > 0 in training mode is not implemented in the HIP path yet; '
+                                      'set dropout/attn_dropout to 0.0 (eval mode is unaffected)')
+        return self.arena
+
+    def _empty(self, *shape, dtype=F32):
+        return torch.empty(*shape, dtype=dtype, device=self.arena.device)
+
+    # ------------------------------------------------------------------------------------------------ block
+    def block_fwd(self, pfx: str, x, B, T, d, H, ff, causal, mem_bf, S, save: bool):
+        a = self.arena
+        M = B * T
+        sv = SimpleNamespace(x=x, cross=False)
+        ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
+        ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
+        qkv = self._empty(B, T, 3 * d, dtype=BF16)
+        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv.view(M, 3 * d), M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'))
+        ao, lse = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
+        ops.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ao, lse, B, H, T, T, causal)
+        x1 = self._empty(M, d)
+        ops.gemm(ao.view(M, d), a.W(f'{pfx}.attn.c_proj.weight'), x1, M, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=x)
+        sv.ln1, sv.m1, sv.r1, sv.qkv, sv.ao, sv.lse, sv.x1 = ln1, m1, r1, qkv, ao, lse, x1
+        x2 = x1
+        if mem_bf is not None:
+            if f'{pfx}.cross_attn.in_proj_weight' not in a.entries:
+                raise ValueError('Model not configured for cross attn inputs!!!')         # reference layers.py:598-599
+            win, bin_ = a.W(f'{pfx}.cross_attn.in_proj_weight'), a.P(f'{pfx}.cross_attn.in_proj_bias')
+            ln3, m3, r3 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
+            ops.layernorm_fwd(x1, a.P(f'{pfx}.ln_3.weight'), a.P(f'{pfx}.ln_3.bias'), ln3, m3, r3, M, d)
+            q = self._empty(B, T, d, dtype=BF16)
+            ops.gemm(ln3, win[:d], q.view(M, d), M, d, d, bias=bin_[:d])
+            kv = self._empty(B, S, 2 * d, dtype=BF16)
+            ops.gemm(mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, 2 * d, d, bias=bin_[d:])
+            co, lse_c = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
+            ops.attention_fwd(q, kv[..., :d], kv[..., d:], co, lse_c, B, H, T, S, False)
+            x2 = self._empty(M, d)
+            ops.gemm(co.view(M, d), a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
+                     bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1)
+            sv.cross, sv.ln3, sv.m3, sv.r3, sv.q, sv.kv, sv.co, sv.lse_c, sv.mem = True, ln3, m3, r3, q, kv, co, lse_c, mem_bf
+        ln2, m2, r2 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
+        ops.layernorm_fwd(x2, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, M, d)
+        h = self._empty(M, ff, dtype=BF16)
+        pre = self._empty(M, ff, dtype=BF16) if save else None
+        ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+        x3 = self._empty(M, d)
+        ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2)
+        sv.x2, sv.ln2, sv.m2, sv.r2, sv.h, sv.pre = x2, ln2, m2, r2, h, pre
+        return x3, (sv if save else None)
+
+    def _linear_bwd(self, dyb, M, N, K, x_bf, wname: str, bname: Optional[str], dx_out=None, **dx_kw):
+        """y = x W^T + b with y [M,N], x [M,K], W [N,K]: accumulates dW, db; returns/fills dX when requested."""
+        a = self.arena
+        gb = a.G(bname) if bname else None
+        if gb is not None:
+            ops.colsum(dyb, gb, M, N, accumulate=True)
+        ops.gemm(dyb, x_bf, a.G(wname), N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if dx_out is not None:
+            ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
+        return dx_out
+
+    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool):
+        """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output, already normalised.  On return dx (and
+        dxb when emit_last_bf16) hold the gradient w.r.t. the block input."""
+        a = self.arena
+        M = B * T
+        ws = self._empty(B, H, T)
+        # ---- MLP: x3 = x2 + c_proj(gelu(c_fc(ln_2 x2)))
+        dpre = self._empty(M, ff, dtype=BF16)
+        self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
+                         dx_out=dpre, act=2, aux_in=sv.pre)
+        dln = self._empty(M, d, dtype=BF16)
+        self._linear_bwd(dpre, M, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', f'{pfx}.mlp.c_fc.bias' if a.G(f'{pfx}.mlp.c_fc.bias') is not None else None,
+                         dx_out=dln)
+        ops.layernorm_bwd(dln, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.G(f'{pfx}.ln_2.weight'),
+                          a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb)
+        # ---- cross attention: x2 = x1 + out_proj(attn(q(ln_3 x1), kv(mem)))
+        if sv.cross:
+            win = a.W(f'{pfx}.cross_attn.in_proj_weight')
+            gin, gbin = a.G(f'{pfx}.cross_attn.in_proj_weight'), a.G(f'{pfx}.cross_attn.in_proj_bias')
+            dco = self._empty(B, T, d, dtype=BF16)
+            self._linear_bwd(dxb, M, d, d, sv.co.view(M, d), f'{pfx}.cross_attn.out_proj.weight', f'{pfx}.cross_attn.out_proj.bias',
+                             dx_out=dco.view(M, d))
+            dq, dkv = self._empty(B, T, d, dtype=BF16), self._empty(B, S, 2 * d, dtype=BF16)
+            ops.attention_bwd(sv.q, sv.kv[..., :d], sv.kv[..., d:], sv.co, dco, sv.lse_c, ws, dq, dkv[..., :d], dkv[..., d:],
+                              B, H, T, S, False)
+            dqf, dkvf = dq.view(M, d), dkv.view(B * S, 2 * d)
+            ops.colsum(dqf, gbin[:d], M, d, accumulate=True)
+            ops.gemm(dqf, sv.ln3, gin[:d], d, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            ops.gemm(dqf, win[:d], dln, M, d, d, b_kmajor=True)
+            ops.colsum(dkvf, gbin[d:], B * S, 2 * d, accumulate=True)
+            ops.gemm(dkvf, sv.mem, gin[d:], 2 * d, d, B * S, a_kmajor=True, b_kmajor=True, accumulate=True)
+            ops.gemm(dkvf, win[d:], dmem, B * S, d, 2 * d, b_kmajor=True, accumulate=True)
+            ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_3.weight'), sv.m3, sv.r3, dx, a.G(f'{pfx}.ln_3.weight'),
+                              a.G(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb)
+        # ---- self attention: x1 = x + c_proj(attn(c_attn(ln_1 x)))
+        dao = self._empty(B, T, d, dtype=BF16)
+        self._linear_bwd(dxb, M, d, d, sv.ao.view(M, d), f'{pfx}.attn.c_proj.weight',
+                         f'{pfx}.attn.c_proj.bias' if a.G(f'{pfx}.attn.c_proj.bias') is not None else None, dx_out=dao.view(M, d))
+        dqkv = self._empty(B, T, 3 * d, dtype=BF16)
+        q, k, v = sv.qkv[..., :d], sv.qkv[..., d:2 * d], sv.qkv[..., 2 * d:]
+        ops.attention_bwd(q, k, v, sv.ao, dao, sv.lse, ws, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, T, T, causal)
+        self._linear_bwd(dqkv.view(M, 3 * d), M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
+                         f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
+        ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
+                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None)
+
+    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem):
+        dxb = self._empty(B * T, d, dtype=BF16)
+        for l in reversed(range(len(saves))):
+            ops.grad_normalize(dx, self._ws[:1], dxb)          # normalize_gradients at the block output
+            self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False)
+
+    # ------------------------------------------------------------------------------------------------ encoder
+    def encode(self, images: torch.Tensor, save: bool):
+        a, e = self.arena, self.enc
+        images = images.to(device=a.device, dtype=F32).contiguous()
+        B, C, Hh, Ww = images.shape
+        acts, cur = [], images
+        for i, (nm, cin, cout) in enumerate(self.conv):
+            y = self._empty(B, cout, Hh, Ww, dtype=BF16)
+            ops.conv_fwd(cur, i > 0, a.P(f'{nm}.weight'), a.P(f'{nm}.bias'), y, self._conv_ws, B, cin, cout, Hh, Ww, e.k)
+            acts.append(y)
+            cur = y
+        M0, d, T = B * e.P2, e.d, e.ncls + e.P2
+        flat = cur.view(M0, self.input_d)                       # encoder.py:166 flat reshape: same memory
+        proj = self._empty(M0, d)
+        ops.gemm(flat, a.W(f'{self.ep}projector.weight'), proj, M0, d, self.input_d, bias=a.P(f'{self.ep}projector.bias'))
+        g, bta = a.P(f'{self.ep}ln_input.weight'), a.P(f'{self.ep}ln_input.bias')
+        wpe = a.P(f'{self.ep}transformer.wpe.weight')
+        y1, st1, st2 = self._empty(B, e.P2, d), self._empty(B, ops.LNND_STATS_STRIDE), self._empty(B, ops.LNND_STATS_STRIDE)
+        ops.layernorm_nd_fwd(proj, None, g, bta, y1, e.P2 * d, st1, B, e.P2, d)
+        x = self._empty(B, T, d)
+        ops.layernorm_nd_fwd(y1, wpe, g, bta, x[:, e.ncls:], T * d, st2, B, e.P2, d)
+        ops.bcast_rows(a.P(f'{self.ep}cls_token'), x, T * d, B, e.ncls, d)
+        saves, cur_x = [], x.view(B * T, d)
+        for l in range(e.L):
+            cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save)
+            saves.append(sv)
+        Mc = B * e.ncls
+        cls = self._empty(Mc, d)
+        ops.copy_rows(cur_x, T * d, cls, e.ncls * d, B, e.ncls, d)
+        mf, rf = self._empty(Mc), self._empty(Mc)
+        gf, bf = a.P(f'{self.ep}transformer.ln_f.weight'), a.P(f'{self.ep}transformer.ln_f.bias')
+        if self.has_bridge:
+            lnf = self._empty(Mc, d, dtype=BF16)
+            ops.layernorm_fwd(cls, gf, bf, lnf, mf, rf, Mc, d)
+            enc_out = self._empty(Mc, self.dec.d)
+            ops.gemm(lnf, a.W('encoder.1.weight'), enc_out, Mc, self.dec.d, d)
+        else:
+            lnf = None
+            enc_out = self._empty(Mc, d)
+            ops.layernorm_fwd(cls, gf, bf, enc_out, mf, rf, Mc, d)
+        ctx = None
+        if save:
+            ctx = SimpleNamespace(images=images, acts=acts, flat=flat, proj=proj, y1=y1, st1=st1, st2=st2, saves=saves,
+                                  cls=cls, mf=mf, rf=rf, lnf=lnf, B=B, Hh=Hh, Ww=Ww)
+        return enc_out.view(B, e.ncls, -1), ctx
+
+    def encode_backward(self, ctx, denc: torch.Tensor):
+        """denc: fp32 [B*ncls, d_out] gradient w.r.t. the encoder output (bridge output when there is one)."""
+        a, e = self.arena, self.enc
+        B, d, T, Mc = ctx.B, e.d, e.ncls + e.P2, ctx.B * e.ncls
+        gf = a.P(f'{self.ep}transformer.ln_f.weight')
+        dcls = self._empty(Mc, d)
+        if self.has_bridge:
+            dencb = self._empty(Mc, self.dec.d, dtype=BF16)
+            ops.cast_f32_bf16(denc, dencb)
+            dlnf = self._empty(Mc, d, dtype=BF16)
+            self._linear_bwd(dencb, Mc, self.dec.d, d, ctx.lnf, 'encoder.1.weight', None, dx_out=dlnf)
+            ops.layernorm_bwd(dlnf, ctx.cls, gf, ctx.mf, ctx.rf, dcls, a.G(f'{self.ep}transformer.ln_f.weight'),
+                              a.G(f'{self.ep}transformer.ln_f.bias'), Mc, d)
+        else:
+            ops.layernorm_bwd(denc, ctx.cls, gf, ctx.mf, ctx.rf, dcls, a.G(f'{self.ep}transformer.ln_f.weight'),
+                              a.G(f'{self.ep}transformer.ln_f.bias'), Mc, d)
+        dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
+        ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
+        self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
+        ops.sum_over_batch(dx, T * d, a.G(f'{self.ep}cls_token'), B, e.ncls, d, accumulate=True)
+        g = a.P(f'{self.ep}ln_input.weight')
+        gg, gb = a.G(f'{self.ep}ln_input.weight'), a.G(f'{self.ep}ln_input.bias')
+        dy1, dproj = self._empty(B, e.P2, d), self._empty(B, e.P2, d)
+        ops.layernorm_nd_bwd(dx[:, e.ncls:], T * d, ctx.y1, a.P(f'{self.ep}transformer.wpe.weight'), g, ctx.st2, dy1, gg, gb,
+                             a.G(f'{self.ep}transformer.wpe.weight'), B, e.P2, d)
+        ops.layernorm_nd_bwd(dy1, e.P2 * d, ctx.proj, None, g, ctx.st1, dproj, gg, gb, None, B, e.P2, d)
+        M0 = B * e.P2
+        dpb = self._empty(M0, d, dtype=BF16)
+        ops.cast_f32_bf16(dproj, dpb)
+        dflat = self._empty(M0, self.input_d, dtype=BF16)
+        self._linear_bwd(dpb, M0, d, self.input_d, ctx.flat, f'{self.ep}projector.weight',
+                         f'{self.ep}projector.bias' if a.G(f'{self.ep}projector.bias') is not None else None, dx_out=dflat)
+        dy = dflat.view(B, self.conv[-1][2], ctx.Hh, ctx.Ww)
+        for i in reversed(range(len(self.conv))):
+            nm, cin, cout = self.conv[i]
+            xin = ctx.images if i == 0 else ctx.acts[i - 1]
+            ops.conv_bwd_weight(dy, xin, i > 0, a.G(f'{nm}.weight'), a.G(f'{nm}.bias'), B, cin, cout, ctx.Hh, ctx.Ww, e.k)
+            if i > 0:
+                dxi = self._empty(B, cin, ctx.Hh, ctx.Ww, dtype=BF16)
+                ops.conv_bwd_data(dy, a.P(f'{nm}.weight'), ctx.acts[i - 1], True, dxi, self._conv_ws, B, cin, cout, ctx.Hh, ctx.Ww, e.k)
+                dy = dxi
+
+    # ------------------------------------------------------------------------------------------------ decoder
+    def _mem_bf16(self, enc_out: torch.Tensor):
+        mem = self._empty(enc_out.shape[0] * enc_out.shape[1], enc_out.shape[2], dtype=BF16)
+        ops.cast_f32_bf16(enc_out.contiguous(), mem)
+        return mem
+
+    def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0):
+        """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [B*T,d], hidden bf16, ctx)."""
+        a, dc = self.arena, self.dec
+        if T + pos_offset > dc.block:
+            raise AssertionError(f'Cannot forward sequence of length {T + pos_offset}, block size is only {dc.block}')
+        d, M = dc.d, B * T
+        x = self._empty(M, d)
+        wpe = a.P(f'{self.dp}transformer.wpe.weight')
+        if ids is not None:
+            ids = ids.to(device=a.device, dtype=torch.long).contiguous()
+            ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
+        else:
+            ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
+            ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
+        saves, cur = [], x
+        for l in range(dc.L):
+            m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
+            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save)
+            saves.append(sv)
+        hid, mf, rf = self._empty(M, d), self._empty(M), self._empty(M)
+        ops.layernorm_fwd(cur, a.P(f'{self.dp}transformer.ln_f.weight'), a.P(f'{self.dp}transformer.ln_f.bias'), hid, mf, rf, M, d)
+        hb = self._empty(M, d, dtype=BF16)
+        ops.cast_f32_bf16(hid, hb)
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset) if save else None
+        return hid, hb, ctx
+
+    def logits_f32(self, hb: torch.Tensor, M: int):
+        out = self._empty(M, self.dec.V)
+        ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), out, M, self.dec.V, self.dec.d)
+        return out
+
+    def logits_bf16(self, hb: torch.Tensor, M: int):
+        """bf16 logits [M, Vp] in a cached buffer whose pad columns are zero and are never written."""
+        buf = self._logits_cache.get(M)
+        if buf is None:
+            buf = torch.zeros(M, self.dec.Vp, dtype=BF16, device=self.arena.device)
+            self._logits_cache[M] = buf
+        ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), buf, M, self.dec.V, self.dec.d)
+        return buf
+
+    def decode_backward(self, ctx, dlogits_bf: Optional[torch.Tensor], dhid: Optional[torch.Tensor], dmem):
+        """dlogits_bf: bf16 [M, Vp] (pads zero) or None; dhid: fp32 [M, d] or None; dmem: fp32 [B*S, d] accumulator."""
+        a, dc = self.arena, self.dec
+        B, T, d, M = ctx.B, ctx.T, dc.d, ctx.B * ctx.T
+        wte = f'{self.dp}transformer.wte.weight'
+        dh = torch.zeros(M, d, dtype=F32, device=a.device) if dlogits_bf is None else self._empty(M, d)
+        if dlogits_bf is not None:
+            ops.gemm(dlogits_bf, ctx.hb, a.G(wte), dc.V, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)   # tied lm_head
+            ops.gemm(dlogits_bf, a.W(wte), dh, M, d, dc.V, b_kmajor=True)
+        if dhid is not None:
+            ops.add_(dh, dhid.contiguous())
+        dx = self._empty(M, d)
+        ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
+                          a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
+        self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem)
+        if ctx.ids is not None:
+            ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), B, T, d, ctx.pos_offset, dc.V)
+            return None
+        ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)
+        return dx      # gradient w.r.t. the embeddings fed in

@@ -1,0 +1,135 @@
+"""Parameter containers for the transformer / conv blocks (reference models/layers.py).
+
+The module tree, attribute names, parameter shapes and initial distributions match the reference so that
+``state_dict()`` keys and checkpoints are interchangeable.  The arithmetic does NOT live here: it is
+``engine.HotPath`` launching HIP kernels; these classes only own parameters (and refuse unsupported variants).
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..configs.models import MLPConfig, SelfAttentionConfig, SelfAttentionType, TransformerConfig
+
+_STANDALONE = ('{} is a parameter container in image2text_amd: its arithmetic runs inside the fused HIP path '
+               '(VisionEncoderDecoder / Encoder / Decoder forward), not as a standalone torch module')
+
+
+class _Container(nn.Module):
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(_STANDALONE.format(type(self).__name__))
+
+
+class LayerNorm(_Container):
+    """weight (+ optional bias) of a row LayerNorm, eps 1e-5 (reference layers.py:349-358)."""
+
+    def __init__(self, ndim: int, bias: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ndim))
+        self.bias = nn.Parameter(torch.zeros(ndim)) if bias else None
+
+
+class LayerNormND(_Container):
+    """weight (+ optional bias) of a LayerNorm over the trailing ``shape`` dims jointly (reference layers.py:361-370)."""
+
+    def __init__(self, shape: Tuple[int, ...], bias: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(*shape))
+        self.bias = nn.Parameter(torch.zeros(*shape)) if bias else None
+
+
+class ConvMLP(_Container):
+    """Conv2d('same') [GELU(tanh) Conv2d('same')]* -- Sequential slots 0,2,4,... hold the convs (layers.py:258-282)."""
+
+    def __init__(self, in_features: int, out_features: int, kernel_size: Tuple[int, int],
+                 gate_sizes: Optional[Tuple[int, ...]] = None):
+        super().__init__()
+        if kernel_size[0] != kernel_size[1] or kernel_size[0] not in (4, 6):
+            raise NotImplementedError(f'feature_extractor_kernel_size {kernel_size}: the HIP conv kernels cover 4x4 and 6x6')
+        blocks, prev = [], in_features
+        for width in (gate_sizes or []):
+            blocks += [nn.Conv2d(prev, width, kernel_size, padding='same'), nn.GELU(approximate='tanh')]
+            prev = width
+        blocks.append(nn.Conv2d(prev, out_features, kernel_size, padding='same'))
+        self.model = nn.Sequential(*blocks)
+
+
+class MultiHeadAttention(_Container):
+    """c_attn (d -> 3d) and c_proj (d -> d) of the fused self-attention (reference layers.py:433-445)."""
+
+    def __init__(self, config: SelfAttentionConfig):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.config = config
+        self.c_attn = nn.Linear(config.n_embd, 3 * config.n_embd, bias=config.bias)
+        self.c_proj = nn.Linear(config.n_embd, config.n_embd, bias=config.bias)
+        self.n_head, self.n_embd, self.dropout = config.n_head, config.n_embd, config.dropout
+
+
+class SelfAttention:
+    @classmethod
+    def from_config(cls, config: SelfAttentionConfig):
+        if config.attn_type == SelfAttentionType.MULTI_HEAD:
+            return MultiHeadAttention(config)
+        raise NotImplementedError('multi_query attention is outside the HIP hot path (SURVEY.md 8(f) next #2)')
+
+
+class _MLP(_Container):
+    """c_fc (d -> ff d), c_proj (ff d -> d) of the GELU-MLP (reference layers.py:473-479)."""
+
+    def __init__(self, n_embd: int, bias: bool, dropout: float, config: MLPConfig):
+        super().__init__()
+        hidden = int(config.ff_mult * n_embd)
+        self.c_fc = nn.Linear(n_embd, hidden, bias=bias)
+        self.c_proj = nn.Linear(hidden, n_embd, bias=bias)
+
+
+class _CrossAttentionParams(_Container):
+    """Parameters of nn.MultiheadAttention(batch_first) as the reference instantiates it (layers.py:537-542):
+    packed in_proj (3d, d) + bias (always present) and out_proj; same names and the same default initialisation."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class TransformerBlock(_Container):
+    """Pre-LN block: x += attn(ln_1 x); x += cross(ln_3 x, enc); x += mlp(ln_2 x); normalize_gradients(x)
+    (reference layers.py:521-608, dense branch only)."""
+
+    def __init__(self, config: TransformerConfig, seed: Optional[int] = None, n_cls: int = 0):
+        super().__init__()
+        why = config.hot_path_unsupported_reason()
+        if why is not None:
+            raise NotImplementedError(f'TransformerBlock variant outside the HIP hot path: {why}')
+        ac = config.attn_config
+        self.is_causal = config.is_causal
+        self.ln_1 = LayerNorm(ac.n_embd, bias=ac.bias)
+        self.attn = SelfAttention.from_config(ac)
+        self.ln_2 = LayerNorm(ac.n_embd, bias=ac.bias)
+        self.mlp = _MLP(ac.n_embd, ac.bias, ac.dropout, config.rotator_config)
+        self.is_cross_attn = config.is_cross_attn
+        self.cross_attn = _CrossAttentionParams(ac.n_embd) if config.is_cross_attn else nn.Identity()
+        self.ln_3 = LayerNorm(ac.n_embd, bias=ac.bias) if config.is_cross_attn else nn.Identity()
+        self.is_sparse = False
+        self.null_connector = nn.Identity()
+
+
+def init_gpt_weights_(module: nn.Module, n_layer: int):
+    """nanoGPT initialisation of the decoder (reference decoder.py:192-212): N(0, 0.02) for Linear / Embedding
+    weights, zero Linear biases, N(0, 0.02 / sqrt(2 n_layer)) for the residual projections ``*.c_proj.weight``."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+    for name, p in module.named_parameters():
+        if name.endswith('c_proj.weight'):
+            nn.init.normal_(p, mean=0.0, std=0.02 / math.sqrt(2 * n_layer))

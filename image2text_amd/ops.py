@@ -63,10 +63,10 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d):
     return y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None):
     _need_cuda(dy, x, dx)
     _l.check(_lib().i2t_layernorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
-                                      int(dx_accumulate), _p(dgamma), _p(dbeta), M, d), 'i2t_layernorm_bwd')
+                                      int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d), 'i2t_layernorm_bwd')
     return dx
 
 
@@ -134,9 +134,9 @@ def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
                                _p(gscale), M, V), 'i2t_ce_bwd')
 
 
-def grad_normalize(g: torch.Tensor, ws: torch.Tensor):
+def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None):
     _need_cuda(g, ws)
-    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws)), 'i2t_grad_normalize')
+    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws), _p(g_bf16)), 'i2t_grad_normalize')
     return g
 
 

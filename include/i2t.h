@@ -65,13 +65,14 @@ int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* ou
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (layers.py:349-358, F.layer_norm eps 1e-5, optional bias)
  *   fwd: x f32 [M][d] -> y (bf16 or f32) [M][d]; saves mean/rstd f32 [M] when non-null
- *   bwd: dx[M][d] (f32) (+)= LN'(dy); dgamma/dbeta f32 [d] are ACCUMULATED (atomics); dy bf16 or f32
+ *   bwd: dx[M][d] (f32) (+)= LN'(dy); dgamma/dbeta f32 [d] are ACCUMULATED (atomics); dy bf16 or f32;
+ *        dx_bf16 (nullable): bf16 copy of the final dx rows, i.e. the A operand of the next backward GEMMs
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta,
                       void* y, int y_is_f32, float* mean, float* rstd, int M, int d);
 int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                       const float* mean, const float* rstd,
-                      float* dx, int dx_accumulate, float* dgamma, float* dbeta, int M, int d);
+                      float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNormND (layers.py:361-370 via encoder.py:150,166,170): one normalisation per image over the joint
@@ -128,9 +129,9 @@ int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const 
 
 /* ---------------------------------------------------------------------------------------------------------
  * Gradient normaliser (functions.py:19-24): g <- g / (||g||_2 + 1e-6) over the whole f32 tensor, in place.
- *   ws = 1 float of zero-initialised-by-the-call scratch.
+ *   ws = 1 float of zero-initialised-by-the-call scratch; g_bf16 (nullable) receives a bf16 copy of the result.
  * --------------------------------------------------------------------------------------------------------- */
-int i2t_grad_normalize(void* stream, float* g, long n, float* ws);
+int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16);
 
 /* ---------------------------------------------------------------------------------------------------------
  * ConvMLP feature extractor (layers.py:258-282): Conv2d(k x k, padding='same', k even => pad (k-1)/2 before,

@@ -148,8 +148,10 @@ def test_layernorm(ops, M, d, bias):
     for dy_in, tol in ((dy, 1e-4), (dy.to(BF16), 2e-2)):
         dx = torch.full((M, d), 0.25, device=dev())
         dg, db = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
-        ops.layernorm_bwd(dy_in, x, g, mean, rstd, dx, dg, db if bias else None, M, d, dx_accumulate=True)
+        dxb = torch.empty(M, d, dtype=BF16, device=dev())
+        ops.layernorm_bwd(dy_in, x, g, mean, rstd, dx, dg, db if bias else None, M, d, dx_accumulate=True, dx_bf16=dxb)
         check('ln dx (+accumulate)', dx, xr.grad + 0.25, tol, tol)
+        check('ln dx bf16 copy', dxb, dx, 0, 1 / 128)
         check('ln dgamma', dg, gr.grad, tol * math.sqrt(M), tol)
         if bias:
             check('ln dbeta', db, br.grad, tol * math.sqrt(M), tol)
@@ -285,8 +287,10 @@ def test_grad_normalize(ops):
         g = rnd(n, seed=29) * 3
         ref = g / (torch.linalg.vector_norm(g.double()).float() + 1e-6)
         ws = torch.empty(1, device=dev())
-        ops.grad_normalize(g, ws)
+        gb = torch.empty(n, dtype=BF16, device=dev())
+        ops.grad_normalize(g, ws, gb)
         check('grad_normalize', g, ref, 1e-7, 1e-4)
+        check('grad_normalize bf16 copy', gb, g, 0, 1 / 128)
 
 
 # ------------------------------------------------------------------------------------------------------ conv stack
