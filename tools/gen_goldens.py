@@ -119,6 +119,18 @@ def main():
     wrapper = RefWrapper(rcfg, tok, RefTrainerCfg(), ignore_index=-100)
     det_init_(wrapper.model, seed=0)
     templates, caps = class_task(6, 32, T, vocab)
+    # well-conditioned gradient fixture: untrained det_init_ weights (regenerated in the test, not stored)
+    g0 = torch.Generator().manual_seed(11)
+    cls0 = torch.tensor([0, 3, 5, 1])
+    images0 = templates[cls0] + 0.1 * torch.randn(4, 3, 32, 32, generator=g0)
+    wrapper.train()
+    loss0, _ = wrapper.train_step(images0, caps[cls0])
+    loss0.backward()
+    init = {'loss': np.float32(loss0.item()), 'images': images0.numpy(), 'labels': caps[cls0].numpy()}
+    for n, p in wrapper.model.named_parameters():
+        init[f'grad.{n}'] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'tiny_train_init.npz'), **init)
+    wrapper.zero_grad()
     opt = torch.optim.AdamW(wrapper.parameters(), lr=2e-3, betas=(0.9, 0.95))
     g = torch.Generator().manual_seed(3)
     wrapper.train()
