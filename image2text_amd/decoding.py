@@ -1,0 +1,154 @@
+"""Greedy decoding with a static KV cache under hipGraph replay.
+
+Replaces the reference's cache-free sampling loop (models/vision_encoder_decoder.py:136-182 with ``top_k=1``,
+``temperature=1``): there every new token re-runs the whole decoder over all t tokens and synchronises with the host
+for the n-gram ban (``.tolist()``).  Here
+  * the encoder runs once, the cross-attention K/V of every cross layer are projected once per image;
+  * one decode step = one token per caption through single-row kernels: LayerNorm -> QKV GEMM -> append K/V to the
+    cache -> attention of the new query against keys 0..pos -> projections / MLP with fused residuals -> ln_f ->
+    tied lm_head (fp32 logits) -> on-device no-repeat-n-gram ban + argmax that appends the token to the id buffer;
+  * every position-dependent kernel reads ``pos`` / ``len`` from device memory, so the step is captured ONCE into a
+    hipGraph and replayed per token: no host sync, no per-step launch overhead, token ids never leave the GPU until
+    the end.
+Because text rows never attend to the soft-prompt columns (see engine.py) the cache holds text positions only; the
+prompt shifts the position embedding by n_cls.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .engine import BF16, F32, HotPath
+
+
+class GreedyDecoder:
+    def __init__(self, model):
+        self.model = model
+        self.eng: HotPath = model._engine
+        self._state = None
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _build(self, B: int, ids_ld: int):
+        eng, a = self.eng, self.eng.arena
+        dc = eng.dec
+        dev = a.device
+        cfg = self.model.config
+        ncls = eng.enc.ncls
+        off = ncls if cfg.use_soft_prompting else 0
+        tmax = dc.block - off
+        d, ff = dc.d, dc.ff
+        st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a)
+        e = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=dev)
+        st.ids = torch.zeros(B, ids_ld, dtype=torch.long, device=dev)
+        st.counters = torch.zeros(2, dtype=torch.int32, device=dev)        # [pos, len]
+        st.x = e(B, d, dtype=F32)
+        st.ln = e(B, d)
+        st.qkv = e(B, 3 * d)
+        st.ao = e(B, d)
+        st.q = e(B, d)
+        st.h = e(B, ff)
+        st.hid = e(B, d)
+        st.logits = e(B, dc.V, dtype=F32)
+        st.margin = e(B, dtype=F32)
+        st.kc = [e(B, tmax, d) for _ in range(dc.L)]
+        st.vc = [e(B, tmax, d) for _ in range(dc.L)]
+        S = ncls
+        st.cross_kv = {l: (e(B, S, 2 * d), S) for l in self._cross_layers()}
+        st.ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
+        st.graph_full = st.graph_prefill = None
+        return st
+
+    def _cross_layers(self):
+        cfg = self.model.config
+        return [l for l in range(self.eng.dec.L)
+                if cfg.use_cross_attn and (self.eng.dec_cross[l] or not cfg.decoder_config.skip_alternate_cross_attn)]
+
+    # ------------------------------------------------------------------------------------------------ one token
+    def _step(self, st, with_head: bool):
+        """Consume the token at ids[:, pos]; when with_head also choose ids[:, len]; then advance pos and len."""
+        eng, a, dc = self.eng, self.eng.arena, self.eng.dec
+        B, d, ff, H = st.B, dc.d, dc.ff, dc.H
+        pos_ptr, len_ptr = st.counters[0:1], st.counters[1:2]
+        dp = eng.dp
+        ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(f'{dp}transformer.wte.weight'), a.P(f'{dp}transformer.wpe.weight'),
+                       st.x, B, d, st.off, dc.V)
+        for l in range(dc.L):
+            p = f'{dp}transformer.h.{l}'
+            ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
+            ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
+            ops.kv_append(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, pos_ptr, B, d)
+            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, st.ao, d, pos_ptr, 0, B, H)
+            ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
+            if l in st.cross_kv:
+                kv, S = st.cross_kv[l]
+                win, bin_ = a.W(f'{p}.cross_attn.in_proj_weight'), a.P(f'{p}.cross_attn.in_proj_bias')
+                ops.layernorm_fwd(st.x, a.P(f'{p}.ln_3.weight'), a.P(f'{p}.ln_3.bias'), st.ln, None, None, B, d)
+                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d])
+                ops.decode_attention(st.q, d, kv, kv.view(-1)[d:], S * 2 * d, 2 * d, st.ao, d, None, S, B, H)
+                ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), st.x, B, d, d,
+                         bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=st.x)
+            ops.layernorm_fwd(st.x, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
+            ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
+            ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
+        if with_head:
+            ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
+            ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
+            ops.ngram_ban_argmax(st.logits, dc.V, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
+        ops.advance(pos_ptr, 1)
+        ops.advance(len_ptr, 1)
+
+    def _capture(self, st, with_head: bool):
+        side = torch.cuda.Stream(device=st.arena.device)
+        side.wait_stream(torch.cuda.current_stream())
+        g = ops.Graph()
+        with torch.cuda.stream(side):
+            g.begin()
+            self._step(st, with_head)
+            g.end()
+        torch.cuda.current_stream().wait_stream(side)
+        return g
+
+    # ------------------------------------------------------------------------------------------------ public
+    @torch.no_grad()
+    def generate(self, images, prompt_ids: torch.Tensor, max_new_tokens: int, return_margins: bool = False,
+                 use_graph: bool = True):
+        eng = self.eng
+        a = eng.prepare(False)
+        dc = eng.dec
+        B, P = prompt_ids.shape
+        total = P + max_new_tokens
+        st = self._state
+        if st is None or st.B != B or st.arena is not a or st.ids_ld < total:
+            st = self._state = self._build(B, max(total, dc.block))
+        assert total <= st.tmax, f'prompt + new tokens ({total}) exceed the text window ({st.tmax})'
+        # encoder + per-layer cross K/V (once per image)
+        enc_out, _ = eng.encode(images, False)
+        S = enc_out.shape[1]
+        if st.cross_kv:
+            assert S == next(iter(st.cross_kv.values()))[1]
+            mem = eng._mem_bf16(enc_out)
+            for l, (kv, _) in st.cross_kv.items():              # persistent buffers: captured graphs bake their pointers
+                p = f'{eng.dp}transformer.h.{l}.cross_attn'
+                ops.gemm(mem, a.W(f'{p}.in_proj_weight')[dc.d:], kv.view(B * S, 2 * dc.d), B * S, 2 * dc.d, dc.d,
+                         bias=a.P(f'{p}.in_proj_bias')[dc.d:])
+        st.ids.zero_()
+        st.ids[:, :P] = prompt_ids
+        st.counters.copy_(torch.tensor([0, 1], dtype=torch.int32))
+        margins = torch.zeros(max_new_tokens, B, dtype=F32, device=a.device) if return_margins else None
+        if use_graph and st.graph_full is None:
+            # warm up eagerly once (code objects must be loaded before capture), then capture both step kinds
+            self._step(st, True)
+            self._step(st, False)
+            st.graph_full = self._capture(st, True)
+            st.graph_prefill = self._capture(st, False)
+            st.ids.zero_()
+            st.ids[:, :P] = prompt_ids
+            st.counters.copy_(torch.tensor([0, 1], dtype=torch.int32))
+        for _ in range(P - 1):                                  # prompt tokens before the last: fill the cache only
+            st.graph_prefill.launch() if use_graph else self._step(st, False)
+        for i in range(max_new_tokens):
+            st.graph_full.launch() if use_graph else self._step(st, True)
+            if return_margins:
+                margins[i].copy_(st.margin)
+        out = st.ids[:, :total].clone()
+        return (out, margins.t().contiguous()) if return_margins else out

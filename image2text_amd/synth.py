@@ -117,18 +117,49 @@ def synthetic_batch(batch: int, img: int, caption_len: int, vocab: int, seed: in
     return images, labels
 
 
+def _reference_style(name: str, p: torch.Tensor, x: torch.Tensor, n_layer_dec: int) -> torch.Tensor:
+    """The reference's own initial DISTRIBUTIONS (same moments, Gaussian draws): decoder = nanoGPT init
+    (decoder.py:192-212: N(0, 0.02) weights, zero biases, c_proj N(0, 0.02/sqrt(2L)), xavier in_proj); encoder = torch
+    defaults (Linear/Conv kaiming-uniform(a=sqrt 5) => std 1/sqrt(3 fan_in), Embedding N(0,1), CLS randn/sqrt(d))."""
+    leaf = name.rsplit('.', 1)[-1]
+    is_ln = ('.ln_' in name or name.startswith('ln_') or 'ln_input' in name)
+    if is_ln:
+        return torch.ones_like(x) if leaf == 'weight' else torch.zeros_like(x)
+    if name.startswith('decoder.'):
+        if leaf in ('bias', 'in_proj_bias'):
+            return torch.zeros_like(x)
+        if leaf == 'in_proj_weight':
+            return x * (2.0 / (p.shape[0] + p.shape[1])) ** 0.5
+        if name.endswith('c_proj.weight'):
+            return x * 0.02 / (2 * n_layer_dec) ** 0.5
+        return 0.02 * x
+    if 'cls_token' in name:
+        return x / (p.shape[-1] ** 0.5)
+    if '.wpe.' in name:
+        return x
+    fan_in = p[0].numel() if p.dim() >= 2 else None
+    if fan_in is None:                                      # conv / linear biases: U(+-1/sqrt(fan_in)) scale
+        return 0.05 * x
+    return x / (3.0 * fan_in) ** 0.5
+
+
 @torch.no_grad()
-def det_init_(module: torch.nn.Module, seed: int = 0) -> torch.nn.Module:
+def det_init_(module: torch.nn.Module, seed: int = 0, style: str = 'stress') -> torch.nn.Module:
     """Overwrite every parameter from ``Generator(seed ^ crc32(name))`` on the CPU, then copy to the param's device.
 
-    Scales are chosen so that nothing is hidden by a trivial value: matrices ~N(0, 0.02^2) (projection matrices
-    N(0, fan_in^-1/2 * 0.5)), LayerNorm gains 1 + 0.1 N, biases 0.02 N, CLS tokens N(0, 1/d).
+    ``style='stress'`` (default): scales chosen so that nothing is hidden by a trivial value and every residual
+    branch contributes O(1): linear maps N(0, 0.7^2/fan_in), LayerNorm gains 1 + 0.1 N, biases 0.02 N, CLS N(0, 1/d).
+    ``style='reference'``: the reference's own initial distributions (see ``_reference_style``).
     Tied parameters are visited once (``named_parameters`` de-duplicates).
     """
+    n_layer_dec = sum(1 for n, _ in module.named_parameters() if n.startswith('decoder.') and n.endswith('ln_1.weight'))
     for name, p in module.named_parameters():
         g = torch.Generator().manual_seed((seed * 1000003) ^ zlib.crc32(name.encode()))
         x = torch.randn(p.shape, generator=g, dtype=torch.float32)
         leaf = name.rsplit('.', 1)[-1]
+        if style == 'reference':
+            p.copy_(_reference_style(name, p, x, max(n_layer_dec, 1)).to(p.device, p.dtype))
+            continue
         if p.dim() >= 2 and ('ln_' in name or 'ln_input' in name) and leaf == 'weight':
             x = 1.0 + 0.1 * x                      # LayerNormND gain (2-D)
         elif p.dim() == 1 and leaf == 'weight':

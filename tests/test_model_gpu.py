@@ -224,9 +224,13 @@ def test_nano224_full_size_forward_and_loss(nano224_golden):
     with torch.no_grad():
         out = w.model(images=images.to(dev()), ids=ids.to(dev()))
         vloss, _ = w.val_step(images.to(dev()), labels.to(dev()))
+    # 'stress' weights (every residual branch O(1), 12 layers of bf16 rounding): measured max 1.6-2e-2, rms 4e-3
     maxerr('nano224.encoder_output', out.encoder_output, g['encoder_output'], 3e-2)
-    maxerr('nano224.logits_head', out.logits[:, :, :256], g['logits_head'], 1e-2)
-    maxerr('nano224.logits_tail', out.logits[:, :, -64:], g['logits_tail'], 1e-2)
+    maxerr('nano224.logits_head', out.logits[:, :, :256], g['logits_head'], 2.5e-2)
+    maxerr('nano224.logits_tail', out.logits[:, :, -64:], g['logits_tail'], 2.5e-2)
+    rms = float((out.logits[:, :, :256].float().cpu() - torch.from_numpy(g['logits_head'])).pow(2).mean().sqrt())
+    REPORT['nano224.logits_head_rms_err'] = {'got': rms}
+    assert rms <= 5e-3
     maxerr('nano224.logits_lse', torch.logsumexp(out.logits.float(), -1), g['logits_lse'], 1e-2)
     maxerr('nano224.hidden_text', out.hidden_state[:, 64:], g['hidden_text'], hidden_tol(g['hidden_text']))
     REPORT['nano224.val_loss'] = {'got': float(vloss), 'ref': float(g['val_loss'])}
@@ -248,3 +252,100 @@ def test_nano224_full_size_forward_and_loss(nano224_golden):
         if abs(got - ref) > 6e-2 * ref + 1e-7:
             bad.append((n, got, ref))
     assert not bad, bad[:8]
+
+
+def test_nano224_reference_init_logits_within_1e2():
+    """North-star tolerance: logits within 1e-2 of the fp32 reference at the reference's own initial distributions."""
+    from conftest import load_golden
+    g = load_golden('nano224_refinit.npz')
+    cfg = nano224_config()
+    w = _wrapper(cfg)
+    det_init_(w.model, seed=0, style='reference')
+    w.eval()
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    images, labels = synthetic_batch(2, 224, 64, cfg.decoder_config.vocab_size, seed=1)
+    ids = torch.where(labels != -100, labels, torch.full_like(labels, tok.eos_token_id))
+    ids = torch.cat((torch.full((2, 1), tok.bos_token_id), ids), dim=1)[:, :64]
+    with torch.no_grad():
+        out = w.model(images=images.to(dev()), ids=ids.to(dev()))
+        vloss, _ = w.val_step(images.to(dev()), labels.to(dev()))
+    maxerr('nano224_refinit.encoder_output', out.encoder_output, g['encoder_output'], 3e-2)
+    maxerr('nano224_refinit.logits_head', out.logits[:, :, :256], g['logits_head'], 1e-2)
+    maxerr('nano224_refinit.logits_tail', out.logits[:, :, -64:], g['logits_tail'], 1e-2)
+    maxerr('nano224_refinit.logits_lse', torch.logsumexp(out.logits.float(), -1), g['logits_lse'], 1e-2)
+    assert abs(float(vloss) - float(g['val_loss'])) <= 1e-3 * float(g['val_loss'])
+
+
+# ------------------------------------------------------------------------------------------------------ greedy decode
+def assert_greedy_matches(model, images, gold_ids, gold_margins, P, eps, use_graph=True):
+    """Token-exact wherever the oracle's top-1 margin >= eps; after a low-margin step the run is restarted from the
+    golden prefix so that every later step is still checked.  Returns the number of low-margin restarts."""
+    from image2text_amd.decoding import GreedyDecoder
+    dec = GreedyDecoder(model)
+    total = gold_ids.shape[1]
+    start, restarts = P, 0
+    while start < total:
+        out = dec.generate(images, torch.from_numpy(gold_ids[:, :start]).to(dev()), total - start, use_graph=use_graph)
+        out = out.cpu().numpy()
+        assert np.array_equal(out[:, :start], gold_ids[:, :start])
+        mism = out[:, start:] != gold_ids[:, start:]
+        if not mism.any():
+            break
+        first = int(mism.any(0).argmax())
+        col = start + first
+        for b in np.nonzero(mism[:, first])[0]:
+            assert gold_margins[b, col - P] < eps, (f'row {b} step {col - P}: token {out[b, col]} != {gold_ids[b, col]} although '
+                                                    f'the oracle margin is {gold_margins[b, col - P]:.4f} >= {eps}')
+        restarts += 1
+        start = col + 1
+    return restarts
+
+
+def test_tiny_greedy_tokens(tiny_model, tiny_decode):
+    d = tiny_decode
+    images = torch.from_numpy(d['images']).to(dev())
+    # trained tiny model: logits reach +-27, bf16 error up to ~0.2 there -> steps with margin < 0.5 may flip
+    r = assert_greedy_matches(tiny_model, images, d['ids'], d['margins'], 1, eps=0.5)
+    r3 = assert_greedy_matches(tiny_model, images, d['ids3'], d['margins3'], 3, eps=0.5)
+    REPORT['tiny.greedy'] = {'low_margin_restarts': r, 'low_margin_restarts_prompt3': r3,
+                             'steps_with_margin_ge_eps': int((d['margins'] >= 0.5).sum()), 'steps': int(d['margins'].size)}
+    # public API + hipGraph replay == eager step sequence
+    from image2text_amd.decoding import GreedyDecoder
+    prompt = torch.from_numpy(d['prompt']).to(dev())
+    a = tiny_model.generate(images, prompt, max_new_tokens=24, temperature=1.0, top_k=1)
+    b = GreedyDecoder(tiny_model).generate(images, prompt, 24, use_graph=False)
+    assert a.shape == (4, 25) and torch.equal(a, b)
+    a2 = tiny_model.generate(images, prompt, max_new_tokens=24, temperature=1.0, top_k=1)     # replay of the cached graph
+    assert torch.equal(a, a2)
+
+
+def test_sampling_modes_shapes(tiny_model, tiny_decode):
+    """The reference unit test's contract (models/vision_encoder_decoder_test.py:88-92): shapes of sampled ids."""
+    d = tiny_decode
+    images = torch.from_numpy(d['images']).to(dev())[:2]
+    ids = torch.from_numpy(d['ids3'][:2, :3]).to(dev())
+    out = tiny_model.generate(images, ids, max_new_tokens=8, temperature=1.0, nucleus_p=0.5)
+    assert tuple(out.shape) == (2, 11) and torch.equal(out[:, :3], ids)
+    out = tiny_model.generate(images, ids, max_new_tokens=4, temperature=0.7, top_k=5)
+    assert tuple(out.shape) == (2, 7)
+
+
+def test_nano224_greedy_tokens(nano224_golden):
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    g = nano224_golden
+    cfg = nano224_config()
+    m = det_init_(VisionEncoderDecoder(cfg), seed=0).to(dev()).eval()
+    images, _ = synthetic_batch(2, 224, 64, cfg.decoder_config.vocab_size, seed=1)
+    r = assert_greedy_matches(m, images.to(dev()), g['greedy_ids'], g['greedy_margins'], 1, eps=0.05)
+    REPORT['nano224.greedy'] = {'low_margin_restarts': r, 'steps_with_margin_ge_eps': int((g['greedy_margins'] >= 0.05).sum()),
+                                'steps': int(g['greedy_margins'].size)}
+    # full-size property: 64 new tokens for 8 captions, n-gram constraint holds on the output, replay is deterministic
+    images8, _ = synthetic_batch(8, 224, 64, cfg.decoder_config.vocab_size, seed=2)
+    prompt = torch.full((8, 1), cfg.decoder_config.vocab_size - 1, dtype=torch.long, device=dev())
+    out = m.generate(images8.to(dev()), prompt, max_new_tokens=64, top_k=1)
+    out2 = m.generate(images8.to(dev()), prompt, max_new_tokens=64, top_k=1)
+    assert tuple(out.shape) == (8, 65) and torch.equal(out, out2)
+    for row in out.cpu().tolist():
+        for n in (2, 3, 4, 5):
+            grams = [tuple(row[i:i + n]) for i in range(len(row) - n + 1)]
+            assert len(grams) == len(set(grams)), f'repeated {n}-gram in greedy output'

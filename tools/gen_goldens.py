@@ -283,6 +283,24 @@ def main():
     for n, p in named.items():
         nano[f'gradnorm.{n}'] = np.float32(p.grad.norm().item())
     np.savez_compressed(os.path.join(OUT, 'nano224.npz'), **nano)
+
+    # ------------------------------------------------------------------ nano-224 with the reference's own init
+    # distributions (det_init_ style='reference'): the logit scale the north-star tolerance (1e-2) is stated for
+    wrapper = RefWrapper(to_ref_config(cfg), tok, RefTrainerCfg(), ignore_index=-100)
+    det_init_(wrapper.model, seed=0, style='reference')
+    wrapper.eval()
+    with torch.no_grad():
+        out = wrapper.model(images=images, ids=bos_ids, attn_msk=row_mask)
+        vloss, _ = wrapper.val_step(images, labels)
+    logits = out.logits
+    gids, gm = greedy_with_margins(wrapper.model, images, prompt, 8)
+    print(f'nano224 refinit val_loss {vloss.item():.5f} logits absmax {logits.abs().max().item():.3f} '
+          f'margins min {gm.min():.5f} med {np.median(gm):.5f}')
+    np.savez_compressed(os.path.join(OUT, 'nano224_refinit.npz'),
+                        encoder_output=out.encoder_output.numpy(), logits_head=logits[:, :, :256].numpy().copy(),
+                        logits_tail=logits[:, :, -64:].numpy().copy(), logits_lse=torch.logsumexp(logits, dim=-1).numpy(),
+                        logits_absmax=np.float32(logits.abs().max().item()), hidden_text=out.hidden_state[:, 64:, :].numpy().copy(),
+                        val_loss=np.float32(vloss.item()), greedy_ids=gids.numpy(), greedy_margins=gm)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
 
