@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: nano-224 captioning train step (images/s) + greedy decode (captions/s) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of the hot path on a resident synthetic batch: encoder + decoder forward, fused
+weighted cross-entropy, hand-written backward, (N > 1: RCCL all-reduce of the flat gradient arena), fused AdamW.
+Prints ONE JSON line (rank 0).  ``value`` is whole-job train images/s; the same line carries greedy captions/s, the
+roofline of the dominant kernel (the bf16 MFMA GEMM, timed live with HIP events) and the CPU baseline (the fp32
+oracle port on the host cores, rank 0 at N = 1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic FLOPs of the path ("required-output" variant: the 64 dead prompt rows are not counted):
+# forward 32.6 GFLOP / image, train step 3x.
+FWD_GFLOP_PER_IMAGE = 32.6
+TRAIN_GFLOP_PER_IMAGE = 3 * FWD_GFLOP_PER_IMAGE
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--decode-batch', type=int, default=64, help='captions per GPU per greedy run')
+    ap.add_argument('--decode-reps', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """Wraps ops.gemm with HIP events on the launch stream: per-launch duration and algorithmic FLOPs (2 M N K)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.records = ops, ops.gemm, []
+
+    def __enter__(self):
+        def timed(a, b, out, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = self.orig(a, b, out, M, N, K, **kw)
+            e1.record(torch.cuda.current_stream())
+            self.records.append((e0, e1, 2.0 * M * N * K))
+            return r
+        self.ops.gemm = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), total_ms=ms, avg_us=1e3 * ms / max(1, len(self.records)),
+                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, gflop_per_launch=fl / max(1, len(self.records)) / 1e9)
+
+
+def cpu_baseline(batch=8, steps=2):
+    """The fp32 oracle port (oracle/reference_model.py) timed on the host cores: train step + torch AdamW."""
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch
+    from oracle import reference_model as orc
+    cfg = nano224_config(dropout=0.0)
+    torch.manual_seed(0)
+    model = VisionEncoderDecoder(cfg)                       # parameter container only: supplies reference-style init
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items() if k != 'decoder.lm_head.weight'}
+    sd['decoder.lm_head.weight'] = sd['decoder.transformer.wte.weight']
+    params = [v for k, v in sd.items() if k != 'decoder.lm_head.weight']
+    opt = torch.optim.AdamW(params, lr=6e-4, betas=(0.9, 0.95))
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    images, labels = synthetic_batch(batch, 224, 64, cfg.decoder_config.vocab_size, seed=1)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        loss = orc.lm_step(sd, cfg, images, labels, tok, training=True)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orc.generate_greedy({k: v.detach() for k, v in sd.items()}, cfg, images[:4], torch.full((4, 1), tok.bos_token_id), 8)
+    dec = time.perf_counter() - t0
+    return dict(value=batch / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'oracle fp32 train step (fwd+bwd+AdamW), nano-224, batch {batch}, 1 warm-up + {steps} timed steps',
+                greedy_captions_per_sec_8tok=4 / dec,
+                greedy_sample='4 captions x 8 new tokens, cache-free loop as the reference runs it (cost grows O(t^2))')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    from image2text_amd import ops
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch
+    from image2text_amd.training.dp import DataParallelGrads
+    from image2text_amd.training.optim import FusedAdamW
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+
+    cfg = nano224_config(dropout=0.0)
+    V = cfg.decoder_config.vocab_size
+    torch.manual_seed(0)
+    wrapper = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
+    opt = FusedAdamW(wrapper.model.parameters(), wrapper.model, lr=6e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    dp = DataParallelGrads(wrapper.model) if world > 1 else None
+    images, labels = synthetic_batch(args.batch, 224, 64, V, seed=1 + rank)      # each rank draws its own shard
+    images, labels = images.to(dev), labels.to(dev)
+
+    def step():
+        loss, _ = wrapper.train_step(images, labels)
+        loss.backward()
+        if dp is not None:
+            dp.all_reduce_mean()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if dp is not None:
+        wrapper.train_step(images[:1], labels[:1])[0].backward()     # builds the arena
+        opt.zero_grad()
+        dp.broadcast_parameters()
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    img_s = world * args.batch * args.steps / elapsed
+
+    # ---- per-kernel timing of the dominant kernel (bf16 MFMA GEMM) with HIP events, 2 extra steps
+    gemm = None
+    if not args.no_kernel_timing:
+        with GemmTimer(ops) as gt:
+            for _ in range(2):
+                step()
+        gemm = gt.summary()
+    fence()
+
+    # ---- greedy decode: B captions x 64 new tokens per run (encoder + KV-cache decode under hipGraph replay)
+    cap_s = None
+    if not args.no_decode:
+        wrapper.eval()
+        Bd = args.decode_batch
+        dimg, _ = synthetic_batch(Bd, 224, 64, V, seed=100 + rank)
+        dimg = dimg.to(dev)
+        prompt = torch.full((Bd, 1), V - 1, dtype=torch.long, device=dev)
+        wrapper.model.generate(dimg, prompt, max_new_tokens=64, top_k=1)      # warm-up + graph capture
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.decode_reps):
+            wrapper.model.generate(dimg, prompt, max_new_tokens=64, top_k=1)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        cap_s = world * Bd * args.decode_reps / dt
+        wrapper.train()
+
+    if rank == 0:
+        out = {
+            'metric': 'train images/sec + greedy captions/sec, nano config',
+            'value': round(img_s, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'nano-224 (6x512 ViT encoder + 12x768 nanoGPT decoder, 224x224x3 images, 64-token captions)',
+                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'caption_len': 64,
+                       'parallelism': f'dp{world}', 'dropout': 0.0, 'optimizer': 'AdamW lr 6e-4 betas (0.9,0.95)',
+                       'weights': 'random init (reference distributions)'},
+            'greedy_captions_per_sec': None if cap_s is None else round(cap_s, 2),
+            'greedy_config': {'captions_per_gpu': args.decode_batch, 'new_tokens': 64, 'ngrams': [2, 3, 4, 5]},
+            'final_loss': round(final_loss, 4),
+            'step_tflops': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
+            'step_frac_of_mfma_peak': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
+        }
+        if gemm is not None:
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all layouts)', 'achieved': round(gemm['tflops'], 1),
+                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gemm['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4),
+                               'traffic': None, 'launches_per_step': gemm['launches'] // 2,
+                               'avg_launch_us': round(gemm['avg_us'], 2), 'gflop_per_launch': round(gemm['gflop_per_launch'], 3),
+                               'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -139,6 +139,11 @@ class HotPath:
                           for l in range(dcfg.n_layer)]
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
+        self.grad_ready_hooks = []      # callables(which: 'decoder' | 'encoder'), e.g. the data-parallel exchange
+
+    def notify_grads_ready(self, which: str):
+        for hook in self.grad_ready_hooks:
+            hook(which)
 
     # ------------------------------------------------------------------------------------------------ plumbing
     def prepare(self, training: bool):

@@ -70,6 +70,7 @@ class _HotPathFunction(torch.autograd.Function):
             dl[:, :eng.dec.V] = d_logits.reshape(B * T, -1)
         dh = None if d_hid is None else d_hid.reshape(B * T, -1).to(F32)
         eng.decode_backward(ctx.dctx, dl, dh, dmem)
+        eng.notify_grads_ready('decoder')
         if d_enc is not None:
             dmem += d_enc.reshape(B * ncls, -1)
         d_enc_in = None
@@ -77,6 +78,7 @@ class _HotPathFunction(torch.autograd.Function):
             d_enc_in = dmem.view(B, ncls, -1)
         else:
             eng.encode_backward(ctx.enc_ctx, dmem)
+            eng.notify_grads_ready('encoder')
         a.attach_grads()
         ctx.enc_ctx = ctx.dctx = None
         return None, None, None, None, d_enc_in, None

@@ -1,0 +1,78 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce (mean) of the flat gradient arena.
+
+The reference wraps the trainer in accelerate/DDP (trainer.py:108-114,173-174) but its call pattern bypasses
+``DDP.forward`` so no gradient is ever reduced; this implements the intended semantics:
+every rank runs forward/backward on its own shard (per-replica ``normalize_gradients`` norms, loss divided by the
+local batch), then parameters see the MEAN over ranks of the per-shard gradients.
+
+MI355X mapping: gradients live in ONE contiguous fp32 arena, so the exchange is two large collectives instead of
+DDP's 25 MB buckets: the decoder slice (80 % of the bytes) is reduced on RCCL's stream as soon as the decoder backward
+has finished, overlapped with the whole encoder backward; the encoder slice follows.  xGMI is point-to-point, large
+messages keep every link busy; RCCL picks the rings/trees.  ``torch.distributed`` (backend "nccl" = RCCL) is the
+transport; on CPU the same code runs over gloo (tests).
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallelGrads:
+    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.overlap = overlap
+        self._pending = []
+        self._reduced_upto = None
+        eng = getattr(model, '_engine', None)
+        if eng is not None and overlap:
+            eng.grad_ready_hooks.append(self._on_grads_ready)
+
+    def _arena(self):
+        arena = self.model._engine.arena if hasattr(self.model, '_engine') else self.model.arena
+        if arena is None:
+            raise RuntimeError('no parameter arena yet: run one forward/backward first')
+        return arena
+
+    def _split(self, arena) -> int:
+        """First arena offset that belongs to the decoder (parameters are laid out encoder first)."""
+        for name, (off, _, _) in arena.entries.items():
+            if name.startswith('decoder.'):
+                return off
+        return arena.total
+
+    def _reduce(self, t: torch.Tensor, async_op: bool):
+        backend = dist.get_backend(self.group)
+        if backend == 'nccl':
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
+
+    def _on_grads_ready(self, which: str):
+        """Engine callback: 'decoder' fires before the encoder backward starts."""
+        if which == 'decoder' and self._reduced_upto is None:
+            arena = self._arena()
+            cut = self._split(arena)
+            work, need_div = self._reduce(arena.g32[cut:], async_op=True)
+            self._pending.append((work, arena.g32[cut:], need_div))
+            self._reduced_upto = cut
+
+    def all_reduce_mean(self):
+        """Finish the exchange: after this every rank holds mean-over-ranks gradients in its arena / p.grad."""
+        arena = self._arena()
+        hi = arena.total if self._reduced_upto is None else self._reduced_upto
+        if hi > 0:
+            work, need_div = self._reduce(arena.g32[:hi], async_op=True)
+            self._pending.append((work, arena.g32[:hi], need_div))
+        for work, t, need_div in self._pending:
+            work.wait()
+            if need_div:
+                t.div_(self.world)
+        self._pending.clear()
+        self._reduced_upto = None
+
+    def broadcast_parameters(self, src: int = 0):
+        """Initial parameter sync (what DDP does at wrap time)."""
+        arena = self._arena()
+        dist.broadcast(arena.p32, src=src, group=self.group)
+        arena._versions = None          # force a bf16 shadow refresh on the next forward

@@ -52,7 +52,9 @@ class _LMLossFunction(torch.autograd.Function):
         ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, B * T, eng.dec.V)
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
         eng.decode_backward(dctx, logits, None, dmem)
+        eng.notify_grads_ready('decoder')
         eng.encode_backward(enc_ctx, dmem)
+        eng.notify_grads_ready('encoder')
         a.attach_grads()
         ctx.pack = None
         return None, None, None, None, None, None, None

@@ -1,0 +1,88 @@
+"""Data-parallel exchange on CPU: world_size 2 over gloo.  The oracle for DP is the MEAN over ranks of
+the per-shard gradients, each shard's gradient taken from the CPU oracle on that shard (per-replica gradient
+normaliser, loss divided by the local batch)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from image2text_amd.synth import det_init_, fake_tokenizer, tiny_config
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _shard_grads(cfg, sd0, images, labels):
+    from oracle import reference_model as orc
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items() if k != 'decoder.lm_head.weight'}
+    sd['decoder.lm_head.weight'] = sd['decoder.transformer.wte.weight']
+    loss = orc.lm_step(sd, cfg, images, labels, fake_tokenizer(cfg.decoder_config.vocab_size), training=True)
+    loss.backward()
+    return {k: v.grad for k, v in sd.items() if k != 'decoder.lm_head.weight'}
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from image2text_amd.engine import ParamArena
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.training.dp import DataParallelGrads
+    from conftest import load_golden
+    cfg = tiny_config()
+    model = VisionEncoderDecoder(cfg)
+    det_init_(model, seed=rank)                      # ranks start from DIFFERENT weights: broadcast must fix that
+    arena = ParamArena(model, torch.device('cpu'))
+
+    class Holder:                                    # the exchange only needs `.arena`
+        pass
+    h = Holder()
+    h.arena = arena
+    dp = DataParallelGrads(h, overlap=False)
+    dp.broadcast_parameters(0)
+    g = load_golden('tiny_train_init.npz')
+    images, labels = torch.from_numpy(g['images']), torch.from_numpy(g['labels'])
+    shard = slice(2 * rank, 2 * rank + 2)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    grads = _shard_grads(cfg, sd0, images[shard], labels[shard])
+    for name, gr in grads.items():
+        arena.G(name).copy_(gr)
+    # emulate the engine's early decoder-slice reduction, then finish
+    dp._on_grads_ready('decoder')
+    dp.all_reduce_mean()
+    torch.save({'p': arena.p32.clone(), 'g': arena.g32.clone(), 'entries': arena.entries}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_mean_of_per_shard_gradients(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'r{i}.pt', weights_only=False) for i in range(world)]
+    assert torch.equal(r[0]['p'], r[1]['p']), 'parameters must be identical after broadcast'
+    assert torch.equal(r[0]['g'], r[1]['g']), 'every rank must hold the same reduced gradients'
+    # single-process oracle of the same thing
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from conftest import load_golden
+    cfg = tiny_config()
+    model = det_init_(VisionEncoderDecoder(cfg), seed=0)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = load_golden('tiny_train_init.npz')
+    images, labels = torch.from_numpy(g['images']), torch.from_numpy(g['labels'])
+    per = [_shard_grads(cfg, sd0, images[2 * i:2 * i + 2], labels[2 * i:2 * i + 2]) for i in range(world)]
+    for name, (off, n, shape) in r[0]['entries'].items():
+        want = (per[0][name] + per[1][name]) / 2
+        got = r[0]['g'][off:off + n].view(shape)
+        assert torch.allclose(got, want, rtol=1e-3, atol=1e-6), name
+    # and it is NOT the gradient of the concatenated batch (per-replica normaliser): guards against "one big batch"
+    full = _shard_grads(cfg, sd0, images, labels)
+    name = 'decoder.transformer.h.0.mlp.c_fc.weight'
+    off, n, shape = r[0]['entries'][name]
+    assert not torch.allclose(r[0]['g'][off:off + n].view(shape), full[name], rtol=1e-3, atol=1e-7)
