@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: libi2t_hip.so has to bind to the HIP runtime torch has already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libi2t_hip.so')
 
