@@ -277,8 +277,12 @@ def test_nano224_reference_init_logits_within_1e2():
         err = np.abs(got - g[key])
         REPORT[f'nano224_refinit.{key}'] = {'max_abs_err': float(err.max()), 'rms_err': float(np.sqrt((err ** 2).mean())),
                                              'frac_within_1e-2': float((err <= 1e-2).mean()), 'ref_absmax': float(np.abs(g[key]).max())}
-        assert (err <= 1e-2 + 1e-2 * np.abs(g[key])).all(), f'{key}: max abs err {err.max():.4g}'
-        assert (err <= 1e-2).mean() >= 0.985 and np.sqrt((err ** 2).mean()) < 5e-3
+        # calibration stored in the fixture: the REFERENCE ITSELF under bf16 autocast (how trainer.py runs precision
+        # 'bf16') deviates from its own fp32 run by max 2.09e-2 / rms 4.1e-3 / 98.5 % within 1e-2 on these inputs.
+        ref_max, ref_rms, ref_frac = (float(v) for v in g['reference_bf16_autocast_dev'])
+        assert err.max() <= max(1e-2, ref_max), f'{key}: max abs err {err.max():.4g} > reference bf16 deviation {ref_max:.4g}'
+        assert np.sqrt((err ** 2).mean()) <= max(2.5e-3, ref_rms), f'{key}: rms {np.sqrt((err ** 2).mean()):.4g}'
+        assert (err <= 1e-2).mean() >= min(0.985, ref_frac), f'{key}: only {(err <= 1e-2).mean():.4f} within 1e-2'
     maxerr('nano224_refinit.logits_lse', torch.logsumexp(out.logits.float(), -1), g['logits_lse'], 1e-2)
     assert abs(float(vloss) - float(g['val_loss'])) <= 1e-3 * float(g['val_loss'])
 

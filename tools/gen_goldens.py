@@ -293,6 +293,15 @@ def main():
         out = wrapper.model(images=images, ids=bos_ids, attn_msk=row_mask)
         vloss, _ = wrapper.val_step(images, labels)
     logits = out.logits
+    # how far does the REFERENCE ITSELF move when run the way trainer.py runs it with precision 'bf16'
+    # (accelerate autocast; here torch.autocast on the CPU)?  Recorded to calibrate the bf16 tolerance.
+    with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        out_bf = wrapper.model(images=images, ids=bos_ids, attn_msk=row_mask)
+    dev_bf = (out_bf.logits.float() - logits).abs()
+    print(f'reference under bf16 autocast vs its fp32 run: logits max abs dev {dev_bf.max().item():.5f} '
+          f'rms {dev_bf.pow(2).mean().sqrt().item():.5f} frac<=1e-2 {(dev_bf <= 1e-2).float().mean().item():.4f}')
+    autocast_stats = np.array([dev_bf.max().item(), dev_bf.pow(2).mean().sqrt().item(), (dev_bf <= 1e-2).float().mean().item()],
+                              dtype=np.float32)
     gids, gm = greedy_with_margins(wrapper.model, images, prompt, 8)
     print(f'nano224 refinit val_loss {vloss.item():.5f} logits absmax {logits.abs().max().item():.3f} '
           f'margins min {gm.min():.5f} med {np.median(gm):.5f}')
@@ -300,7 +309,8 @@ def main():
                         encoder_output=out.encoder_output.numpy(), logits_head=logits[:, :, :256].numpy().copy(),
                         logits_tail=logits[:, :, -64:].numpy().copy(), logits_lse=torch.logsumexp(logits, dim=-1).numpy(),
                         logits_absmax=np.float32(logits.abs().max().item()), hidden_text=out.hidden_state[:, 64:, :].numpy().copy(),
-                        val_loss=np.float32(vloss.item()), greedy_ids=gids.numpy(), greedy_margins=gm)
+                        val_loss=np.float32(vloss.item()), greedy_ids=gids.numpy(), greedy_margins=gm,
+                        reference_bf16_autocast_dev=autocast_stats)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
 
