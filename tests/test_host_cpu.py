@@ -1,0 +1,136 @@
+"""Host-side logic that needs no GPU: config schema parses the reference's YAML presets, state-dict keys, factories
+refuse out-of-scope families, the drop-in aliasing, and the product path fails loudly without a GPU."""
+import os
+
+import pytest
+import torch
+import yaml
+
+from image2text_amd.configs.models import PretrainedViTConfig, TransformerDecoderConfig, VisionTransformerEncoderConfig
+from image2text_amd.configs.trainer import TrainerWrapperConfig, TrainingConfig
+from image2text_amd.lib import I2TError
+from image2text_amd.models.decoder import Decoder
+from image2text_amd.models.encoder import Encoder
+from image2text_amd.models.utils import PatternMatcher, mutate_transformer_config
+from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch, tiny_config
+
+NANO_YAML = """
+tokenizer_str: 'gpt2'
+trainer: {}
+optimizers:
+  - lr: 6e-4
+    betas: [0.9, 0.95]
+    target_modules: ['decoder*.transformer.h.*.cross_attn.*', 'decoder*.transformer.h.*.ln_3.*']
+batch_size: 8
+gradient_accumulation_steps: 4
+precision: 'no'
+model:
+  use_cross_attn: True
+  use_soft_prompting: True
+  no_repeat_n_grams: [2, 3, 4, 5]
+  vision_encoder_config:
+    n_embd_out_vit: 768
+    n_cls: 8
+    refine_base_model: False
+    enable_gradient_checkpointing: True
+  decoder_config:
+    pretrained_model: gpt2
+    n_layer: 12
+    block_size: 256
+    vocab_size: 50257
+    transformer_config:
+      is_cross_attn: True
+      is_causal: True
+      attn_config: {attn_dropout: 0.1, bias: True, dropout: 0.1, n_head: 12, n_embd: 768, attn_type: multi_head}
+      rotator_config: {ff_mult: 4}
+"""
+
+
+def test_yaml_schema_parses_like_the_reference():
+    cfg = TrainingConfig.model_validate(yaml.safe_load(NANO_YAML))
+    assert isinstance(cfg.model.vision_encoder_config, PretrainedViTConfig)      # unknown key silently ignored
+    assert isinstance(cfg.model.decoder_config, TransformerDecoderConfig)
+    assert cfg.model.decoder_config.pretrained_model.value == 'gpt2'
+    assert cfg.optimizers[0].betas == (0.9, 0.95) and cfg.trainer == TrainerWrapperConfig()
+    with pytest.raises(NotImplementedError):
+        Encoder.from_config(cfg.model.vision_encoder_config)
+    with pytest.raises(NotImplementedError):
+        Decoder.from_config(cfg.model.decoder_config)
+
+
+def test_nano224_state_dict_layout_and_param_groups():
+    m = VisionEncoderDecoder(nano224_config())
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 161_759_384
+    for k in ('encoder.0.cls_token', 'encoder.0.feature_extractor.model.4.weight', 'encoder.0.ln_input.weight',
+              'encoder.0.transformer.h.5.mlp.c_proj.weight', 'encoder.1.weight', 'decoder.transformer.wte.weight',
+              'decoder.transformer.h.0.cross_attn.in_proj_weight', 'decoder.transformer.h.10.ln_3.bias', 'decoder.lm_head.weight'):
+        assert k in sd, k
+    assert 'decoder.transformer.h.1.cross_attn.in_proj_weight' not in sd          # cross-attention on even depths only
+    assert 'encoder.0.projector.bias' not in sd                                   # bias: False in the encoder
+    assert sd['decoder.lm_head.weight'].data_ptr() == sd['decoder.transformer.wte.weight'].data_ptr()
+    matcher = PatternMatcher(['decoder*.transformer.h.*.cross_attn.*', 'decoder*.transformer.h.*.ln_3.*'])
+    picked = [n for n, _ in m.named_parameters() if matcher.match(n)]
+    assert len(picked) == 6 * 4 + 6 * 2
+    assert m.space_for_prompt == 64 and m.decoder.block_size == 256 and m.decoder.n_embd == 768
+    assert m.encoder[0].num_outputs == 64 and m.encoder[0].output_embed_dim == 512
+
+
+def test_misconfiguration_errors_match_the_reference():
+    with pytest.raises(ValueError):
+        VisionEncoderDecoder(tiny_config(use_cross_attn=False, use_soft_prompting=False))
+    cfg = tiny_config()
+    tc = cfg.decoder_config.transformer_config
+    assert mutate_transformer_config(tc, 1, True).is_cross_attn is False and mutate_transformer_config(tc, 2, True).is_cross_attn is True
+    assert tc.is_cross_attn is True                                               # original left untouched (deepcopy)
+
+
+def test_no_cpu_path_fails_loudly():
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = tiny_config()
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(cfg.decoder_config.vocab_size), TrainerWrapperConfig())
+    images, labels = synthetic_batch(2, 32, 16, cfg.decoder_config.vocab_size)
+    with pytest.raises(I2TError):
+        w.train_step(images, labels)
+    with pytest.raises(I2TError):
+        w.model(images=images, ids=labels.clamp(min=0))
+    with pytest.raises(NotImplementedError):
+        w.model.decoder.transformer.h[0](torch.zeros(1, 4, 128))                  # blocks are parameter containers
+
+
+def test_unsupported_trainer_options_are_refused():
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = tiny_config()
+    for kw in (dict(moco_momentum=0.995, moco_alpha=0.4), dict(mask_fraction=0.15), dict(add_contrastive_loss=True)):
+        with pytest.raises(NotImplementedError):
+            ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(**kw))
+
+
+def test_loss_weights_match_the_oracle():
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    from oracle import reference_model as orc
+    cfg = tiny_config()
+    _, labels = synthetic_batch(5, 32, 16, 384, seed=4)
+    for kw in (dict(), dict(weight_fn='inverse_sqrt_position'), dict(eos_token_weight=3.0)):
+        w = ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(**kw))
+        ref = orc.loss_weights(labels, -100, kw.get('weight_fn', 'constant'), 383, kw.get('eos_token_weight'))
+        assert torch.allclose(w.get_weights(labels), ref)
+
+
+def test_dropin_aliases():
+    import sys
+    import image2text_amd.dropin as dropin
+    saved = {k: sys.modules.get(k) for k in dropin._ALIASES}
+    try:
+        dropin.install()
+        from models.vision_encoder_decoder import VisionEncoderDecoder as V2     # noqa: the reference's import line
+        from training.wrapper import ModelTrainerWrapper as W2                   # noqa
+        from configs.trainer import TrainingConfig as T2                         # noqa
+        assert V2 is VisionEncoderDecoder and T2 is TrainingConfig
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
