@@ -92,7 +92,11 @@ __device__ __forceinline__ void stage_store(const Stage& s, unsigned char* lds, 
 
 // Fragment of 16 rows starting at r0 for k-substep ks (32 wide): lane (g = lane>>4, i = lane&15) gets
 // tile[r0 + i][32 ks + 8 g + 0..7].
-template <bool KMAJOR>
+// PERMUTE_K (both operands k-major): MFMA k-slot (g, j) is mapped to k = 32 ks + 16 (j>>2) + 4 g + (j&3) on BOTH
+// operands (the reduction order is free), so that a half-wave's transposed reads touch 8 CONSECUTIVE k-rows: with the
+// 288-byte row stride (8 banks per row) those are 8 disjoint 8-bank windows = conflict-free; the natural mapping
+// (k = 8 g + j) reads rows {0-3, 8-11} per half-wave, which collide pairwise on this stride.
+template <bool KMAJOR, bool PERMUTE_K = false>
 __device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, int ks, int lane) {
     const int g = lane >> 4, i = lane & 15;
     if (!KMAJOR) {
@@ -102,16 +106,21 @@ __device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, in
         return __builtin_bit_cast(bf16x8, v);
     } else {
         const int q = i >> 2, p = i & 3;
-        const unsigned char* a0 = lds + (ks * 32 + 8 * g + q) * CF_ROW_BYTES + (r0 + 4 * p) * 2;
+        const unsigned char* a0 = lds + (ks * 32 + (PERMUTE_K ? 4 : 8) * g + q) * CF_ROW_BYTES + (r0 + 4 * p) * 2;
         s16x4 lo = lds_read_tr16(a0);
-        s16x4 hi = lds_read_tr16(a0 + 4 * CF_ROW_BYTES);
+        s16x4 hi = lds_read_tr16(a0 + (PERMUTE_K ? 16 : 4) * CF_ROW_BYTES);
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// SPLITK: gridDim.y slices of the reduction; every slice adds its partial tile into the fp32 C with float atomics
+// (C must already hold the value to accumulate onto -- the gradient arena does).  The MFMA is issued un-swapped
+// there so that one atomic wave-instruction covers 4 rows x 64 contiguous bytes instead of 16 rows x 4 scattered
+// dwords (MI355X_MICROARCH.md, global float atomics: access shape).
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    constexpr bool PK = A_KMAJOR && B_KMAJOR;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -134,11 +143,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     // rows of an M/N-contiguous (k-major) operand may be read up to the next multiple of 8 (inside ld)
     const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
     const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
+    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
+    const int nk = min(nk_per, nk_all - kt0);
+    if (nk <= 0) return;                                     // block-uniform
 
     Stage sa, sb;
-    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, 0, p.K, tid);
-    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, 0, p.K, tid);
+    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
+    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
     stage_store<A_KMAJOR>(sa, smem, tid);
     stage_store<B_KMAJOR>(sb, smem + OPERAND_BYTES, tid);
     __syncthreads();
@@ -148,21 +161,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         const unsigned char* lb = la + OPERAND_BYTES;
         const bool more = (t + 1) < nk;
         if (more) {   // issue the next tile's global loads before the MFMA phase (T14)
-            stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, (t + 1) * BK, p.K, tid);
-            stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, (t + 1) * BK, p.K, tid);
+            stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, (kt0 + t + 1) * BK, p.K, tid);
+            stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, (kt0 + t + 1) * BK, p.K, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KMAJOR>(la, wm * 64 + i * 16, ks, lane);
+            for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KMAJOR, PK>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KMAJOR>(lb, wn * 64 + j * 16, ks, lane);
+            for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KMAJOR, PK>(lb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
             unsigned char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
@@ -172,8 +186,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
     const int g = lane >> 4, li = lane & 15;
+    if (SPLITK) {
+        // un-swapped accumulators: lane holds C[m0 + wm*64 + 16 i + 4 g + r][n0 + wn*64 + 16 j + li], r = 0..3
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                    if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                }
+            }
+        return;
+    }
+    // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -265,6 +295,84 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 64: one decode step for up to 64 captions).  Weight-streaming bound: every weight byte is read
+// exactly once, straight from HBM into VGPRs (no LDS round trip -- cdna_hip_programming.md, "GEMV / M <= 16 decode
+// weights" row), 16 weight rows x 64 k per wave-step; the few activation rows are re-read from L1/L2.
+//   grid.x = N / 16 column tiles, the 4 waves of a workgroup interleave over 64-wide K-steps and combine through LDS;
+//   grid.y > 1 (only for the in-place residual form C += x W^T + b with fp32 C): K is also split across workgroups and
+//   the partial tiles are added with float atomics, which lifts the N = 768 projections from 48 to 384 workgroups.
+// MFMA is issued with the weight fragment as the A operand (rows = n), so a lane owns 4 consecutive n of one m.
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int nsteps_all = (p.K + 63) / 64;
+    const int per = (nsteps_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s0 = (int)blockIdx.y * per, s1 = min(nsteps_all, s0 + per);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nrow = n0 + li;
+    const bf16_t* wrow = p.B + (size_t)min(nrow, p.N - 1) * p.ldb;
+    const bool nvalid = nrow < p.N;
+    for (int st = s0 + w; st < s1; st += 4) {
+        const int k0 = st * 64 + 8 * g;
+        u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+        if (nvalid && k0 < p.K) w0 = *reinterpret_cast<const u32x4*>(wrow + k0);
+        if (nvalid && k0 + 32 < p.K) w1 = *reinterpret_cast<const u32x4*>(wrow + k0 + 32);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 16 + li;
+            u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
+            if (m < p.M && k0 < p.K) x0 = *reinterpret_cast<const u32x4*>(p.A + (size_t)m * p.lda + k0);
+            if (m < p.M && k0 + 32 < p.K) x1 = *reinterpret_cast<const u32x4*>(p.A + (size_t)m * p.lda + k0 + 32);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, x0), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, x1), acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(red[w][t][lane]) = acc[t];
+    __syncthreads();
+    // wave w finishes m-subtile w, w+4, ... : lane holds C[m = 16 t + li][n0 + 4 g .. +3]
+    for (int t = w; t < MT; t += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(red[0][t][lane]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(red[ww][t][lane]);
+        const int m = t * 16 + li, n4 = n0 + 4 * g;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n4 + r;
+            if (n >= p.N) continue;
+            float val = v[r] * p.alpha;
+            if (gridDim.y > 1) {            // split-K: C already holds the residual; slice 0 contributes the bias
+                if (p.bias && blockIdx.y == 0) val += p.bias[n];
+                atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, val);
+                continue;
+            }
+            if (p.bias) val += p.bias[n];
+            if (p.act == I2T_ACT_GELU) val = gelu_tanh(val);
+            if (p.residual) val += p.residual[(size_t)m * p.ldr + n];
+            if (p.c_is_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                *c = p.accumulate ? *c + val : val;
+            } else {
+                reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(val);
+            }
+        }
+    }
+}
+
+template <int MT>
+void launch_skinny(hipStream_t s, const GemmParams& p, int ksplit) {
+    dim3 grid((p.N + 15) / 16, ksplit);
+    hipLaunchKernelGGL(gemm_skinny_kernel<MT>, grid, dim3(256), 0, s, p);
+}
+
 }  // namespace
 
 extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor, const void* B, int ldb,
@@ -291,12 +399,43 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU) {
+        // decode-step shape: weight-streaming kernel.  In-place residual form (C is fp32 and IS the residual) may also
+        // split K across workgroups when there are too few column tiles to pull HBM bandwidth from every CU.
+        int ksplit = 1;
+        const int ntiles = (N + 15) / 16;
+        if (c_is_f32 && residual == (const float*)C && ldr == ldc && act == I2T_ACT_NONE && !accumulate)
+            while (ntiles * ksplit < 256 && (K / 64) / (ksplit * 2) >= 2 && ksplit < 16) ksplit *= 2;
+        const int mt = (M + 15) / 16;
+        if (mt == 1) launch_skinny<1>(s, p, ksplit);
+        else if (mt == 2) launch_skinny<2>(s, p, ksplit);
+        else if (mt == 3) launch_skinny<3>(s, p, ksplit);
+        else launch_skinny<4>(s, p, ksplit);
+        I2T_CHECK_LAUNCH("i2t_gemm_bf16(skinny)");
+        return I2T_OK;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    // split-K for accumulate-into-fp32 problems whose tile grid cannot fill the 256 CUs (the dW = dY^T.X GEMMs: small
+    // M x N, very long K): enough slices to reach ~2 workgroups per CU, each slice at least 4 K-steps long
+    int splits = 1;
+    const int plain_epilogue = !bias && act == I2T_ACT_NONE && !aux_out && !residual;
+    if (accumulate && c_is_f32 && plain_epilogue) {
+        const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
+        while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
+    }
+    if (splits > 1) {
+        grid.y = splits;
+        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true>), grid, block, 0, s, p);
+        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, true>), grid, block, 0, s, p);
+        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, true>), grid, block, 0, s, p);
+    } else {
+        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false>), grid, block, 0, s, p);
+        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, false>), grid, block, 0, s, p);
+        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, block, 0, s, p);
+    }
     I2T_CHECK_LAUNCH("i2t_gemm_bf16");
     return I2T_OK;
 }

@@ -422,3 +422,48 @@ def test_decode_attention_and_kv_append(ops):
     ops.decode_attention(qkv, 3 * d, kc, vc, Tmax * d, d, o, d, None, 20, B, H)
     ref, _ = ref_attention(q, kc[:, :20].float().reshape(B, 20, H, 64), vc[:, :20].float().reshape(B, 20, H, 64), False)
     check('decode attention (fixed keys)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
+
+
+# ------------------------------------------------------------------------------------------------------ split-K / skinny paths
+@pytest.mark.parametrize('a_km,b_km', [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_splitk_accumulate(ops, a_km, b_km):
+    """dW-shaped problems (small M x N, long K) take the split-K + float-atomics path: C += op(A).op(B)."""
+    M, N, K = 512, 768, 8192
+    a, b = rnd(M, K, dtype=BF16, seed=90, scale=0.2), rnd(N, K, dtype=BF16, seed=91, scale=0.2)
+    base = rnd(M, N, seed=92)
+    ref = base.double() + a.double() @ b.double().t()
+    a_in = a.t().contiguous() if a_km else a
+    b_in = b.t().contiguous() if b_km else b
+    c = base.clone()
+    ops.gemm(a_in, b_in, c, M, N, K, a_kmajor=a_km, b_kmajor=b_km, accumulate=True)
+    check(f'splitk a_km={a_km} b_km={b_km}', c, ref, 3e-3, 2e-3)
+    # odd sizes + K tail
+    M2, N2, K2 = 200, 136, 4104
+    a2, b2 = rnd(M2, K2, dtype=BF16, seed=93, scale=0.2), rnd(N2, K2, dtype=BF16, seed=94, scale=0.2)
+    c2 = torch.zeros(M2, N2, device=dev())
+    ops.gemm(a2.t().contiguous() if a_km else a2, b2.t().contiguous() if b_km else b2, c2, M2, N2, K2, a_kmajor=a_km,
+             b_kmajor=b_km, accumulate=True)
+    check('splitk odd', c2, a2.double() @ b2.double().t(), 3e-3, 2e-3)
+
+
+@pytest.mark.parametrize('M', [1, 8, 33, 64])
+def test_gemm_skinny_decode_shapes(ops, M):
+    d, ff, V = 768, 3072, 50257
+    x = rnd(M, d, dtype=BF16, seed=95)
+    w1, b1 = rnd(ff, d, dtype=BF16, seed=96, scale=0.05), rnd(ff, seed=97)
+    h = torch.empty(M, ff, dtype=BF16, device=dev())
+    ops.gemm(x, w1, h, M, ff, d, bias=b1, act=1)                                   # c_fc + GELU, bf16 out
+    ref_h = F.gelu(x.float() @ w1.float().t() + b1, approximate='tanh')
+    check('skinny fc+gelu', h, ref_h, 1e-2, 1 / 128)
+    w2, b2 = rnd(d, ff, dtype=BF16, seed=98, scale=0.05), rnd(d, seed=99)
+    res = rnd(M, d, seed=100)
+    want = res.double() + (h.double() @ w2.double().t() + b2.double())
+    ops.gemm(h, w2, res, M, d, ff, bias=b2, residual=res)                          # in-place residual -> split-K atomics
+    check('skinny proj in-place residual', res, want, 5e-3, 2e-3)
+    wte = rnd(V, d, dtype=BF16, seed=101, scale=0.05)
+    logits = torch.empty(M, V, device=dev())
+    ops.gemm(x, wte, logits, M, V, d)                                              # lm_head, fp32 logits, odd N
+    check('skinny lm_head', logits, x.float() @ wte.float().t(), 3e-3, 2e-3)
+    out = torch.empty(M, d, device=dev())
+    ops.gemm(h, w2, out, M, d, ff, bias=b2, residual=rnd(M, d, seed=102))          # out-of-place residual (no split)
+    check('skinny proj residual', out, rnd(M, d, seed=102).double() + h.double() @ w2.double().t() + b2.double(), 5e-3, 2e-3)
