@@ -17,6 +17,7 @@
 // Block -> tile map is XCD-aware (8 XCDs, private L2s): blocks that share an XCD walk consecutive M-tiles of the
 // same N panel, so a weight panel is fetched into one L2 instead of eight.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -405,7 +406,10 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         // split K across workgroups when there are too few column tiles to pull HBM bandwidth from every CU.
         int ksplit = 1;
         const int ntiles = (N + 15) / 16;
-        if (c_is_f32 && residual == (const float*)C && ldr == ldc && act == I2T_ACT_NONE && !accumulate)
+        // NOTE: the cross-workgroup split is OFF by default: float atomics make the sum order, hence the last bits of
+        // the logits, vary from run to run, and greedy decoding must be token-exact reproducible.  The N = 768
+        // projections then run on 48 workgroups; they are launch-latency-sized anyway (1.2 - 4.7 MB of weights).
+        if (getenv("I2T_SKINNY_KSPLIT") && c_is_f32 && residual == (const float*)C && ldr == ldc && act == I2T_ACT_NONE && !accumulate)
             while (ntiles * ksplit < 256 && (K / 64) / (ksplit * 2) >= 2 && ksplit < 16) ksplit *= 2;
         const int mt = (M + 15) / 16;
         if (mt == 1) launch_skinny<1>(s, p, ksplit);

@@ -458,7 +458,7 @@ def test_gemm_skinny_decode_shapes(ops, M):
     w2, b2 = rnd(d, ff, dtype=BF16, seed=98, scale=0.05), rnd(d, seed=99)
     res = rnd(M, d, seed=100)
     want = res.double() + (h.double() @ w2.double().t() + b2.double())
-    ops.gemm(h, w2, res, M, d, ff, bias=b2, residual=res)                          # in-place residual -> split-K atomics
+    ops.gemm(h, w2, res, M, d, ff, bias=b2, residual=res)                          # in-place residual (decode form)
     check('skinny proj in-place residual', res, want, 5e-3, 2e-3)
     wte = rnd(V, d, dtype=BF16, seed=101, scale=0.05)
     logits = torch.empty(M, V, device=dev())
