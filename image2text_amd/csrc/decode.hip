@@ -36,20 +36,39 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 
 // one wave per (b, h): keys strided over lanes for the scores, head dims over lanes for the output
 constexpr int DEC_MAX_KEYS = 1024;
+// append_dm > 0: q points at a packed [q | k | v] row of width 3*append_dm; the new token's k/v (this head's 64
+// columns) are written into the cache at *pos by this workgroup and attended to from LDS (fused kv_append).
 __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __restrict__ q, int q_rs,
-                                                              const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                              bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                               long cache_bs, int cache_rs, bf16_t* __restrict__ o, int o_rs,
-                                                              const int* __restrict__ pos_ptr, int n_keys_fixed) {
-    __shared__ float qs[64];
+                                                              const int* __restrict__ pos_ptr, int n_keys_fixed,
+                                                              int append_dm) {
+    __shared__ float qs[64], kn[64], vn[64];
     __shared__ float ps[DEC_MAX_KEYS];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int n = pos_ptr ? (*pos_ptr + 1) : n_keys_fixed;
-    qs[lane] = bf16_to_f32(q[(size_t)b * q_rs + h * 64 + lane]);
+    const bf16_t* qrow = q + (size_t)b * q_rs + h * 64 + lane;
+    qs[lane] = bf16_to_f32(qrow[0]);
+    bf16_t* kb = kc + (size_t)b * cache_bs + h * 64;
+    bf16_t* vb = vc + (size_t)b * cache_bs + h * 64;
+    const int n_cached = append_dm > 0 ? n - 1 : n;          // keys read back from the cache
+    if (append_dm > 0) {
+        const bf16_t kv = qrow[append_dm], vv = qrow[2 * append_dm];
+        kn[lane] = bf16_to_f32(kv);
+        vn[lane] = bf16_to_f32(vv);
+        kb[(size_t)(n - 1) * cache_rs + lane] = kv;
+        vb[(size_t)(n - 1) * cache_rs + lane] = vv;
+    }
     __syncthreads();
-    const bf16_t* kb = kc + (size_t)b * cache_bs + h * 64;
-    const bf16_t* vb = vc + (size_t)b * cache_bs + h * 64;
     float mx = -INFINITY;
-    for (int key = lane; key < n; key += 64) {
+    if (append_dm > 0 && lane == ((n - 1) & 63)) {
+        float s = 0.f;
+        for (int c = 0; c < 64; ++c) s += kn[c] * qs[c];
+        s *= 0.125f;
+        ps[n - 1] = s;
+        mx = s;
+    }
+    for (int key = lane; key < n_cached; key += 64) {
         const u32x4* kr = reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs);
         float s = 0.f;
 #pragma unroll
@@ -72,7 +91,8 @@ __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __re
     sum = wave_sum(sum);
     __syncthreads();
     float acc = 0.f;
-    for (int key = 0; key < n; ++key) acc += ps[key] * bf16_to_f32(vb[(size_t)key * cache_rs + lane]);
+    for (int key = 0; key < n_cached; ++key) acc += ps[key] * bf16_to_f32(vb[(size_t)key * cache_rs + lane]);
+    if (append_dm > 0) acc += ps[n - 1] * vn[lane];
     o[(size_t)b * o_rs + h * 64 + lane] = f32_to_bf16(acc / sum);
 }
 
@@ -159,7 +179,9 @@ __global__ __launch_bounds__(BAN_THREADS) void ngram_ban_argmax_kernel(const voi
     }
 }
 
-__global__ void advance_kernel(int* counter, int delta) { *counter += delta; }
+__global__ void advance_kernel(int* counters, int n, int delta) {
+    if ((int)threadIdx.x < n) counters[threadIdx.x] += delta;
+}
 
 }  // namespace
 
@@ -183,14 +205,15 @@ extern "C" int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kc
     return I2T_OK;
 }
 
-extern "C" int i2t_decode_attention(void* stream, const void* q, int q_rs, const void* kcache, const void* vcache,
+extern "C" int i2t_decode_attention(void* stream, const void* q, int q_rs, void* kcache, void* vcache,
                                     long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
-                                    int B, int H) {
+                                    int append_dm, int B, int H) {
+    I2T_REQUIRE(append_dm == 0 || (pos_ptr && append_dm == 64 * H), "i2t_decode_attention: append needs pos_ptr and a packed qkv row");
     I2T_REQUIRE(q && kcache && vcache && o && B > 0 && H > 0, "i2t_decode_attention: bad args");
     I2T_REQUIRE(pos_ptr || (n_keys_fixed > 0 && n_keys_fixed <= DEC_MAX_KEYS), "i2t_decode_attention: key count out of range");
     I2T_REQUIRE(cache_rs % 8 == 0 && cache_bs % 8 == 0 && ALIGNED16(kcache) && ALIGNED16(vcache), "i2t_decode_attention: cache misaligned");
     hipLaunchKernelGGL(decode_attention_kernel, dim3(H, B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed);
+                       (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed, append_dm);
     I2T_CHECK_LAUNCH("i2t_decode_attention");
     return I2T_OK;
 }
@@ -208,9 +231,9 @@ extern "C" int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, in
     return I2T_OK;
 }
 
-extern "C" int i2t_advance(void* stream, int* counter, int delta) {
-    I2T_REQUIRE(counter, "i2t_advance: null counter");
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+extern "C" int i2t_advance(void* stream, int* counters, int n, int delta) {
+    I2T_REQUIRE(counters && n > 0 && n <= 64, "i2t_advance: bad args");
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, n, delta);
     I2T_CHECK_LAUNCH("i2t_advance");
     return I2T_OK;
 }

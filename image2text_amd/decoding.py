@@ -76,8 +76,7 @@ class GreedyDecoder:
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
-            ops.kv_append(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, pos_ptr, B, d)
-            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, st.ao, d, pos_ptr, 0, B, H)
+            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, st.ao, d, pos_ptr, 0, B, H, append_dm=d)
             ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
             if l in st.cross_kv:
                 kv, S = st.cross_kv[l]
@@ -94,8 +93,7 @@ class GreedyDecoder:
             ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
             ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
             ops.ngram_ban_argmax(st.logits, dc.V, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
-        ops.advance(pos_ptr, 1)
-        ops.advance(len_ptr, 1)
+        ops.advance(st.counters, 1)                            # pos and len together
 
     def _capture(self, st, with_head: bool):
         side = torch.cuda.Stream(device=st.arena.device)

@@ -191,9 +191,9 @@ def add_(dst, src):
     return dst
 
 
-def decode_attention(q, q_rs, kcache, vcache, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H):
+def decode_attention(q, q_rs, kcache, vcache, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0):
     _l.check(_lib().i2t_decode_attention(_stream(), _p(q), q_rs, _p(kcache), _p(vcache), cache_bs, cache_rs, _p(o), o_rs,
-                                         _p(pos), n_keys_fixed, B, H), 'i2t_decode_attention')
+                                         _p(pos), n_keys_fixed, append_dm, B, H), 'i2t_decode_attention')
 
 
 def kv_append(qkv, qkv_rs, kcache, vcache, cache_bs, cache_rs, pos, B, d):
@@ -211,8 +211,8 @@ def embed_step(ids, ids_ld, len_ptr, wte, wpe, x, B, d, pos_offset, vocab):
              'i2t_embed_step')
 
 
-def advance(counter, delta=1):
-    _l.check(_lib().i2t_advance(_stream(), _p(counter), delta), 'i2t_advance')
+def advance(counters, delta=1):
+    _l.check(_lib().i2t_advance(_stream(), _p(counters), counters.numel(), delta), 'i2t_advance')
 
 
 class Graph:

@@ -174,20 +174,22 @@ int i2t_add_f32(void* stream, float* dst, const float* src, long n);
  * Greedy decode step pieces (vision_encoder_decoder.py:136-182 with top_k=1, temperature=1):
  *   decode_attention: one new query token per caption against the self K/V cache (keys 0..*pos) -- cache layout
  *     [B][Tmax][d] bf16 for K and for V; also used for cross-attention with fixed n_keys (pos_ptr NULL);
+ *     append_dm = d (0 = off): q is a packed [q|k|v] row and the new k/v are written to the cache at *pos by the same
+ *     launch (fused kv_append);
  *   ngram_ban_argmax: HF NoRepeatNGramLogitsProcessor for every size in ngram_sizes (prompt included), then argmax
  *     (first index on ties); appends the token at ids[b][*len] and (block 0) bumps *len / *pos after the grid.
  *   Positions live in device memory so that a captured hipGraph replays the same launch for every step.
  * --------------------------------------------------------------------------------------------------------- */
-int i2t_decode_attention(void* stream, const void* q, int q_rs, const void* kcache, const void* vcache,
+int i2t_decode_attention(void* stream, const void* q, int q_rs, void* kcache, void* vcache,
                          long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
-                         int B, int H);
+                         int append_dm, int B, int H);
 int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kcache, void* vcache, long cache_bs,
                   int cache_rs, const int* pos_ptr, int B, int d);
 int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, int logits_is_f32, int64_t* ids, int ids_ld,
                          int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V, float* margin_out);
 int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
                    const float* wpe, float* x, int B, int d, int pos_offset, int vocab);
-int i2t_advance(void* stream, int* counter, int delta);
+int i2t_advance(void* stream, int* counters, int n, int delta);   /* counters[0..n) += delta */
 
 /* hipGraph capture around any sequence of the calls above (replaces the Python loop of
  * vision_encoder_decoder.py:143-180 with one replayed launch per token) */

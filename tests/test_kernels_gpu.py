@@ -422,6 +422,14 @@ def test_decode_attention_and_kv_append(ops):
     ops.decode_attention(qkv, 3 * d, kc, vc, Tmax * d, d, o, d, None, 20, B, H)
     ref, _ = ref_attention(q, kc[:, :20].float().reshape(B, 20, H, 64), vc[:, :20].float().reshape(B, 20, H, 64), False)
     check('decode attention (fixed keys)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
+    # fused append: position 10 is written by the attention launch itself and attended to
+    pos.fill_(10)
+    qkv2 = rnd(B, 3 * d, dtype=BF16, seed=83)
+    ops.decode_attention(qkv2, 3 * d, kc, vc, Tmax * d, d, o, d, pos, 0, B, H, append_dm=d)
+    assert torch.equal(kc[:, 10], qkv2[:, d:2 * d]) and torch.equal(vc[:, 10], qkv2[:, 2 * d:])
+    q2 = qkv2[:, :d].float().reshape(B, 1, H, 64)
+    ref, _ = ref_attention(q2, kc[:, :11].float().reshape(B, 11, H, 64), vc[:, :11].float().reshape(B, 11, H, 64), False)
+    check('decode attention (fused append)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
 
 
 # ------------------------------------------------------------------------------------------------------ split-K / skinny paths
