@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// Skinny GEMM (M <= 256: one decode step for up to 256 captions).  Weight-streaming bound: every weight byte is read
+// Skinny GEMM (M <= 64: one decode step for up to 64 captions).  Weight-streaming bound: every weight byte is read
 // exactly once, straight from HBM into VGPRs (no LDS round trip -- cdna_hip_programming.md, "GEMV / M <= 16 decode
 // weights" row), 16 weight rows x 64 k per wave-step; the few activation rows are re-read from L1/L2.
 //   grid.x = N / 16 column tiles, the 4 waves of a workgroup interleave over 64-wide K-steps and combine through LDS;
@@ -320,32 +320,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
     const int nrow = n0 + li;
     const bf16_t* wrow = p.B + (size_t)min(nrow, p.N - 1) * p.ldb;
     const bool nvalid = nrow < p.N;
-    // two of this wave's K-steps per iteration: all weight loads are issued before the first MFMA
-    for (int st = s0 + w; st < s1; st += 8) {
-        const int ka = st * 64 + 8 * g, kb = (st + 4) * 64 + 8 * g;
-        const bool second = (st + 4) < s1;
-        u32x4 wv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = u32x4{0u, 0u, 0u, 0u};
-        if (nvalid && ka < p.K) wv[0] = *reinterpret_cast<const u32x4*>(wrow + ka);
-        if (nvalid && ka + 32 < p.K) wv[1] = *reinterpret_cast<const u32x4*>(wrow + ka + 32);
-        if (second && nvalid && kb < p.K) wv[2] = *reinterpret_cast<const u32x4*>(wrow + kb);
-        if (second && nvalid && kb + 32 < p.K) wv[3] = *reinterpret_cast<const u32x4*>(wrow + kb + 32);
+    for (int st = s0 + w; st < s1; st += 4) {
+        const int k0 = st * 64 + 8 * g;
+        u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+        if (nvalid && k0 < p.K) w0 = *reinterpret_cast<const u32x4*>(wrow + k0);
+        if (nvalid && k0 + 32 < p.K) w1 = *reinterpret_cast<const u32x4*>(wrow + k0 + 32);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int m = t * 16 + li;
-            const bf16_t* xr = p.A + (size_t)min(m, p.M - 1) * p.lda;
-            const bool mv = m < p.M;
-            u32x4 xv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xv[u] = u32x4{0u, 0u, 0u, 0u};
-            if (mv && ka < p.K) xv[0] = *reinterpret_cast<const u32x4*>(xr + ka);
-            if (mv && ka + 32 < p.K) xv[1] = *reinterpret_cast<const u32x4*>(xr + ka + 32);
-            if (second && mv && kb < p.K) xv[2] = *reinterpret_cast<const u32x4*>(xr + kb);
-            if (second && mv && kb + 32 < p.K) xv[3] = *reinterpret_cast<const u32x4*>(xr + kb + 32);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[u]), __builtin_bit_cast(bf16x8, xv[u]), acc[t], 0, 0, 0);
+            u32x4 x0 = {0u, 0u, 0u, 0u}, x1 = {0u, 0u, 0u, 0u};
+            if (m < p.M && k0 < p.K) x0 = *reinterpret_cast<const u32x4*>(p.A + (size_t)m * p.lda + k0);
+            if (m < p.M && k0 + 32 < p.K) x1 = *reinterpret_cast<const u32x4*>(p.A + (size_t)m * p.lda + k0 + 32);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, x0), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, x1), acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -414,7 +401,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 256 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU && !accumulate) {
+    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU && !accumulate) {
         // decode-step shape: weight-streaming kernel.  In-place residual form (C is fp32 and IS the residual) may also
         // split K across workgroups when there are too few column tiles to pull HBM bandwidth from every CU.
         int ksplit = 1;
@@ -427,10 +414,8 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         const int mt = (M + 15) / 16;
         if (mt == 1) launch_skinny<1>(s, p, ksplit);
         else if (mt == 2) launch_skinny<2>(s, p, ksplit);
-        else if (mt <= 4) launch_skinny<4>(s, p, ksplit);
-        else if (mt <= 8) launch_skinny<8>(s, p, ksplit);
-        else if (mt <= 12) launch_skinny<12>(s, p, ksplit);
-        else launch_skinny<16>(s, p, ksplit);
+        else if (mt == 3) launch_skinny<3>(s, p, ksplit);
+        else launch_skinny<4>(s, p, ksplit);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(skinny)");
         return I2T_OK;
     }

@@ -41,6 +41,7 @@ class GreedyDecoder:
         e = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=dev)
         st.ids = torch.zeros(B, ids_ld, dtype=torch.long, device=dev)
         st.counters = torch.zeros(2, dtype=torch.int32, device=dev)        # [pos, len]
+        st.counters_init = torch.tensor([0, 1], dtype=torch.int32, device=dev)
         st.x = e(B, d, dtype=F32)
         st.ln = e(B, d)
         st.qkv = e(B, 3 * d)
@@ -131,7 +132,7 @@ class GreedyDecoder:
                          bias=a.P(f'{p}.in_proj_bias')[dc.d:])
         st.ids.zero_()
         st.ids[:, :P] = prompt_ids
-        st.counters.copy_(torch.tensor([0, 1], dtype=torch.int32))
+        st.counters.copy_(st.counters_init)                     # device-to-device: no host sync in the loop
         margins = torch.zeros(max_new_tokens, B, dtype=F32, device=a.device) if return_margins else None
         if use_graph and st.graph_full is None:
             # warm up eagerly once (code objects must be loaded before capture), then capture both step kinds
@@ -141,7 +142,7 @@ class GreedyDecoder:
             st.graph_prefill = self._capture(st, False)
             st.ids.zero_()
             st.ids[:, :P] = prompt_ids
-            st.counters.copy_(torch.tensor([0, 1], dtype=torch.int32))
+            st.counters.copy_(st.counters_init)
         for _ in range(P - 1):                                  # prompt tokens before the last: fill the cache only
             st.graph_prefill.launch() if use_graph else self._step(st, False)
         for i in range(max_new_tokens):
@@ -150,3 +151,28 @@ class GreedyDecoder:
                 margins[i].copy_(st.margin)
         out = st.ids[:, :total].clone()
         return (out, margins.t().contiguous()) if return_margins else out
+
+
+class ConcurrentGreedyDecoder:
+    """Several independent caption batches decoded at the same time, one HIP stream + one captured graph each.
+
+    A single decode stream is latency-bound (one token per caption per step: ~120 short dependent kernels, most of
+    them on far fewer than 256 workgroups), so the chip is mostly idle; batches are independent (decode shards
+    trivially), so their graphs are replayed on separate streams and overlap on the GPU."""
+
+    def __init__(self, model, n_streams: int):
+        self.model = model
+        self.lanes = [(GreedyDecoder(model), torch.cuda.Stream()) for _ in range(n_streams)]
+
+    @torch.no_grad()
+    def generate(self, image_batches, prompt_batches, max_new_tokens: int):
+        assert len(image_batches) == len(prompt_batches) <= len(self.lanes)
+        cur = torch.cuda.current_stream()
+        outs = []
+        for (dec, stream), images, prompt in zip(self.lanes, image_batches, prompt_batches):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                outs.append(dec.generate(images, prompt, max_new_tokens))
+        for _, stream in self.lanes:
+            cur.wait_stream(stream)
+        return outs
