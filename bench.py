@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--decode-batch', type=int, default=64, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
-    ap.add_argument('--decode-streams', type=int, default=4, help='independent caption batches decoded concurrently')
+    ap.add_argument('--decode-streams', type=int, default=8, help='independent caption batches decoded concurrently')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
