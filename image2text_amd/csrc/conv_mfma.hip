@@ -1,0 +1,397 @@
+// 6x6 'same' convolutions of the ConvMLP feature extractor as implicit GEMMs on the MFMA units (gfx950).
+//
+// Why a new layout: the MFMA A/B fragments want 8 consecutive reduction indices per lane as ONE aligned 16-byte LDS
+// read.  With channels-last (NHWC) activations the 8 consecutive indices are 8 input channels of one tap at one
+// pixel -- always 16-byte aligned -- whereas with NCHW they would be 8 consecutive x positions at an arbitrary
+// (2-byte aligned) offset.  So the intermediate pre-activations live in HBM as NHWC bf16; the first layer converts
+// the fp32 NCHW image while staging, and the last layer writes NCHW (its output IS the flat-patch operand of the
+// projector GEMM, reference encoder.py:166).
+//
+//   forward / backward-data (one kernel, weights flipped + roles swapped for backward-data):
+//       D[co][pixel] = sum_{tap, ci} W[co][tap][ci] * patch[pixel + tap][ci]
+//       workgroup = 16 x 16 output pixels; wave w owns 4 pixel rows; MFMA 16x16x32 with A = weights (rows = co),
+//       B = patch (cols = 16 consecutive x); k-step = 4 (tap, 8-channel chunk) groups; weights (<= 36 KiB) and the
+//       21 x 21 halo patch sit in LDS; GELU is applied while staging, bias / GELU' in the epilogue.
+//   backward-weight:  dW[co][tap][ci] = sum_pixels dY[pixel][co] * act[pixel + tap][ci]
+//       reduction over pixels = the ROW index of both LDS tiles -> both fragments come from transposed LDS reads
+//       (ds_read_b64_tr_b16, any 4-row set); a workgroup sweeps a row of 14 tiles keeping dW in registers, then adds
+//       its partial with contiguous float atomics into a [co][tap][ci] scratch that a tiny kernel folds into dW.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;            // output tile edge
+constexpr int KS = 6;             // kernel size
+constexpr int PW = TS + KS - 1;   // 21: patch edge
+constexpr int NTAP = KS * KS;
+
+enum { SRC_NCHW_F32 = 0, SRC_NCHW_BF16 = 1, SRC_NHWC_BF16 = 2 };
+
+// wr[co][tap][ci_p] (bf16, zero padded) from w[Cout][Cin][6][6] (f32).
+//   flip = 0: forward            co = output channel of w, ci = input channel of w
+//   flip = 1: backward-data      roles swapped: rows = Cin of w, reduction = Cout of w, taps mirrored
+__global__ void conv_repack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wr, int Cout, int Cin, int rows_p,
+                                   int red_p, int flip) {
+    const int n = rows_p * NTAP * red_p;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int c = i % red_p, tap = (i / red_p) % NTAP, r = i / (red_p * NTAP);
+        const int ky = tap / KS, kx = tap % KS;
+        float v = 0.f;
+        if (!flip) {
+            if (r < Cout && c < Cin) v = w[((r * Cin + c) * KS + ky) * KS + kx];
+        } else {
+            if (r < Cin && c < Cout) v = w[((c * Cin + r) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)];
+        }
+        wr[i] = f32_to_bf16(v);
+    }
+}
+
+// stage the (PW x PW) halo patch around tile (y0, x0) into LDS as [py][px][CP] bf16 (zero outside the image / pads)
+template <int CP, int SRC, bool IN_GELU>
+__device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void* __restrict__ src, int b, int C, int H, int W,
+                                            int y0, int x0, int pad_before, int tid) {
+    if (SRC == SRC_NHWC_BF16) {
+        constexpr int CH = CP / 8;                                   // 16-byte chunks per pixel
+        const bf16_t* s = reinterpret_cast<const bf16_t*>(src) + (size_t)b * H * W * CP;
+        for (int i = tid; i < PW * PW * CH; i += 256) {
+            const int ch = i % CH, px = (i / CH) % PW, py = i / (CH * PW);
+            const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = *reinterpret_cast<const u32x4*>(s + ((size_t)gy * W + gx) * CP + ch * 8);
+                if (IN_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(gelu_tanh(bf16lo(v[e])), gelu_tanh(bf16hi(v[e])));
+                }
+            }
+            *reinterpret_cast<u32x4*>(pl + (py * PW + px) * CP + ch * 8) = v;
+        }
+    } else {
+        const size_t plane = (size_t)H * W;
+        for (int i = tid; i < CP * PW * PW; i += 256) {
+            const int px = i % PW, py = (i / PW) % PW, c = i / (PW * PW);
+            const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
+            float v = 0.f;
+            if (c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t off = ((size_t)b * C + c) * plane + (size_t)gy * W + gx;
+                v = (SRC == SRC_NCHW_F32) ? reinterpret_cast<const float*>(src)[off]
+                                          : bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[off]);
+                if (IN_GELU) v = gelu_tanh(v);
+            }
+            pl[(py * PW + px) * CP + c] = f32_to_bf16(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fwd / bwd-data
+template <int CP, int NT, int SRC, bool IN_GELU, bool DGELU, bool DST_NCHW>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__ src, const bf16_t* __restrict__ wr,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ dst,
+                                                        const bf16_t* __restrict__ pre, int Cin, int Cout, int H, int W,
+                                                        int pad_before, int tiles_x) {
+    constexpr int WROW = NTAP * CP + 8;                       // +16 B pad: conflict-free 16-lane weight reads
+    constexpr int COP = NT * 16;                              // padded output channels
+    __shared__ __attribute__((aligned(16))) bf16_t wl[COP * WROW];
+    __shared__ __attribute__((aligned(16))) bf16_t pl[PW * PW * CP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.y;
+    const int y0 = (blockIdx.x / tiles_x) * TS, x0 = (blockIdx.x % tiles_x) * TS;
+    for (int i = tid; i < COP * NTAP * CP / 8; i += 256) {    // weights: contiguous [co][tap][ci] -> padded rows
+        const int co = i / (NTAP * CP / 8), rest = i % (NTAP * CP / 8);
+        *reinterpret_cast<u32x4*>(wl + co * WROW + rest * 8) = *reinterpret_cast<const u32x4*>(wr + (size_t)i * 8);
+    }
+    stage_patch<CP, SRC, IN_GELU>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
+    __syncthreads();
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = CP / 8;
+    constexpr int NSTEP = NTAP * CH / 4;                      // k-steps of 4 (tap, chunk) groups
+#pragma unroll 2
+    for (int s = 0; s < NSTEP; ++s) {
+        const int kg = 4 * s + g;
+        const int tap = kg / CH, ch = kg % CH;
+        const int ky = tap / KS, kx = tap % KS;
+        bf16x8 fw[NT], fp[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (16 * t + li) * WROW + kg * 8));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            fp[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((4 * w + r + ky) * PW + li + kx) * CP + ch * 8));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], fp[r], acc[r][t], 0, 0, 0);
+    }
+    // D[co = 16 t + 4 g + e][pixel = li] of output row y0 + 4 w + r
+    const int ox = x0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = y0 + 4 * w + r;
+        if (oy >= H || ox >= W) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c0 = 16 * t + 4 * g;
+            if (c0 >= Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[r][t][e] + ((bias && c0 + e < Cout) ? bias[c0 + e] : 0.f);
+            if (DGELU) {       // pre-activation of the layer below, NHWC with Cout channels
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(pre + (((size_t)b * H + oy) * W + ox) * Cout + c0);
+                v[0] *= gelu_tanh_grad(bf16lo(pk[0]));
+                v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
+                v[2] *= gelu_tanh_grad(bf16lo(pk[1]));
+                v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
+            }
+            if (DST_NCHW) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < Cout) dst[(((size_t)b * Cout + c0 + e) * H + oy) * W + ox] = f32_to_bf16(v[e]);
+            } else {
+                const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(dst + (((size_t)b * H + oy) * W + ox) * Cout + c0) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bwd-weight
+// scratch layout: [COP][NTAP][CP] f32 (this launch's partial dW), db scratch [COP]
+template <int CP, int COP, int DY_SRC, int ACT_SRC, bool ACT_GELU>
+__global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* __restrict__ dy, const void* __restrict__ act,
+                                                                   float* __restrict__ scratch, float* __restrict__ db,
+                                                                   int Cin, int Cout, int H, int W, int pad_before,
+                                                                   int tiles_x) {
+    constexpr int NT = COP / 16;                              // co tiles
+    constexpr int NN = (CP == 16) ? NTAP : NTAP / 2;           // n-tiles of 16 (tap x ci) columns
+    constexpr int NPW = (NN + 3) / 4;                          // n-tiles per wave
+    __shared__ __attribute__((aligned(16))) bf16_t dl[TS * TS * COP];     // dY tile  [pixel][co]
+    __shared__ __attribute__((aligned(16))) bf16_t pl[PW * PW * CP];      // act patch [py][px][ci]
+    __shared__ float dbs[COP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int q = li >> 2, p = li & 3;
+    const int b = blockIdx.y, ty = blockIdx.x;               // one workgroup sweeps the tile row ty of image b
+    const int y0 = ty * TS;
+    f32x4 acc[NPW][NT];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < COP) dbs[tid] = 0.f;
+
+    for (int tx = 0; tx < tiles_x; ++tx) {
+        const int x0 = tx * TS;
+        __syncthreads();
+        // dY tile as [pixel][COP] (pads zero); pad_before = 0: no halo
+        if (DY_SRC == SRC_NHWC_BF16) {
+            constexpr int CH = COP / 8;
+            const bf16_t* s = reinterpret_cast<const bf16_t*>(dy) + (size_t)b * H * W * Cout;
+            for (int i = tid; i < TS * TS * CH; i += 256) {
+                const int ch = i % CH, px = (i / CH) % TS, py = i / (CH * TS);
+                const int gy = y0 + py, gx = x0 + px;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (gy < H && gx < W && ch * 8 < Cout) v = *reinterpret_cast<const u32x4*>(s + ((size_t)gy * W + gx) * Cout + ch * 8);
+                *reinterpret_cast<u32x4*>(dl + (py * TS + px) * COP + ch * 8) = v;
+            }
+        } else {
+            const size_t plane = (size_t)H * W;
+            for (int i = tid; i < COP * TS * TS; i += 256) {
+                const int px = i % TS, py = (i / TS) % TS, c = i / (TS * TS);
+                const int gy = y0 + py, gx = x0 + px;
+                bf16_t v = 0;
+                if (c < Cout && gy < H && gx < W) v = reinterpret_cast<const bf16_t*>(dy)[((size_t)b * Cout + c) * plane + (size_t)gy * W + gx];
+                dl[(py * TS + px) * COP + c] = v;
+            }
+        }
+        stage_patch<CP, ACT_SRC, ACT_GELU>(pl, act, b, Cin, H, W, y0, x0, pad_before, tid);
+        __syncthreads();
+        if (db && tid < COP) {
+            float s = 0.f;
+            for (int px = 0; px < TS * TS; ++px) s += bf16_to_f32(dl[px * COP + tid]);
+            dbs[tid] += s;
+        }
+        // 8 k-steps of 32 pixels = 2 tile rows x 16 x; k-slot (g, j) <-> pixel (row 2 s + (j >> 2), x = 4 g + (j & 3))
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {
+            bf16x8 fa[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16_t* a0 = dl + ((2 * s) * TS + 4 * g + q) * COP + 16 * t + 4 * p;
+                s16x4 lo = lds_read_tr16(a0);
+                s16x4 hi = lds_read_tr16(a0 + TS * COP);
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fa[t] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+                const int nt = min(w * NPW + n, NN - 1);     // clamped: out-of-range slots recompute the last tile (discarded)
+                int ky, kx, coff;
+                if (CP == 16) {
+                    ky = nt / KS; kx = nt % KS; coff = 4 * p;
+                } else {                                     // CP == 8: 16 columns = taps (kx, kx+1) x 8 channels
+                    ky = nt / (KS / 2); kx = 2 * (nt % (KS / 2)) + (p >> 1); coff = 4 * (p & 1);
+                }
+                const bf16_t* b0 = pl + ((2 * s + ky) * PW + 4 * g + q + kx) * CP + coff;
+                s16x4 lo = lds_read_tr16(b0);
+                s16x4 hi = lds_read_tr16(b0 + PW * CP);
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t], fb, acc[n][t], 0, 0, 0);
+            }
+        }
+    }
+    // D[co = 16 t + 4 g + e][column li of n-tile]: add into scratch[co][tap][ci]
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int nt = w * NPW + n;
+        if (nt >= NN) continue;
+        int tap, ci;
+        if (CP == 16) { tap = nt; ci = li; }
+        else { tap = (nt / (KS / 2)) * KS + 2 * (nt % (KS / 2)) + (li >> 3); ci = li & 7; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = 16 * t + 4 * g + e;
+                atomicAdd(scratch + ((size_t)co * NTAP + tap) * CP + ci, acc[n][t][e]);
+            }
+    }
+    __syncthreads();
+    if (db && tid < Cout) atomicAdd(db + tid, dbs[tid]);
+}
+
+// dw[co][ci][ky][kx] += scratch[co][tap][ci]
+__global__ void conv_fold_dw_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int Cout, int Cin, int CP) {
+    const int n = Cout * Cin * NTAP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int tap = i % NTAP, ci = (i / NTAP) % Cin, co = i / (NTAP * Cin);
+        dw[i] += scratch[((size_t)co * NTAP + tap) * CP + ci];
+    }
+}
+
+int pad8(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : 32); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+#define LAUNCH_CONV(CP_, NT_, SRC_, G_, D_, N_)                                                                        \
+    hipLaunchKernelGGL((conv_mfma_kernel<CP_, NT_, SRC_, G_, D_, N_>), grid, dim3(256), 0, s, src, (const bf16_t*)wr,  \
+                       bias, (bf16_t*)dst, (const bf16_t*)pre, Cin, Cout, H, W, pad_before, tiles_x)
+
+static int conv_mfma_dispatch(hipStream_t s, const void* src, int src_layout, int in_gelu, const void* wr, const float* bias,
+                              void* dst, int dst_nchw, const void* pre, int B, int Cin, int Cout, int H, int W,
+                              int pad_before) {
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+    dim3 grid(tiles_x * tiles_y, B);
+    const int cp = pad8(Cin), nt = Cout <= 16 ? 1 : 2;
+    const bool dg = pre != nullptr;
+    // the combinations the feature extractor uses (forward: f32 NCHW image | NHWC+GELU; backward-data: NCHW | NHWC dY)
+    if (src_layout == SRC_NCHW_F32 && cp == 8 && !in_gelu && !dg && !dst_nchw) { if (nt == 1) LAUNCH_CONV(8, 1, SRC_NCHW_F32, false, false, false); else LAUNCH_CONV(8, 2, SRC_NCHW_F32, false, false, false); }
+    else if (src_layout == SRC_NCHW_F32 && cp == 8 && !in_gelu && !dg && dst_nchw) { if (nt == 1) LAUNCH_CONV(8, 1, SRC_NCHW_F32, false, false, true); else LAUNCH_CONV(8, 2, SRC_NCHW_F32, false, false, true); }
+    else if (src_layout == SRC_NHWC_BF16 && in_gelu && !dg && !dst_nchw) {
+        if (cp == 8 && nt == 1) LAUNCH_CONV(8, 1, SRC_NHWC_BF16, true, false, false);
+        else if (cp == 8) LAUNCH_CONV(8, 2, SRC_NHWC_BF16, true, false, false);
+        else if (cp == 16 && nt == 1) LAUNCH_CONV(16, 1, SRC_NHWC_BF16, true, false, false);
+        else if (cp == 16) LAUNCH_CONV(16, 2, SRC_NHWC_BF16, true, false, false);
+        else if (nt == 1) LAUNCH_CONV(32, 1, SRC_NHWC_BF16, true, false, false);
+        else LAUNCH_CONV(32, 2, SRC_NHWC_BF16, true, false, false);
+    } else if (src_layout == SRC_NHWC_BF16 && in_gelu && !dg && dst_nchw) {
+        if (cp == 8 && nt == 1) LAUNCH_CONV(8, 1, SRC_NHWC_BF16, true, false, true);
+        else if (cp == 8) LAUNCH_CONV(8, 2, SRC_NHWC_BF16, true, false, true);
+        else if (cp == 16 && nt == 1) LAUNCH_CONV(16, 1, SRC_NHWC_BF16, true, false, true);
+        else if (cp == 16) LAUNCH_CONV(16, 2, SRC_NHWC_BF16, true, false, true);
+        else if (nt == 1) LAUNCH_CONV(32, 1, SRC_NHWC_BF16, true, false, true);
+        else LAUNCH_CONV(32, 2, SRC_NHWC_BF16, true, false, true);
+    } else if (dg && !in_gelu && !dst_nchw && (src_layout == SRC_NCHW_BF16 || src_layout == SRC_NHWC_BF16)) {
+        if (src_layout == SRC_NCHW_BF16) {
+            if (cp == 8) LAUNCH_CONV(8, 1, SRC_NCHW_BF16, false, true, false);
+            else if (cp == 16) LAUNCH_CONV(16, 1, SRC_NCHW_BF16, false, true, false);
+            else LAUNCH_CONV(32, 1, SRC_NCHW_BF16, false, true, false);
+        } else {
+            if (cp == 8) LAUNCH_CONV(8, 1, SRC_NHWC_BF16, false, true, false);
+            else if (cp == 16) LAUNCH_CONV(16, 1, SRC_NHWC_BF16, false, true, false);
+            else LAUNCH_CONV(32, 1, SRC_NHWC_BF16, false, true, false);
+        }
+        if (nt != 1) { i2t_set_error("conv6 bwd-data: Cin=%d > 16 unsupported", Cout); return I2T_EINVAL; }
+    } else {
+        i2t_set_error("conv6 mfma: unsupported layout combination (src=%d gelu=%d dgelu=%d nchw_out=%d)", src_layout, in_gelu, (int)dg, dst_nchw);
+        return I2T_EINVAL;
+    }
+    return I2T_OK;
+}
+
+extern "C" int i2t_conv6_fwd(void* stream, const void* x, int x_layout, int in_gelu, const float* w, const float* bias,
+                             void* y, int y_nchw, void* w_ws, int B, int Cin, int Cout, int H, int W) {
+    I2T_REQUIRE(x && w && y && w_ws && B > 0 && Cin > 0 && Cout > 0 && Cin <= 32 && Cout <= 32, "i2t_conv6_fwd: bad args");
+    I2T_REQUIRE(x_layout != SRC_NHWC_BF16 || Cin == pad8(Cin), "i2t_conv6_fwd: NHWC input needs 8/16/32 channels");
+    I2T_REQUIRE(y_nchw || Cout % 8 == 0, "i2t_conv6_fwd: NHWC output needs Cout %% 8 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = pad8(Cin), cop = Cout <= 16 ? 16 : 32;
+    hipLaunchKernelGGL(conv_repack_kernel, dim3(64), dim3(256), 0, s, w, (bf16_t*)w_ws, Cout, Cin, cop, cp, 0);
+    int rc = conv_mfma_dispatch(s, x, x_layout, in_gelu, w_ws, bias, y, y_nchw, nullptr, B, Cin, Cout, H, W, (KS - 1) / 2);
+    if (rc != I2T_OK) return rc;
+    I2T_CHECK_LAUNCH("i2t_conv6_fwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_conv6_bwd_data(void* stream, const void* dy, int dy_layout, const float* w, const void* x_pre, void* dx,
+                                  void* w_ws, int B, int Cin, int Cout, int H, int W) {
+    I2T_REQUIRE(dy && w && x_pre && dx && w_ws && B > 0 && Cin % 8 == 0 && Cin <= 16 && Cout <= 32, "i2t_conv6_bwd_data: bad args");
+    I2T_REQUIRE(dy_layout == SRC_NCHW_BF16 || (dy_layout == SRC_NHWC_BF16 && Cout == pad8(Cout)), "i2t_conv6_bwd_data: dy layout");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = pad8(Cout);                 // reduction channels = Cout of the forward conv
+    hipLaunchKernelGGL(conv_repack_kernel, dim3(64), dim3(256), 0, s, w, (bf16_t*)w_ws, Cout, Cin, 16, cp, 1);
+    // roles swapped: "Cin" of the kernel = Cout, "Cout" of the kernel = Cin; mirrored padding (3 before)
+    int rc = conv_mfma_dispatch(s, dy, dy_layout, 0, w_ws, nullptr, dx, 0, x_pre, B, Cout, Cin, H, W, KS - 1 - (KS - 1) / 2);
+    if (rc != I2T_OK) return rc;
+    I2T_CHECK_LAUNCH("i2t_conv6_bwd_data");
+    return I2T_OK;
+}
+
+#define LAUNCH_BW(CP_, COP_, DS_, AS_, G_)                                                                              \
+    hipLaunchKernelGGL((conv_mfma_bwd_weight_kernel<CP_, COP_, DS_, AS_, G_>), grid, dim3(256), 0, s, dy, x, scratch, db, \
+                       Cin, Cout, H, W, (KS - 1) / 2, tiles_x)
+
+extern "C" int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout, const void* x, int x_layout, int in_gelu,
+                                    float* dw, float* db, float* scratch, int B, int Cin, int Cout, int H, int W) {
+    I2T_REQUIRE(dy && x && dw && scratch && B > 0 && Cin <= 16 && Cout <= 32, "i2t_conv6_bwd_weight: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = pad8(Cin), cop = Cout <= 16 ? 16 : 32;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)cop * NTAP * cp, s);
+    if (e != hipSuccess) { i2t_set_error("i2t_conv6_bwd_weight: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+    dim3 grid(tiles_y, B);
+    bool ok = true;
+    if (x_layout == SRC_NCHW_F32 && !in_gelu && cp == 8) {
+        if (dy_layout == SRC_NHWC_BF16 && cop == 16) LAUNCH_BW(8, 16, SRC_NHWC_BF16, SRC_NCHW_F32, false);
+        else if (dy_layout == SRC_NHWC_BF16) LAUNCH_BW(8, 32, SRC_NHWC_BF16, SRC_NCHW_F32, false);
+        else if (cop == 16) LAUNCH_BW(8, 16, SRC_NCHW_BF16, SRC_NCHW_F32, false);
+        else LAUNCH_BW(8, 32, SRC_NCHW_BF16, SRC_NCHW_F32, false);
+    } else if (x_layout == SRC_NHWC_BF16 && in_gelu && Cin == cp) {
+        if (cp == 8) {
+            if (dy_layout == SRC_NHWC_BF16 && cop == 16) LAUNCH_BW(8, 16, SRC_NHWC_BF16, SRC_NHWC_BF16, true);
+            else if (dy_layout == SRC_NHWC_BF16) LAUNCH_BW(8, 32, SRC_NHWC_BF16, SRC_NHWC_BF16, true);
+            else if (cop == 16) LAUNCH_BW(8, 16, SRC_NCHW_BF16, SRC_NHWC_BF16, true);
+            else LAUNCH_BW(8, 32, SRC_NCHW_BF16, SRC_NHWC_BF16, true);
+        } else {
+            if (dy_layout == SRC_NHWC_BF16 && cop == 16) LAUNCH_BW(16, 16, SRC_NHWC_BF16, SRC_NHWC_BF16, true);
+            else if (dy_layout == SRC_NHWC_BF16) LAUNCH_BW(16, 32, SRC_NHWC_BF16, SRC_NHWC_BF16, true);
+            else if (cop == 16) LAUNCH_BW(16, 16, SRC_NCHW_BF16, SRC_NHWC_BF16, true);
+            else LAUNCH_BW(16, 32, SRC_NCHW_BF16, SRC_NHWC_BF16, true);
+        }
+    } else {
+        ok = false;
+    }
+    I2T_REQUIRE(ok, "i2t_conv6_bwd_weight: unsupported layout combination (x_layout=%d gelu=%d Cin=%d)", x_layout, in_gelu, Cin);
+    I2T_REQUIRE(dy_layout != SRC_NHWC_BF16 || Cout % 8 == 0, "i2t_conv6_bwd_weight: NHWC dy needs Cout %% 8 == 0");
+    hipLaunchKernelGGL(conv_fold_dw_kernel, dim3(32), dim3(256), 0, s, scratch, dw, Cout, Cin, cp);
+    I2T_CHECK_LAUNCH("i2t_conv6_bwd_weight");
+    return I2T_OK;
+}

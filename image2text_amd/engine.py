@@ -133,6 +133,9 @@ class HotPath:
         gates = list(ecfg.feature_extractor_gate_sizes or [])
         chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
         self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]
+        # MFMA (channels-last) convolutions when the kernel is 6x6 and every intermediate width is 8/16/32 channels
+        self.conv_mfma = (ecfg.feature_extractor_kernel_size[0] == 6 and all(c in (8, 16, 32) for c in chans[1:-1])
+                          and chans[0] <= 8 and chans[-1] <= 32 and all(c <= 16 for c in chans[:-1]))
         self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
         self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
         self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
@@ -153,7 +156,9 @@ class HotPath:
         if self.arena is None or self.arena.device != dev or not self.arena.valid():
             self.arena = ParamArena(self.model, dev)
             self._ws = torch.zeros(4, dtype=F32, device=dev)
-            self._conv_ws = torch.empty(max(self.arena.entries[f'{n}.weight'][1] for n, _, _ in self.conv), dtype=F32, device=dev)
+            self._conv_ws = torch.empty(max(32 * 36 * 32, max(self.arena.entries[f'{n}.weight'][1] for n, _, _ in self.conv)),
+                                        dtype=F32, device=dev)
+            self._conv_scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev)
             self._logits_cache.clear()
         self.arena.refresh_shadow()
         if training and (self.enc.dropout > 0 or self.dec.dropout > 0 or self.enc.attn_dropout > 0 or self.dec.attn_dropout > 0):
@@ -275,8 +280,14 @@ class HotPath:
         B, C, Hh, Ww = images.shape
         acts, cur = [], images
         for i, (nm, cin, cout) in enumerate(self.conv):
-            y = self._empty(B, cout, Hh, Ww, dtype=BF16)
-            ops.conv_fwd(cur, i > 0, a.P(f'{nm}.weight'), a.P(f'{nm}.bias'), y, self._conv_ws, B, cin, cout, Hh, Ww, e.k)
+            last = i == len(self.conv) - 1
+            if self.conv_mfma:      # intermediates channels-last (NHWC); the last layer writes NCHW = the flat patches
+                y = self._empty(*((B, cout, Hh, Ww) if last else (B, Hh, Ww, cout)), dtype=BF16)
+                ops.conv6_fwd(cur, ops.LAYOUT_NCHW_F32 if i == 0 else ops.LAYOUT_NHWC_BF16, i > 0, a.P(f'{nm}.weight'),
+                              a.P(f'{nm}.bias'), y, last, self._conv_ws, B, cin, cout, Hh, Ww)
+            else:
+                y = self._empty(B, cout, Hh, Ww, dtype=BF16)
+                ops.conv_fwd(cur, i > 0, a.P(f'{nm}.weight'), a.P(f'{nm}.bias'), y, self._conv_ws, B, cin, cout, Hh, Ww, e.k)
             acts.append(y)
             cur = y
         M0, d, T = B * e.P2, e.d, e.ncls + e.P2
@@ -347,9 +358,19 @@ class HotPath:
         self._linear_bwd(dpb, M0, d, self.input_d, ctx.flat, f'{self.ep}projector.weight',
                          f'{self.ep}projector.bias' if a.G(f'{self.ep}projector.bias') is not None else None, dx_out=dflat)
         dy = dflat.view(B, self.conv[-1][2], ctx.Hh, ctx.Ww)
+        dy_layout = ops.LAYOUT_NCHW_BF16
         for i in reversed(range(len(self.conv))):
             nm, cin, cout = self.conv[i]
             xin = ctx.images if i == 0 else ctx.acts[i - 1]
+            if self.conv_mfma:
+                ops.conv6_bwd_weight(dy, dy_layout, xin, ops.LAYOUT_NCHW_F32 if i == 0 else ops.LAYOUT_NHWC_BF16, i > 0,
+                                     a.G(f'{nm}.weight'), a.G(f'{nm}.bias'), self._conv_scratch, B, cin, cout, ctx.Hh, ctx.Ww)
+                if i > 0:
+                    dxi = self._empty(B, ctx.Hh, ctx.Ww, cin, dtype=BF16)
+                    ops.conv6_bwd_data(dy, dy_layout, a.P(f'{nm}.weight'), ctx.acts[i - 1], dxi, self._conv_ws, B, cin, cout,
+                                       ctx.Hh, ctx.Ww)
+                    dy, dy_layout = dxi, ops.LAYOUT_NHWC_BF16
+                continue
             ops.conv_bwd_weight(dy, xin, i > 0, a.G(f'{nm}.weight'), a.G(f'{nm}.bias'), B, cin, cout, ctx.Hh, ctx.Ww, e.k)
             if i > 0:
                 dxi = self._empty(B, cin, ctx.Hh, ctx.Ww, dtype=BF16)

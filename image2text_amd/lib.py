@@ -29,6 +29,9 @@ SIGNATURES = {
     'i2t_conv_fwd': [P, P, I, I, P, P, P, P, I, I, I, I, I, I],
     'i2t_conv_bwd_data': [P, P, P, P, I, P, P, I, I, I, I, I, I],
     'i2t_conv_bwd_weight': [P, P, P, I, I, P, P, I, I, I, I, I, I],
+    'i2t_conv6_fwd': [P, P, I, I, P, P, P, I, P, I, I, I, I, I],
+    'i2t_conv6_bwd_data': [P, P, I, P, P, P, P, I, I, I, I, I],
+    'i2t_conv6_bwd_weight': [P, P, I, P, I, I, P, P, P, I, I, I, I, I],
     'i2t_cast_f32_bf16': [P, P, P, L],
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_bcast_rows': [P, P, P, L, I, I, I],

@@ -160,6 +160,29 @@ def conv_bwd_weight(dy, x, in_gelu, dw, db, B, Cin, Cout, H, W, k):
                                         Cout, H, W, k), 'i2t_conv_bwd_weight')
 
 
+LAYOUT_NCHW_F32, LAYOUT_NCHW_BF16, LAYOUT_NHWC_BF16 = 0, 1, 2
+
+
+def conv6_fwd(x, x_layout, in_gelu, w, bias, y, y_nchw, w_ws, B, Cin, Cout, H, W):
+    _need_cuda(x, w, y, w_ws)
+    _l.check(_lib().i2t_conv6_fwd(_stream(), _p(x), x_layout, int(in_gelu), _p(w), _p(bias), _p(y), int(y_nchw), _p(w_ws), B, Cin,
+                                  Cout, H, W), 'i2t_conv6_fwd')
+    return y
+
+
+def conv6_bwd_data(dy, dy_layout, w, x_pre, dx, w_ws, B, Cin, Cout, H, W):
+    _need_cuda(dy, w, x_pre, dx, w_ws)
+    _l.check(_lib().i2t_conv6_bwd_data(_stream(), _p(dy), dy_layout, _p(w), _p(x_pre), _p(dx), _p(w_ws), B, Cin, Cout, H, W),
+             'i2t_conv6_bwd_data')
+    return dx
+
+
+def conv6_bwd_weight(dy, dy_layout, x, x_layout, in_gelu, dw, db, scratch, B, Cin, Cout, H, W):
+    _need_cuda(dy, x, dw, scratch)
+    _l.check(_lib().i2t_conv6_bwd_weight(_stream(), _p(dy), dy_layout, _p(x), x_layout, int(in_gelu), _p(dw), _p(db), _p(scratch),
+                                         B, Cin, Cout, H, W), 'i2t_conv6_bwd_weight')
+
+
 def cast_f32_bf16(src, dst, n=None):
     _need_cuda(src, dst)
     _l.check(_lib().i2t_cast_f32_bf16(_stream(), _p(src), _p(dst), src.numel() if n is None else n), 'i2t_cast_f32_bf16')

@@ -148,6 +148,20 @@ int i2t_conv_bwd_data(void* stream, const void* dy, const float* w, const void* 
 int i2t_conv_bwd_weight(void* stream, const void* dy, const void* x, int in_is_f32, int in_gelu,
                         float* dw, float* db, int B, int Cin, int Cout, int H, int W, int k);
 
+/* MFMA implicit-GEMM form of the same 6x6 convolutions (the path the engine uses when every intermediate channel
+ * count is 8, 16 or 32).  Layout codes: 0 = NCHW f32 (the image), 1 = NCHW bf16, 2 = NHWC bf16.  Intermediate
+ * pre-activations are NHWC bf16; the last layer writes NCHW bf16 (y_nchw) because its output is the flat-patch operand
+ * of the projector GEMM (encoder.py:166), whose gradient therefore arrives NCHW (dy_layout 1).
+ *   w_ws:    >= 32*36*32 bf16 scratch (weights repacked [co][tap][ci], flipped + transposed for bwd_data)
+ *   scratch: >= 32*36*16 f32 (partial dW in [co][tap][ci] order, folded into dw[Cout][Cin][6][6] by the call)
+ *   bwd_data: dx (NHWC bf16, Cin channels) = convT(dy) * gelu'(x_pre);  bwd_weight: dw, db accumulated. */
+int i2t_conv6_fwd(void* stream, const void* x, int x_layout, int in_gelu, const float* w, const float* bias,
+                  void* y, int y_nchw, void* w_ws, int B, int Cin, int Cout, int H, int W);
+int i2t_conv6_bwd_data(void* stream, const void* dy, int dy_layout, const float* w, const void* x_pre, void* dx,
+                       void* w_ws, int B, int Cin, int Cout, int H, int W);
+int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout, const void* x, int x_layout, int in_gelu,
+                         float* dw, float* db, float* scratch, int B, int Cin, int Cout, int H, int W);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Elementwise / arena utilities
  *   cast:  dst bf16[n] = src f32[n]                     (bf16 weight shadows after an optimizer step)

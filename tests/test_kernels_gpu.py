@@ -475,3 +475,48 @@ def test_gemm_skinny_decode_shapes(ops, M):
     out = torch.empty(M, d, device=dev())
     ops.gemm(h, w2, out, M, d, ff, bias=b2, residual=rnd(M, d, seed=102))          # out-of-place residual (no split)
     check('skinny proj residual', out, rnd(M, d, seed=102).double() + h.double() @ w2.double().t() + b2.double(), 5e-3, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------ MFMA convolutions
+@pytest.mark.parametrize('B,H,W,chans', [(2, 32, 48, (3, 8, 16, 32)), (1, 40, 24, (3, 8, 8)), (2, 224, 224, (3, 8, 16, 32))])
+def test_conv6_mfma_stack(ops, B, H, W, chans):
+    """Channels-last implicit-GEMM convolutions: forward chain, then backward-data / backward-weight layer by layer against
+    autograd on the same bf16-rounded operands (weights are bf16-rounded inside the kernels: tolerance 2^-7)."""
+    k, L = 6, len(chans) - 1
+    x0 = rnd(B, chans[0], H, W, seed=130)
+    ws = [rnd(chans[i + 1], chans[i], k, k, seed=131 + i) / math.sqrt(chans[i] * k * k) for i in range(L)]
+    bs = [0.1 * rnd(chans[i + 1], seed=141 + i) for i in range(L)]
+    w_ws = torch.empty(32 * 36 * 32, dtype=BF16, device=dev())
+    scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev())
+    pad = lambda t: F.pad(t, (2, 3, 2, 3))
+    ys, cur, refs = [], x0, []
+    for i in range(L):
+        last = i == L - 1
+        y = torch.empty((B, chans[i + 1], H, W) if last else (B, H, W, chans[i + 1]), dtype=BF16, device=dev())
+        ops.conv6_fwd(cur, 0 if i == 0 else 2, i > 0, ws[i], bs[i], y, last, w_ws, B, chans[i], chans[i + 1], H, W)
+        a = x0 if i == 0 else F.gelu(ys[i - 1].float().permute(0, 3, 1, 2), approximate='tanh')      # kernel's own stored input
+        ref = F.conv2d(pad(a), ws[i].to(BF16).float(), bs[i])
+        check(f'conv6 fwd layer {i}', y.float() if last else y.float().permute(0, 3, 1, 2), ref, 2e-2, 1 / 64)
+        ys.append(y)
+        refs.append(a)
+        cur = y
+    dy = rnd(B, chans[-1], H, W, dtype=BF16, seed=150)           # NCHW, as the projector's dX GEMM produces it
+    dy_layout = 1
+    for i in reversed(range(L)):
+        a = refs[i].detach().requires_grad_(True)
+        wi, bi = ws[i].clone().requires_grad_(True), bs[i].clone().requires_grad_(True)
+        dyn = dy.float() if dy_layout == 1 else dy.float().permute(0, 3, 1, 2)
+        F.conv2d(pad(a), wi, bi).backward(dyn)
+        dw, db = torch.ones_like(ws[i]), torch.ones_like(bs[i])
+        ops.conv6_bwd_weight(dy, dy_layout, x0 if i == 0 else ys[i - 1], 0 if i == 0 else 2, i > 0, dw, db, scratch, B, chans[i],
+                             chans[i + 1], H, W)
+        check(f'conv6 dW layer {i}', dw, wi.grad + 1, 1e-2 * float(wi.grad.abs().max()), 1 / 64)
+        check(f'conv6 db layer {i}', db, bi.grad + 1, 1e-2 * float(bi.grad.abs().max()), 1 / 64)
+        if i > 0:
+            dx = torch.empty(B, H, W, chans[i], dtype=BF16, device=dev())
+            ops.conv6_bwd_data(dy, dy_layout, ws[i], ys[i - 1], dx, w_ws, B, chans[i], chans[i + 1], H, W)
+            a2 = refs[i].detach().requires_grad_(True)
+            F.conv2d(pad(a2), ws[i].to(BF16).float(), None).backward(dyn)
+            ref_dx = a2.grad * gelu_grad(ys[i - 1].float().permute(0, 3, 1, 2))
+            check(f'conv6 dX layer {i}', dx.float().permute(0, 3, 1, 2), ref_dx, 2e-2 * float(ref_dx.abs().max()), 1 / 32)
+            dy, dy_layout = dx, 2
