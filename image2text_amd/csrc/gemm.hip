@@ -115,78 +115,10 @@ __device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, in
     }
 }
 
-// SPLITK: gridDim.y slices of the reduction; every slice adds its partial tile into the fp32 C with float atomics
-// (C must already hold the value to accumulate onto -- the gradient arena does).  The MFMA is issued un-swapped
-// there so that one atomic wave-instruction covers 4 rows x 64 contiguous bytes instead of 16 rows x 4 scattered
-// dwords (MI355X_MICROARCH.md, global float atomics: access shape).
-template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-    constexpr bool PK = A_KMAJOR && B_KMAJOR;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware, bijective remap of the 1-D grid (cdna_hip_programming.md 5, "XCD swizzle must be bijective")
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // rows of an M/N-contiguous (k-major) operand may be read up to the next multiple of 8 (inside ld)
-    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
-    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
-    const int nk_all = (p.K + BK - 1) / BK;
-    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
-    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
-    const int nk = min(nk_per, nk_all - kt0);
-    if (nk <= 0) return;                                     // block-uniform
-
-    Stage sa, sb;
-    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
-    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
-    stage_store<A_KMAJOR>(sa, smem, tid);
-    stage_store<B_KMAJOR>(sb, smem + OPERAND_BYTES, tid);
-    __syncthreads();
-
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* la = smem + (t & 1) * STAGE_BYTES;
-        const unsigned char* lb = la + OPERAND_BYTES;
-        const bool more = (t + 1) < nk;
-        if (more) {   // issue the next tile's global loads before the MFMA phase (T14)
-            stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, (kt0 + t + 1) * BK, p.K, tid);
-            stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, (kt0 + t + 1) * BK, p.K, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KMAJOR, PK>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KMAJOR, PK>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            unsigned char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
-            stage_store<A_KMAJOR>(sa, na, tid);
-            stage_store<B_KMAJOR>(sb, na + OPERAND_BYTES, tid);
-        }
-        __syncthreads();
-    }
-
+// Epilogue shared by the GEMM kernels.  SPLITK: un-swapped accumulators, float atomics; else fused bias / GELU /
+// GELU' / residual / accumulate with 8-/16-byte vector stores.
+template <bool SPLITK>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
     const int g = lane >> 4, li = lane & 15;
     if (SPLITK) {
         // un-swapped accumulators: lane holds C[m0 + wm*64 + 16 i + 4 g + r][n0 + wn*64 + 16 j + li], r = 0..3
@@ -274,6 +206,198 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             }
         }
     }
+}
+
+// SPLITK: gridDim.y slices of the reduction; every slice adds its partial tile into the fp32 C with float atomics
+// (C must already hold the value to accumulate onto -- the gradient arena does).  The MFMA is issued un-swapped
+// there so that one atomic wave-instruction covers 4 rows x 64 contiguous bytes instead of 16 rows x 4 scattered
+// dwords (MI355X_MICROARCH.md, global float atomics: access shape).
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    constexpr bool PK = A_KMAJOR && B_KMAJOR;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware, bijective remap of the 1-D grid (cdna_hip_programming.md 5, "XCD swizzle must be bijective")
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // rows of an M/N-contiguous (k-major) operand may be read up to the next multiple of 8 (inside ld)
+    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
+    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
+    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
+    const int nk = min(nk_per, nk_all - kt0);
+    if (nk <= 0) return;                                     // block-uniform
+
+    Stage sa, sb;
+    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
+    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
+    stage_store<A_KMAJOR>(sa, smem, tid);
+    stage_store<B_KMAJOR>(sb, smem + OPERAND_BYTES, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* la = smem + (t & 1) * STAGE_BYTES;
+        const unsigned char* lb = la + OPERAND_BYTES;
+        const bool more = (t + 1) < nk;
+        if (more) {   // issue the next tile's global loads before the MFMA phase (T14)
+            stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, (kt0 + t + 1) * BK, p.K, tid);
+            stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, (kt0 + t + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KMAJOR, PK>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KMAJOR, PK>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            unsigned char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
+            stage_store<A_KMAJOR>(sa, na, tid);
+            stage_store<B_KMAJOR>(sb, na + OPERAND_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
+// DMA-staged variant: operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
+// staging and no ds_write pass -- the v1 kernel spent more LDS cycles on ds_write_b128 than on fragment reads).
+// A DMA writes LDS linearly (wave-uniform base + lane * 16 B), so the conflict-avoiding permutation moves to the
+// per-lane SOURCE address and the fragment reads apply the same involution (cdna_hip_programming.md rule 21):
+//   R  image: [row][8 chunks of 16 B], chunk ^= row & 7                      (ds_read_b128, as before)
+//   Cf image: [k-row][16 chunks] with NO padding; the 32-byte window a transposed read touches is XOR-moved by the
+//             k-row: chunk ^= swz(k) << 1 with swz = k & 7 when both operands are k-major (a half-wave reads 8
+//             consecutive k-rows) and swz = (k & 3) | ((k >> 3) & 1) << 2 for the natural k order (rows {0-3, 8-11}):
+//             8 rows -> 8 disjoint 32-byte windows = all 64 banks.
+// Out-of-range chunks (M/N/K tails) are sourced from a 16-byte zero block instead of being predicated off.
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+constexpr int DMA_OPERAND_BYTES = 128 * 128;            // 16 KiB per operand tile
+constexpr int DMA_STAGE_BYTES = 2 * DMA_OPERAND_BYTES;
+constexpr int DMA_SMEM_BYTES = 2 * DMA_STAGE_BYTES;     // 64 KiB, double buffered
+
+template <bool PK>
+__device__ __forceinline__ int cf_swz(int kr) { return PK ? (kr & 7) : ((kr & 3) | (((kr >> 3) & 1) << 2)); }
+
+template <bool KMAJOR, bool PK>
+__device__ __forceinline__ void dma_stage(unsigned char* lds_op, const bf16_t* __restrict__ base, int ld, int row0, int rows,
+                                          int k0, int K, int tid, int wave) {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = u * 256 + tid;
+        const bf16_t* src;
+        if (!KMAJOR) {
+            const int r = c >> 3, kc = (c & 7) ^ (r & 7);
+            const int gr = row0 + r, gk = k0 + kc * 8;
+            src = (gr < rows && gk < K) ? base + (size_t)gr * ld + gk : zero;
+        } else {
+            const int kr = c >> 4, rc = (c & 15) ^ (cf_swz<PK>(kr) << 1);
+            const int gk = k0 + kr, gr = row0 + rc * 8;
+            src = (gk < K && gr < rows) ? base + (size_t)gk * ld + gr : zero;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_op + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+}
+
+template <bool KMAJOR, bool PK>
+__device__ __forceinline__ bf16x8 dma_frag_read(const unsigned char* lds, int r0, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!KMAJOR) {
+        const int r = r0 + i, kc = ks * 4 + g;
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * 128 + ((kc ^ (r & 7)) << 4));
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        const int q = i >> 2, p = i & 3;
+        const int kr0 = ks * 32 + (PK ? 4 : 8) * g + q, kr1 = kr0 + (PK ? 16 : 4);
+        const int ch = (r0 >> 3) + (p >> 1), half = (p & 1) * 8;
+        s16x4 lo = lds_read_tr16(lds + kr0 * 256 + ((ch ^ (cf_swz<PK>(kr0) << 1)) << 4) + half);
+        s16x4 hi = lds_read_tr16(lds + kr1 * 256 + ((ch ^ (cf_swz<PK>(kr1) << 1)) << 4) + half);
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
+    constexpr bool PK = A_KMAJOR && B_KMAJOR;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DMA_SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
+    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
+    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
+    const int nk = min(nk_per, nk_all - kt0);
+    if (nk <= 0) return;
+
+    dma_stage<A_KMAJOR, PK>(smem, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid, wave);
+    dma_stage<B_KMAJOR, PK>(smem + DMA_OPERAND_BYTES, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid, wave);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* la = smem + (t & 1) * DMA_STAGE_BYTES;
+        const unsigned char* lb = la + DMA_OPERAND_BYTES;
+        if (t + 1 < nk) {
+            unsigned char* na = smem + ((t + 1) & 1) * DMA_STAGE_BYTES;
+            dma_stage<A_KMAJOR, PK>(na, p.A, p.lda, m0, a_rows, (kt0 + t + 1) * BK, p.K, tid, wave);
+            dma_stage<B_KMAJOR, PK>(na + DMA_OPERAND_BYTES, p.B, p.ldb, n0, b_rows, (kt0 + t + 1) * BK, p.K, tid, wave);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = dma_frag_read<A_KMAJOR, PK>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = dma_frag_read<B_KMAJOR, PK>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();      // drains this wave's DMA (vmcnt(0)) and fences the buffer swap
+    }
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // out[n] (+)= sum_m X[m][n]; one block per 64 columns, 4 waves stride the rows, lanes own columns
@@ -427,6 +551,23 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     if (accumulate && c_is_f32 && plain_epilogue) {
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
+    }
+    static const bool use_v1 = getenv("I2T_GEMM_V1") != nullptr;
+    if (!use_v1) {
+        if (splits > 1) {
+            grid.y = splits;
+            if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, false, true>), grid, block, 0, s, p);
+            else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, true, true>), grid, block, 0, s, p);
+            else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<true, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_dma_kernel<true, false, true>), grid, block, 0, s, p);
+        } else {
+            if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, false, false>), grid, block, 0, s, p);
+            else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, true, false>), grid, block, 0, s, p);
+            else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<true, true, false>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_dma_kernel<true, false, false>), grid, block, 0, s, p);
+        }
+        I2T_CHECK_LAUNCH("i2t_gemm_bf16(dma)");
+        return I2T_OK;
     }
     if (splits > 1) {
         grid.y = splits;
