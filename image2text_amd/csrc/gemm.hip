@@ -18,6 +18,7 @@
 // same N panel, so a weight panel is fetched into one L2 instead of eight.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -400,6 +401,142 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
     gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Multi-stage DMA pipeline (the production kernel).  In the training step the operands are COLD (just written by the
+// previous kernel, far beyond L2), so a one-tile-ahead prefetch leaves every K-step waiting a full HBM round trip:
+// the [8192 x 768 x 768] projections ran at 4 us per K-step (200 TFLOP/s) with ~0.25 us of MFMA work in it.  Here
+// NS - 1 tiles of global_load_lds are kept in flight across K-steps: counted `s_waitcnt vmcnt(N)` (never 0 in the
+// steady state) + a raw s_barrier, so the DMA of tiles t+1 .. t+NS-2 stays outstanding while tile t is computed
+// (cdna_hip_programming.md 5, "Pipelining across barriers").  All LDS lives in one __shared__ array.
+//   BKT = 64: 8-chunk rows, swizzle chunk ^= row & 7;   BKT = 32: 4-chunk rows, chunk ^= (-(row >> 2)) & 3
+//   (both conflict-free for the ds_read_b128 lane groups);  Cf images as in the 2-stage kernel.
+template <int BKT>
+__device__ __forceinline__ int r_swz(int r) { return BKT == 64 ? (r & 7) : ((-(r >> 2)) & 3); }
+
+template <bool KMAJOR, bool PK, int BKT>
+__device__ __forceinline__ void pipe_stage(unsigned char* lds_op, const bf16_t* __restrict__ base, int ld, int row0, int rows,
+                                           int k0, int K, int tid, int wave) {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+    constexpr int CPT = BKT / 16;                 // 16-byte chunks per thread per operand tile
+    constexpr int CPR = BKT / 8;                  // chunks per row of the R image
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = u * 256 + tid;
+        const bf16_t* src;
+        if (!KMAJOR) {
+            const int r = c / CPR, kc = (c % CPR) ^ r_swz<BKT>(r);
+            const int gr = row0 + r, gk = k0 + kc * 8;
+            src = (gr < rows && gk < K) ? base + (size_t)gr * ld + gk : zero;
+        } else {
+            const int kr = c >> 4, rc = (c & 15) ^ (cf_swz<PK>(kr) << 1);
+            const int gk = k0 + kr, gr = row0 + rc * 8;
+            src = (gk < K && gr < rows) ? base + (size_t)gk * ld + gr : zero;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_op + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+}
+
+template <bool KMAJOR, bool PK, int BKT>
+__device__ __forceinline__ bf16x8 pipe_frag_read(const unsigned char* lds, int r0, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!KMAJOR) {
+        const int r = r0 + i, kc = ks * 4 + g;
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * (BKT * 2) + ((kc ^ r_swz<BKT>(r)) << 4));
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        return dma_frag_read<true, PK>(lds, r0, ks, lane);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK, int BKT, int NS>
+__global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmParams p) {
+    constexpr bool PK = A_KMAJOR && B_KMAJOR;
+    constexpr int OPB = 128 * BKT * 2;            // bytes per operand tile
+    constexpr int STG = 2 * OPB;
+    constexpr int PER_TILE = 2 * (BKT / 16);      // DMA instructions per thread per K-tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STG];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
+    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
+    const int nk_all = (p.K + BKT - 1) / BKT;
+    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
+    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
+    const int nk = min(nk_per, nk_all - kt0);
+    if (nk <= 0) return;
+
+    // prologue: tiles 0 .. NS-2 in flight (tiles past the end are issued as zero tiles so that the counted waits stay exact)
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        unsigned char* st = smem + t * STG;
+        const int kk = (t < nk) ? (kt0 + t) * BKT : p.K;      // k >= K -> every chunk comes from the zero block
+        pipe_stage<A_KMAJOR, PK, BKT>(st, p.A, p.lda, m0, a_rows, kk, p.K, tid, wave);
+        pipe_stage<B_KMAJOR, PK, BKT>(st + OPB, p.B, p.ldb, n0, b_rows, kk, p.K, tid, wave);
+    }
+    for (int t = 0; t < nk; ++t) {
+        wait_vmcnt<PER_TILE * (NS - 2)>();        // tile t has landed (this wave's share); younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();             // everyone's share landed; everyone is done with stage (t-1) % NS
+        {
+            const int tn = t + NS - 1;
+            unsigned char* st = smem + (tn % NS) * STG;
+            const int kk = (tn < nk) ? (kt0 + tn) * BKT : p.K;
+            pipe_stage<A_KMAJOR, PK, BKT>(st, p.A, p.lda, m0, a_rows, kk, p.K, tid, wave);
+            pipe_stage<B_KMAJOR, PK, BKT>(st + OPB, p.B, p.ldb, n0, b_rows, kk, p.K, tid, wave);
+        }
+        const unsigned char* la = smem + (t % NS) * STG;
+        const unsigned char* lb = la + OPB;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 32; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = pipe_frag_read<A_KMAJOR, PK, BKT>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = pipe_frag_read<B_KMAJOR, PK, BKT>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    wait_vmcnt<0>();                              // the trailing zero tiles
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BKT, int NS>
+void launch_pipe(hipStream_t s, dim3 grid, const GemmParams& p, int a_kmajor, int b_kmajor, bool splitk) {
+    dim3 block(256);
+    if (splitk) {
+        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, true, BKT, NS>), grid, block, 0, s, p);
+        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, true, BKT, NS>), grid, block, 0, s, p);
+        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, true, BKT, NS>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_pipe_kernel<true, false, true, BKT, NS>), grid, block, 0, s, p);
+    } else {
+        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, false, BKT, NS>), grid, block, 0, s, p);
+        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, false, BKT, NS>), grid, block, 0, s, p);
+        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, false, BKT, NS>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_pipe_kernel<true, false, false, BKT, NS>), grid, block, 0, s, p);
+    }
+}
+
 // out[n] (+)= sum_m X[m][n]; one block per 64 columns, 4 waves stride the rows, lanes own columns
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
                                                      float* __restrict__ out, int accumulate) {
@@ -553,6 +690,17 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
     }
     static const bool use_v1 = getenv("I2T_GEMM_V1") != nullptr;
+    static const char* pipe_env = getenv("I2T_GEMM_PIPE");          // "64x3" (default) | "32x4" | "32x3" | "off"
+    static const int pipe_mode = !pipe_env ? 1 : (!strcmp(pipe_env, "32x4") ? 2 : (!strcmp(pipe_env, "32x3") ? 3 : (!strcmp(pipe_env, "off") ? 0 : 1)));
+    if (!use_v1 && pipe_mode) {
+        // the split heuristic counts 64-deep K-steps; the kernels derive their own step count from BKT
+        if (splits > 1) grid.y = splits;
+        if (pipe_mode == 1) launch_pipe<64, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        else if (pipe_mode == 2) launch_pipe<32, 4>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        else launch_pipe<32, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        I2T_CHECK_LAUNCH("i2t_gemm_bf16(pipe)");
+        return I2T_OK;
+    }
     if (!use_v1) {
         if (splits > 1) {
             grid.y = splits;
