@@ -689,9 +689,13 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
     }
-    static const bool use_v1 = getenv("I2T_GEMM_V1") != nullptr;
-    static const char* pipe_env = getenv("I2T_GEMM_PIPE");          // "64x3" (default) | "32x4" | "32x3" | "off"
-    static const int pipe_mode = !pipe_env ? 1 : (!strcmp(pipe_env, "32x4") ? 2 : (!strcmp(pipe_env, "32x3") ? 3 : (!strcmp(pipe_env, "off") ? 0 : 1)));
+    // Kernel selection (measured on MI355X, nano-224 shapes, round 1): the register-staged 2-stage kernel (v1) and the
+    // 2-stage DMA kernel tie (3046 vs 2993 images/s end to end); the deeper DMA pipelines lose (64x3: 2290, 32x4: 2721,
+    // 32x3: 2918) because they cut residency to 1-2 workgroups per CU on K = 512..768 problems that are only 8-12
+    // K-steps long.  v1 is the default; I2T_GEMM=dma|64x3|32x4|32x3 selects the others for A/B runs.
+    static const char* sel = getenv("I2T_GEMM");
+    static const bool use_v1 = !sel || !strcmp(sel, "v1");
+    static const int pipe_mode = !sel ? 0 : (!strcmp(sel, "64x3") ? 1 : (!strcmp(sel, "32x4") ? 2 : (!strcmp(sel, "32x3") ? 3 : 0)));
     if (!use_v1 && pipe_mode) {
         // the split heuristic counts 64-deep K-steps; the kernels derive their own step count from BKT
         if (splits > 1) grid.y = splits;
