@@ -537,26 +537,39 @@ void launch_pipe(hipStream_t s, dim3 grid, const GemmParams& p, int a_kmajor, in
     }
 }
 
-// out[n] (+)= sum_m X[m][n]; one block per 64 columns, 4 waves stride the rows, lanes own columns
+// out[n] (+)= sum_m X[m][n]: 16-byte loads (8 columns per lane, 512 columns per wave-row), the 4 waves of a
+// workgroup stride the rows of its slice, LDS combine, one float atomic per column per workgroup.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
-                                                     float* __restrict__ out, int accumulate) {
-    __shared__ float part[4][64];
+                                                     float* __restrict__ out) {
+    __shared__ float part[4][512];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.x * 512 + lane * 8;
     const int rows_per = (M + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float s = 0.f;
-    if (n < N)
-        for (int m = r0 + w; m < r1; m += 4) s += bf16_to_f32(X[(size_t)m * ld + n]);
-    part[w][lane] = s;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 + 8 <= N) {
+        for (int m = r0 + w; m < r1; m += 4) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(X + (size_t)m * ld + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += bf16lo(v[e]);
+                acc[2 * e + 1] += bf16hi(v[e]);
+            }
+        }
+    } else if (c0 < N) {
+        for (int m = r0 + w; m < r1; m += 4)
+            for (int e = 0; e < 8 && c0 + e < N; ++e) acc[e] += bf16_to_f32(X[(size_t)m * ld + c0 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[w][lane * 8 + e] = acc[e];
     __syncthreads();
-    if (w == 0 && n < N) {
-        float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        if (gridDim.y == 1 && !accumulate) out[n] = t;
-        else atomicAdd(out + n, t);
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int n = blockIdx.x * 512 + c;
+        if (n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
     }
 }
-
 
 // ----------------------------------------------------------------------------------------------------------------
 // Skinny GEMM (M <= 64: one decode step for up to 64 captions).  Weight-streaming bound: every weight byte is read
@@ -739,14 +752,18 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
 
 extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate) {
     I2T_REQUIRE(X && out && M > 0 && N > 0, "i2t_colsum_bf16: bad args");
-    int splits = M >= 4096 ? 16 : (M >= 512 ? 4 : 1);
+    I2T_REQUIRE((ld & 7) == 0 && ALIGNED16(X), "i2t_colsum_bf16: X must be 16-byte aligned with ld %% 8 == 0");
     hipStream_t s = (hipStream_t)stream;
-    if (splits > 1 && !accumulate) {
+    if (!accumulate) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
         if (e != hipSuccess) { i2t_set_error("i2t_colsum_bf16: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
     }
-    dim3 grid((N + 63) / 64, splits);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out, accumulate);
+    const int col_blocks = (N + 511) / 512;
+    int splits = (M + 63) / 64;                       // >= 64 rows per workgroup
+    const int want = 512 / col_blocks;                // ~2 workgroups per CU overall
+    if (splits > want) splits = want;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, splits), dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out);
     I2T_CHECK_LAUNCH("i2t_colsum_bf16");
     return I2T_OK;
 }
