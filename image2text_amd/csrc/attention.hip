@@ -87,7 +87,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 // ================================================================================================== forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O,
                                                        long o_bs, int o_rs, float* __restrict__ lse, int H, int Tq,
-                                                       int Tk, int causal) {
+                                                       int Tk, int causal, unsigned drop_key, unsigned drop_thr,
+                                                       float drop_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* kt_lds = smem;
     unsigned char* vt_lds = smem + TILE_BYTES;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;                   // running max (log2 domain) and this lane's partial row sum
     const int qlim = causal ? (min(qrow, Tq - 1) + shift) : (Tk - 1);
+    const unsigned drow = (((unsigned)b * H + h) * Tq + min(qrow, Tq - 1)) * (unsigned)Tk;    // dropout index of (b, h, q, key 0)
 
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
@@ -144,8 +146,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = exp2f(s[kj][r] - m_safe);
+                rs += p;                               // the softmax denominator is dropout-free
+                if (drop_thr) p = dropout_keep(drop_key, drow + kt * 64 + kj * 16 + 4 * g + r, drop_thr) ? p * drop_scale : 0.f;
                 s[kj][r] = p;
-                rs += p;
             }
         l = l * alpha + rs;
         m = m_new;
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int Tq,
-                                                          int Tk, int causal) {
+                                                          int Tk, int causal, unsigned drop_key, unsigned drop_thr,
+                                                          float drop_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* kt_lds = smem;
     unsigned char* vt_lds = smem + TILE_BYTES;
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     if (causal) last_key = min(last_key, qt * 64 + 63 + shift);
     const int nkt = last_key / 64 + 1;
     const int qlim = causal ? (qc + shift) : (Tk - 1);
+    const unsigned drow = (((unsigned)b * H + h) * Tq + qc) * (unsigned)Tk;
 
     f32x4 acc[4];
 #pragma unroll
@@ -243,7 +248,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 64 + kj * 16 + 4 * g + r;
                 float p = (key <= qlim && key < Tk) ? exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
-                ds[kj][r] = p * (dp[r] - dl) * SCALE;
+                float dpr = dp[r];                     // gradient w.r.t. the dropped probabilities -> undo the mask
+                if (drop_thr) dpr = dropout_keep(drop_key, drow + key, drop_thr) ? dpr * drop_scale : 0.f;
+                ds[kj][r] = p * (dpr - dl) * SCALE;
             }
         }
         const bf16x8 s0 = pack_frag(ds[0], ds[1]);
@@ -271,7 +278,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dK, long dk_bs, int dk_rs,
                                                            bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq,
-                                                           int Tk, int causal) {
+                                                           int Tk, int causal, unsigned drop_key, unsigned drop_thr,
+                                                           float drop_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * 64 * 4];
     unsigned char* q_lds = smem;
     unsigned char* do_lds = smem + TILE_BYTES;
@@ -325,8 +333,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                 int q = qt * 64 + qj * 16 + 4 * g + r;
                 bool vis = (q < Tq) && (key < Tk) && (!causal || key <= q + shift);
                 float pv = vis ? exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
-                p[qj][r] = pv;
-                ds[qj][r] = pv * (dp[r] - d4[r]) * SCALE;
+                float pd = pv, dpr = dp[r];
+                if (drop_thr) {
+                    const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * Tq + min(q, Tq - 1)) * (unsigned)Tk + key, drop_thr);
+                    pd = keep ? pv * drop_scale : 0.f;     // dV sees the dropped probabilities
+                    dpr = keep ? dpr * drop_scale : 0.f;
+                }
+                p[qj][r] = pd;
+                ds[qj][r] = pv * (dpr - d4[r]) * SCALE;
             }
         }
         const bf16x8 p0 = pack_frag(p[0], p[1]), p1 = pack_frag(p[2], p[3]);
@@ -358,7 +372,8 @@ bool strides_ok(const void* p, long bs, int rs) { return p && ALIGNED16(p) && (b
 
 extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                                  const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse, int B,
-                                 int H, int Tq, int Tk, int causal) {
+                                 int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale) {
+    I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_fwd: dropout index overflows 32 bits");
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "i2t_attention_fwd: empty problem");
     I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
                     strides_ok(o, o_bs, o_rs),
@@ -368,7 +383,7 @@ extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_r
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     dim3 grid((Tq + 63) / 64, H, B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
-                       Tq, Tk, causal);
+                       Tq, Tk, causal, drop_key, drop_thr, drop_scale);
     I2T_CHECK_LAUNCH("i2t_attention_fwd");
     return I2T_OK;
 }
@@ -377,8 +392,9 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                                  const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
                                  const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws, void* dq,
                                  long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs, void* dv, long dv_bs, int dv_rs,
-                                 int B, int H, int Tq, int Tk, int causal) {
+                                 int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale) {
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && lse && delta_ws, "i2t_attention_bwd: bad args");
+    I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_bwd: dropout index overflows 32 bits");
     I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
                     strides_ok(o, o_bs, o_rs) && strides_ok(d_o, do_bs, do_rs) && strides_ok(dq, dq_bs, dq_rs) &&
                     strides_ok(dk, dk_bs, dk_rs) && strides_ok(dv, dv_bs, dv_rs),
@@ -391,9 +407,9 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)o, o_bs, o_rs,
                        (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal);
+                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal);
+                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale);
     I2T_CHECK_LAUNCH("i2t_attention_bwd");
     return I2T_OK;
 }

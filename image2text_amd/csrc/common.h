@@ -65,6 +65,15 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// ---- counter-based dropout: keep element idx of site `key` iff hash(key, idx) >= thr (thr = p * 2^32); the same
+// function is evaluated in forward and backward, so no mask is ever stored.  (lowbias32 mixer)
+__device__ __forceinline__ unsigned dropout_hash(unsigned key, unsigned idx) {
+    unsigned x = idx ^ key;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned idx, unsigned thr) { return dropout_hash(key, idx) >= thr; }
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

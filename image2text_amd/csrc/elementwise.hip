@@ -237,6 +237,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// in-place dropout of a [rows][cols] tensor: mode 1 elementwise (idx = r*cols + c), mode 2 per (row, third of cols)
+template <bool F32>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(void* __restrict__ x, long n4, int cols, int mode, unsigned key,
+                                                            unsigned thr, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e0 = i * 4;
+        const unsigned r = (unsigned)(e0 / cols), c = (unsigned)(e0 % cols);
+        float m[4];
+        if (mode == 2) {
+            const float f = dropout_keep(key + c / (unsigned)(cols / 3), r, thr) ? scale : 0.f;
+            m[0] = m[1] = m[2] = m[3] = f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = dropout_keep(key, (unsigned)(e0 + e), thr) ? scale : 0.f;
+        }
+        if (F32) {
+            f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= m[e];
+            reinterpret_cast<f32x4*>(x)[i] = v;
+        } else {
+            u32x2 v = reinterpret_cast<u32x2*>(x)[i];
+            v[0] = pack_bf16x2(bf16lo(v[0]) * m[0], bf16hi(v[0]) * m[1]);
+            v[1] = pack_bf16x2(bf16lo(v[1]) * m[2], bf16hi(v[1]) * m[3]);
+            reinterpret_cast<u32x2*>(x)[i] = v;
+        }
+    }
+}
+
 int grid_for(long work_items, int cap = 2048) {
     long b = (work_items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -302,6 +331,19 @@ extern "C" int i2t_add_f32(void* stream, float* dst, const float* src, long n) {
     I2T_REQUIRE(dst && src && n > 0 && ALIGNED16(dst) && ALIGNED16(src), "i2t_add_f32: bad args");
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, dst, src, n >> 2, n);
     I2T_CHECK_LAUNCH("i2t_add_f32");
+    return I2T_OK;
+}
+
+extern "C" int i2t_dropout_apply(void* stream, void* x, int is_f32, long rows, int cols, int mode, unsigned key, unsigned thr,
+                                 float scale) {
+    I2T_REQUIRE(x && rows > 0 && cols > 0 && cols % 4 == 0 && ALIGNED16(x), "i2t_dropout_apply: bad args");
+    I2T_REQUIRE((mode == 1 && rows * cols < (1L << 32)) || (mode == 2 && cols % 12 == 0), "i2t_dropout_apply: mode %d unsupported here", mode);
+    const long n4 = rows * cols / 4;
+    if (is_f32)
+        hipLaunchKernelGGL(dropout_apply_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, n4, cols, mode, key, thr, scale);
+    else
+        hipLaunchKernelGGL(dropout_apply_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, n4, cols, mode, key, thr, scale);
+    I2T_CHECK_LAUNCH("i2t_dropout_apply");
     return I2T_OK;
 }
 

@@ -47,6 +47,9 @@ struct GemmParams {
     int c_is_f32;
     int accumulate;
     int tiles_m, tiles_n;
+    int drop_mode;            // 0 none | 1 elementwise (idx = m*N + n) | 2 per (row, third of N) -- the q/k/v token multipliers
+    unsigned drop_key, drop_thr;
+    float drop_scale;
 };
 
 // One operand's staging registers: 4 x 16-byte chunks per thread per K-step.
@@ -173,6 +176,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
+            }
+            if (p.drop_mode == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = dropout_keep(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)(n4 + r), p.drop_thr) ? v[r] * p.drop_scale : 0.f;
+            } else if (p.drop_mode == 2) {
+                const unsigned third = (unsigned)n4 / (unsigned)(p.N / 3);
+                const float mult = dropout_keep(p.drop_key + third, (unsigned)m, p.drop_thr) ? p.drop_scale : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= mult;
             }
             if (p.residual) {
                 const float* rr = p.residual + (size_t)m * p.ldr + n4;
@@ -653,7 +666,8 @@ void launch_skinny(hipStream_t s, const GemmParams& p, int ksplit) {
 extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor, const void* B, int ldb,
                              int b_kmajor, void* C, int ldc, int c_is_f32, int M, int N, int K, float alpha,
                              const float* bias, int act, const void* aux_in, int ld_aux_in, void* aux_out,
-                             int ld_aux_out, const float* residual, int ldr, int accumulate) {
+                             int ld_aux_out, const float* residual, int ldr, int accumulate, int drop_mode,
+                             unsigned drop_key, unsigned drop_thr, float drop_scale) {
     I2T_REQUIRE(A && B && C, "i2t_gemm_bf16: null operand");
     I2T_REQUIRE(M > 0 && N > 0 && K > 0, "i2t_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     // K need not be a multiple of 8, but an operand whose reduction index is contiguous is then read up to the
@@ -673,9 +687,12 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_in = (const bf16_t*)aux_in; p.ld_aux_in = ld_aux_in;
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
+    p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
+    I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
+                "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU && !accumulate) {
+    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU && !accumulate && !drop_mode) {
         // decode-step shape: weight-streaming kernel.  In-place residual form (C is fp32 and IS the residual) may also
         // split K across workgroups when there are too few column tiles to pull HBM bandwidth from every CU.
         int ksplit = 1;
@@ -697,7 +714,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     // split-K for accumulate-into-fp32 problems whose tile grid cannot fill the 256 CUs (the dW = dY^T.X GEMMs: small
     // M x N, very long K): enough slices to reach ~2 workgroups per CU, each slice at least 4 K-steps long
     int splits = 1;
-    const int plain_epilogue = !bias && act == I2T_ACT_NONE && !aux_out && !residual;
+    const int plain_epilogue = !bias && act == I2T_ACT_NONE && !aux_out && !residual && !drop_mode;
     if (accumulate && c_is_f32 && plain_epilogue) {
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;

@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import ops, rng
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -39,6 +39,26 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+class DropPlan:
+    """Dropout sites of one training forward: a step seed + the tower's rates.  ``get`` returns the
+    (mode, key, thr, scale) tuple the kernels take, or None when that site is off.  Sites (reference lines):
+    emb = embedding dropout (decoder.py:243, encoder.py:171); qkv = per-token q/k/v multipliers (layers.py:454-461,
+    rate attn_dropout); sdpa = dropout_p of the self-attention probabilities (layers.py:465); resid = after attn.c_proj
+    (layers.py:469); xattn = nn.MultiheadAttention's attention-weight dropout (layers.py:537-542); mlp = after
+    mlp.c_proj (layers.py:485).  The same plan object is kept in the saved context and re-evaluated in backward."""
+    KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5}
+
+    def __init__(self, seed: int, tower: int, p: float, p_attn: float):
+        self.seed, self.tower, self.p, self.p_attn = seed, tower, p, p_attn
+
+    def get(self, layer: int, kind: str):
+        p = self.p_attn if kind == 'qkv' else self.p
+        if p <= 0.0:
+            return None
+        site = self.tower * 4096 + layer * 16 + self.KINDS[kind]
+        return (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), 1.0 / (1.0 - p))
 
 
 class ParamArena:
@@ -161,27 +181,35 @@ class HotPath:
             self._conv_scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev)
             self._logits_cache.clear()
         self.arena.refresh_shadow()
-        if training and (self.enc.dropout > 0 or self.dec.dropout > 0 or self.enc.attn_dropout > 0 or self.dec.attn_dropout > 0):
-            raise NotImplementedError('dropout > 0 in training mode is not implemented in the HIP path yet; '
-                                      'set dropout/attn_dropout to 0.0 (eval mode is unaffected)')
+        self.enc_drop = self.dec_drop = None
+        if training:
+            # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run)
+            self._seed_state = (getattr(self, '_seed_state', torch.initial_seed()) * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+            if self.enc.dropout > 0 or self.enc.attn_dropout > 0:
+                self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout)
+            if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
+                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout)
         return self.arena
 
     def _empty(self, *shape, dtype=F32):
         return torch.empty(*shape, dtype=dtype, device=self.arena.device)
 
     # ------------------------------------------------------------------------------------------------ block
-    def block_fwd(self, pfx: str, x, B, T, d, H, ff, causal, mem_bf, S, save: bool):
+    def block_fwd(self, pfx: str, x, B, T, d, H, ff, causal, mem_bf, S, save: bool, plan: Optional[DropPlan] = None, layer: int = 0):
         a = self.arena
         M = B * T
-        sv = SimpleNamespace(x=x, cross=False)
+        dr = {k: (plan.get(layer, k) if plan is not None else None) for k in ('qkv', 'sdpa', 'resid', 'xattn', 'mlp')}
+        sv = SimpleNamespace(x=x, cross=False, dr=dr)
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
         qkv = self._empty(B, T, 3 * d, dtype=BF16)
-        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv.view(M, 3 * d), M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'))
+        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv.view(M, 3 * d), M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'),
+                 drop=dr['qkv'])
         ao, lse = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
-        ops.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ao, lse, B, H, T, T, causal)
+        ops.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ao, lse, B, H, T, T, causal, drop=dr['sdpa'])
         x1 = self._empty(M, d)
-        ops.gemm(ao.view(M, d), a.W(f'{pfx}.attn.c_proj.weight'), x1, M, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=x)
+        ops.gemm(ao.view(M, d), a.W(f'{pfx}.attn.c_proj.weight'), x1, M, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=x,
+                 drop=dr['resid'])
         sv.ln1, sv.m1, sv.r1, sv.qkv, sv.ao, sv.lse, sv.x1 = ln1, m1, r1, qkv, ao, lse, x1
         x2 = x1
         if mem_bf is not None:
@@ -195,7 +223,7 @@ class HotPath:
             kv = self._empty(B, S, 2 * d, dtype=BF16)
             ops.gemm(mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, 2 * d, d, bias=bin_[d:])
             co, lse_c = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
-            ops.attention_fwd(q, kv[..., :d], kv[..., d:], co, lse_c, B, H, T, S, False)
+            ops.attention_fwd(q, kv[..., :d], kv[..., d:], co, lse_c, B, H, T, S, False, drop=dr['xattn'])
             x2 = self._empty(M, d)
             ops.gemm(co.view(M, d), a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
                      bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1)
@@ -206,7 +234,8 @@ class HotPath:
         pre = self._empty(M, ff, dtype=BF16) if save else None
         ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
         x3 = self._empty(M, d)
-        ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2)
+        ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2,
+                 drop=dr['mlp'])
         sv.x2, sv.ln2, sv.m2, sv.r2, sv.h, sv.pre = x2, ln2, m2, r2, h, pre
         return x3, (sv if save else None)
 
@@ -227,7 +256,10 @@ class HotPath:
         a = self.arena
         M = B * T
         ws = self._empty(B, H, T)
-        # ---- MLP: x3 = x2 + c_proj(gelu(c_fc(ln_2 x2)))
+        dr = sv.dr
+        # ---- MLP: x3 = x2 + drop(c_proj(gelu(c_fc(ln_2 x2))))
+        if dr['mlp'] is not None:
+            ops.dropout_apply(dxb, M, d, dr['mlp'])            # the branch sees the masked gradient; dx (residual) does not
         dpre = self._empty(M, ff, dtype=BF16)
         self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
                          dx_out=dpre, act=2, aux_in=sv.pre)
@@ -245,7 +277,7 @@ class HotPath:
                              dx_out=dco.view(M, d))
             dq, dkv = self._empty(B, T, d, dtype=BF16), self._empty(B, S, 2 * d, dtype=BF16)
             ops.attention_bwd(sv.q, sv.kv[..., :d], sv.kv[..., d:], sv.co, dco, sv.lse_c, ws, dq, dkv[..., :d], dkv[..., d:],
-                              B, H, T, S, False)
+                              B, H, T, S, False, drop=dr['xattn'])
             dqf, dkvf = dq.view(M, d), dkv.view(B * S, 2 * d)
             ops.colsum(dqf, gbin[:d], M, d, accumulate=True)
             ops.gemm(dqf, sv.ln3, gin[:d], d, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
@@ -255,13 +287,18 @@ class HotPath:
             ops.gemm(dkvf, win[d:], dmem, B * S, d, 2 * d, b_kmajor=True, accumulate=True)
             ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_3.weight'), sv.m3, sv.r3, dx, a.G(f'{pfx}.ln_3.weight'),
                               a.G(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb)
-        # ---- self attention: x1 = x + c_proj(attn(c_attn(ln_1 x)))
+        # ---- self attention: x1 = x + drop(c_proj(attn(mult * c_attn(ln_1 x))))
+        if dr['resid'] is not None:
+            ops.dropout_apply(dxb, M, d, dr['resid'])
         dao = self._empty(B, T, d, dtype=BF16)
         self._linear_bwd(dxb, M, d, d, sv.ao.view(M, d), f'{pfx}.attn.c_proj.weight',
                          f'{pfx}.attn.c_proj.bias' if a.G(f'{pfx}.attn.c_proj.bias') is not None else None, dx_out=dao.view(M, d))
         dqkv = self._empty(B, T, 3 * d, dtype=BF16)
         q, k, v = sv.qkv[..., :d], sv.qkv[..., d:2 * d], sv.qkv[..., 2 * d:]
-        ops.attention_bwd(q, k, v, sv.ao, dao, sv.lse, ws, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, T, T, causal)
+        ops.attention_bwd(q, k, v, sv.ao, dao, sv.lse, ws, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, T, T, causal,
+                          drop=dr['sdpa'])
+        if dr['qkv'] is not None:
+            ops.dropout_apply(dqkv, M, 3 * d, dr['qkv'])       # gradient w.r.t. the un-multiplied q/k/v
         self._linear_bwd(dqkv.view(M, 3 * d), M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
                          f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
         ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
@@ -301,9 +338,13 @@ class HotPath:
         x = self._empty(B, T, d)
         ops.layernorm_nd_fwd(y1, wpe, g, bta, x[:, e.ncls:], T * d, st2, B, e.P2, d)
         ops.bcast_rows(a.P(f'{self.ep}cls_token'), x, T * d, B, e.ncls, d)
+        plan = self.enc_drop
+        emb_drop = plan.get(0, 'emb') if plan is not None else None
+        if emb_drop is not None:
+            ops.dropout_apply(x, B * T, d, emb_drop)
         saves, cur_x = [], x.view(B * T, d)
         for l in range(e.L):
-            cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save)
+            cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save, plan, l)
             saves.append(sv)
         Mc = B * e.ncls
         cls = self._empty(Mc, d)
@@ -322,7 +363,7 @@ class HotPath:
         ctx = None
         if save:
             ctx = SimpleNamespace(images=images, acts=acts, flat=flat, proj=proj, y1=y1, st1=st1, st2=st2, saves=saves,
-                                  cls=cls, mf=mf, rf=rf, lnf=lnf, B=B, Hh=Hh, Ww=Ww)
+                                  cls=cls, mf=mf, rf=rf, lnf=lnf, B=B, Hh=Hh, Ww=Ww, emb_drop=emb_drop)
         return enc_out.view(B, e.ncls, -1), ctx
 
     def encode_backward(self, ctx, denc: torch.Tensor):
@@ -344,6 +385,8 @@ class HotPath:
         dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
         ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
         self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
+        if ctx.emb_drop is not None:
+            ops.dropout_apply(dx, B * T, d, ctx.emb_drop)
         ops.sum_over_batch(dx, T * d, a.G(f'{self.ep}cls_token'), B, e.ncls, d, accumulate=True)
         g = a.P(f'{self.ep}ln_input.weight')
         gg, gb = a.G(f'{self.ep}ln_input.weight'), a.G(f'{self.ep}ln_input.bias')
@@ -391,22 +434,27 @@ class HotPath:
         d, M = dc.d, B * T
         x = self._empty(M, d)
         wpe = a.P(f'{self.dp}transformer.wpe.weight')
+        plan = self.dec_drop if save else None
+        emb_drop = plan.get(0, 'emb') if plan is not None else None
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()
             ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
+            if emb_drop is not None:
+                ops.dropout_apply(x, M, d, emb_drop)
         else:
             ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
             ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
         saves, cur = [], x
         for l in range(dc.L):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
-            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save)
+            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l)
             saves.append(sv)
         hid, mf, rf = self._empty(M, d), self._empty(M), self._empty(M)
         ops.layernorm_fwd(cur, a.P(f'{self.dp}transformer.ln_f.weight'), a.P(f'{self.dp}transformer.ln_f.bias'), hid, mf, rf, M, d)
         hb = self._empty(M, d, dtype=BF16)
         ops.cast_f32_bf16(hid, hb)
-        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset) if save else None
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset,
+                              emb_drop=emb_drop if ids is not None else None) if save else None
         return hid, hb, ctx
 
     def logits_f32(self, hb: torch.Tensor, M: int):
@@ -439,6 +487,8 @@ class HotPath:
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
         self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem)
         if ctx.ids is not None:
+            if ctx.emb_drop is not None:
+                ops.dropout_apply(dx, M, d, ctx.emb_drop)
             ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), B, T, d, ctx.pos_offset, dc.V)
             return None
         ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)

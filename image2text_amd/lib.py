@@ -7,20 +7,20 @@ import torch  # noqa: F401  -- must come first: libi2t_hip.so has to bind to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libi2t_hip.so')
 
-P, I, L, F, I64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64
+P, I, L, F, I64, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64, C.c_uint
 
 # name -> argtypes, in the order of include/i2t.h
 SIGNATURES = {
     'i2t_abi_version': [],
     'i2t_last_error': [C.c_char_p, C.c_size_t],
-    'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I],
+    'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I, I, U, U, F],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
-    'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I],
-    'i2t_attention_bwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I],
+    'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, U, U, F],
+    'i2t_attention_bwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I, U, U, F],
     'i2t_embed_fwd': [P, P, P, P, P, I, I, I, I, I],
     'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I],
     'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
@@ -33,6 +33,7 @@ SIGNATURES = {
     'i2t_conv6_bwd_data': [P, P, I, P, P, P, P, I, I, I, I, I],
     'i2t_conv6_bwd_weight': [P, P, I, P, I, I, P, P, P, I, I, I, I, I],
     'i2t_cast_f32_bf16': [P, P, P, L],
+    'i2t_dropout_apply': [P, P, I, L, I, I, U, U, F],
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_bcast_rows': [P, P, P, L, I, I, I],
     'i2t_sum_over_batch': [P, P, L, P, I, I, I, I],

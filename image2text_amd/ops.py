@@ -31,9 +31,14 @@ def _need_cuda(*ts):
             raise _l.I2TError('image2text_amd ops need tensors on the MI355X (cuda) device; there is no CPU path')
 
 
+def _drop(drop):
+    """drop = None | (mode, key, thr, scale) -> the four trailing dropout arguments of the C ABI."""
+    return (0, 0, 0, 1.0) if drop is None else (int(drop[0]), int(drop[1]), int(drop[2]), float(drop[3]))
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
          lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         ldr=None, accumulate=False):
+         ldr=None, accumulate=False, drop=None):
     """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16."""
     _need_cuda(a, b, out)
     assert a.dtype == BF16 and b.dtype == BF16 and out.dtype in (BF16, F32)
@@ -45,7 +50,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     ldr = (residual.stride(0) if residual is not None else 0) if ldr is None else ldr
     _l.check(_lib().i2t_gemm_bf16(_stream(), _p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc,
                                   int(out.dtype == F32), M, N, K, float(alpha), _p(bias), int(act), _p(aux_in), ld_ai,
-                                  _p(aux_out), ld_ao, _p(residual), ldr, int(accumulate)), 'i2t_gemm_bf16')
+                                  _p(aux_out), ld_ao, _p(residual), ldr, int(accumulate), *_drop(drop)), 'i2t_gemm_bf16')
     return out
 
 
@@ -93,22 +98,22 @@ def _bs_rs(t: torch.Tensor):
     return t.stride(0), t.stride(1)
 
 
-def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal):
+def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=None):
     """q,k,v,o: bf16 [B, T, >=64H] views (last dim contiguous; heads at 64-column steps)."""
     _need_cuda(q, k, v, o)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o)
     _l.check(_lib().i2t_attention_fwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(lse), B, H, Tq,
-                                      Tk, int(causal)), 'i2t_attention_fwd')
+                                      Tk, int(causal), *_drop(drop)[1:]), 'i2t_attention_fwd')
     return o
 
 
-def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal):
+def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None):
     _need_cuda(q, k, v, o, do, dq, dk, dv)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
     dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
     _l.check(_lib().i2t_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
                                       _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
-                                      int(causal)), 'i2t_attention_bwd')
+                                      int(causal), *_drop(drop)[1:]), 'i2t_attention_bwd')
 
 
 def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab):
@@ -181,6 +186,13 @@ def conv6_bwd_weight(dy, dy_layout, x, x_layout, in_gelu, dw, db, scratch, B, Ci
     _need_cuda(dy, x, dw, scratch)
     _l.check(_lib().i2t_conv6_bwd_weight(_stream(), _p(dy), dy_layout, _p(x), x_layout, int(in_gelu), _p(dw), _p(db), _p(scratch),
                                          B, Cin, Cout, H, W), 'i2t_conv6_bwd_weight')
+
+
+def dropout_apply(x, rows, cols, drop):
+    """in place; drop = (mode, key, thr, scale)"""
+    _need_cuda(x)
+    _l.check(_lib().i2t_dropout_apply(_stream(), _p(x), int(x.dtype == F32), rows, cols, *_drop(drop)), 'i2t_dropout_apply')
+    return x
 
 
 def cast_f32_bf16(src, dst, n=None):

@@ -42,6 +42,9 @@ int i2t_last_error(char* buf, size_t n);
  *   b_kmajor = 0: B stored [N][K] (K contiguous)      b_kmajor = 1: B stored [K][N] (N contiguous)
  *   epilogue order: v = alpha*acc; v += bias[n]; if aux_out: aux_out[m][n] = bf16(v)  (pre-activation)
  *                   act 1: v = gelu_tanh(v);  act 2: v *= gelu_tanh'(aux_in[m][n])
+ *                   dropout (training): drop_mode 1: v = keep(key, m*N+n) ? v*scale : 0  (resid / MLP dropout,
+ *                   layers.py:469,485); drop_mode 2: v *= keep(key + n/(N/3), m) ? scale : 0  (the per-token q/k/v
+ *                   multipliers of layers.py:454-461 on the fused c_attn output); keep(key, i) = hash(key, i) >= thr
  *                   v += residual[m][n] (f32);  accumulate: v += C[m][n] (f32 C only);  store C as f32 or bf16.
  *   K must be a multiple of 8.  Columns [N, ldc) of C are never written.
  * --------------------------------------------------------------------------------------------------------- */
@@ -57,7 +60,8 @@ int i2t_gemm_bf16(void* stream,
                   const void* aux_in, int ld_aux_in,
                   void* aux_out, int ld_aux_out,
                   const float* residual, int ldr,
-                  int accumulate);
+                  int accumulate,
+                  int drop_mode, unsigned drop_key, unsigned drop_thr, float drop_scale);
 
 /* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients; X bf16 [M][ld]) */
 int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate);
@@ -96,15 +100,18 @@ int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch_stride, co
  *   Packed c_attn output: q=base, k=base+d, v=base+2d, row stride 3d.  lse f32 [B][H][Tq] (natural log).
  *   causal: key j visible to query i iff j <= i + (Tk - Tq)   (Tk == Tq in training; Tk > Tq with a KV cache)
  *   bwd: dq/dk/dv written (not accumulated), same strides convention as their forward operands.
+ *   dropout on the attention probabilities (SDPA dropout_p, layers.py:465; nn.MultiheadAttention dropout): drop_thr = p*2^32
+ *   (0 = off), probability (b,h,q,key) kept iff hash(drop_key, ((b*H+h)*Tq+q)*Tk+key) >= drop_thr, scaled by drop_scale.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                       const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
-                      int B, int H, int Tq, int Tk, int causal);
+                      int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale);
 int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                       const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
                       const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,
                       void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
-                      void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal);
+                      void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal,
+                      unsigned drop_key, unsigned drop_thr, float drop_scale);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token + position embedding (decoder.py:231-243): x[b][t] = wte[ids[b][t]] + wpe[t + pos_offset]  (f32)
@@ -171,6 +178,11 @@ int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout, const void
  *   add_rows / cls concat helpers for the encoder token buffer.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n);
+/* in-place dropout of x[rows][cols] (f32 or bf16) with the same counter-based keep rule as the fused epilogues:
+ * mode 1: element (r, c) kept iff hash(key, r*cols + c) >= thr; mode 2: all of (r, third t of cols) kept iff
+ * hash(key + t, r) >= thr.  Used for the embedding dropouts and to re-apply a forward mask to a gradient. */
+int i2t_dropout_apply(void* stream, void* x, int is_f32, long rows, int cols, int mode, unsigned key, unsigned thr,
+                      float scale);
 int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                    const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                    float beta1, float beta2, float eps, int step, float grad_scale);

@@ -42,6 +42,22 @@ def _drop(x, p, training):
     return F.dropout(x, p, training) if (training and p > 0) else x
 
 
+def _planned(entry, x, per_row_third=None):
+    """Dropout with the EXACT mask the HIP path uses for a site (``entry`` = (mode, key, thr, scale) from
+    image2text_amd.engine.DropPlan.get, rebuilt on the host by image2text_amd.rng.keep_mask).  torch's own RNG stream
+    cannot be matched, so parity under dropout is defined as: same masks -> same loss / gradients."""
+    if entry is None:
+        return x
+    from image2text_amd import rng
+    mode, key, thr, scale = entry
+    if mode == 2:       # per (row, third): x is (B, 1, T, 1) ones for third `per_row_third`
+        B, _, T, _ = x.shape
+        m = rng.keep_mask((key + per_row_third) & 0xFFFFFFFF, B * T, thr).view(B, 1, T, 1)
+    else:
+        m = rng.keep_mask(key, x.numel(), thr).view(x.shape)
+    return x * m.to(x.dtype) * scale
+
+
 # --------------------------------------------------------------------------------------------------------------
 # blocks (models/layers.py)
 # --------------------------------------------------------------------------------------------------------------
@@ -68,7 +84,7 @@ def conv_stack(sd: SD, prefix: str, x):
     return x
 
 
-def softmax_attention(q, k, v, add_mask, dropout_p=0.0, training=False):
+def softmax_attention(q, k, v, add_mask, dropout_p=0.0, training=False, planned=None):
     """F.scaled_dot_product_attention semantics as used at layers.py:465 and inside nn.MultiheadAttention:
     softmax(q k^T / sqrt(dh) + mask) v with the torch>=2.5 'safe softmax' rule: a fully masked row yields zeros."""
     s = (q @ k.transpose(-1, -2)) / math.sqrt(q.size(-1))
@@ -79,24 +95,30 @@ def softmax_attention(q, k, v, add_mask, dropout_p=0.0, training=False):
     p = torch.exp(s - m)
     z = p.sum(dim=-1, keepdim=True)
     p = p / torch.where(z == 0, torch.ones_like(z), z)
-    p = _drop(p, dropout_p, training)
+    p = _planned(planned, p) if planned is not None else _drop(p, dropout_p, training)
     return p @ v
 
 
-def self_attention(sd: SD, p: str, x, n_head: int, add_mask, dropout=0.0, attn_dropout=0.0, training=False):
+def self_attention(sd: SD, p: str, x, n_head: int, add_mask, dropout=0.0, attn_dropout=0.0, training=False, plan=None, layer=0):
     """layers.py:433-470 MultiHeadAttention: fused c_attn, per-token dropout multipliers, SDPA, c_proj."""
     B, T, C = x.shape
     qkv = F.linear(x, sd[f'{p}.c_attn.weight'], _get(sd, f'{p}.c_attn.bias'))
     q, k, v = qkv.split(C, dim=2)
     ones = torch.ones((B, 1, T, 1), dtype=x.dtype)
-    k_do, q_do, v_do = (_drop(ones, attn_dropout, training) for _ in range(3))   # layers.py:454-457 order
+    if plan is not None:      # HIP-path masks: thirds 0/1/2 of the fused c_attn output = q/k/v
+        e = plan.get(layer, 'qkv')
+        q_do, k_do, v_do = (_planned(e, ones, t) for t in range(3))
+    else:
+        k_do, q_do, v_do = (_drop(ones, attn_dropout, training) for _ in range(3))   # layers.py:454-457 order
     heads = lambda t: t.view(B, T, n_head, C // n_head).transpose(1, 2)
-    y = softmax_attention(q_do * heads(q), k_do * heads(k), v_do * heads(v), add_mask, dropout, training)
+    y = softmax_attention(q_do * heads(q), k_do * heads(k), v_do * heads(v), add_mask, dropout, training,
+                          planned=plan.get(layer, 'sdpa') if plan is not None else None)
     y = y.transpose(1, 2).contiguous().view(B, T, C)
-    return _drop(F.linear(y, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias')), dropout, training)
+    out = F.linear(y, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias'))
+    return _planned(plan.get(layer, 'resid'), out) if plan is not None else _drop(out, dropout, training)
 
 
-def cross_attention(sd: SD, p: str, x, mem, n_head: int, dropout=0.0, training=False):
+def cross_attention(sd: SD, p: str, x, mem, n_head: int, dropout=0.0, training=False, plan=None, layer=0):
     """layers.py:537-542,600-605 -- nn.MultiheadAttention(batch_first) with packed in_proj (3d,d), always biased:
     q from x, k/v from the encoder output, no mask, dropout on the attention weights, out_proj."""
     B, T, C = x.shape
@@ -108,18 +130,20 @@ def cross_attention(sd: SD, p: str, x, mem, n_head: int, dropout=0.0, training=F
     hq = q.view(B, T, n_head, C // n_head).transpose(1, 2)
     hk = k.view(B, S, n_head, C // n_head).transpose(1, 2)
     hv = v.view(B, S, n_head, C // n_head).transpose(1, 2)
-    y = softmax_attention(hq, hk, hv, None, dropout, training).transpose(1, 2).contiguous().view(B, T, C)
+    y = softmax_attention(hq, hk, hv, None, dropout, training,
+                          planned=plan.get(layer, 'xattn') if plan is not None else None).transpose(1, 2).contiguous().view(B, T, C)
     return F.linear(y, sd[f'{p}.out_proj.weight'], sd[f'{p}.out_proj.bias'])
 
 
-def gelu_mlp(sd: SD, p: str, x, dropout=0.0, training=False):
+def gelu_mlp(sd: SD, p: str, x, dropout=0.0, training=False, plan=None, layer=0):
     """layers.py:473-486 -- Linear d->4d, GELU(tanh), Linear 4d->d, dropout."""
     h = F.gelu(F.linear(x, sd[f'{p}.c_fc.weight'], _get(sd, f'{p}.c_fc.bias')), approximate='tanh')
-    return _drop(F.linear(h, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias')), dropout, training)
+    out = F.linear(h, sd[f'{p}.c_proj.weight'], _get(sd, f'{p}.c_proj.bias'))
+    return _planned(plan.get(layer, 'mlp'), out) if plan is not None else _drop(out, dropout, training)
 
 
 def transformer_block(sd: SD, p: str, x, n_head: int, causal: bool, mem, add_mask, dropout=0.0, attn_dropout=0.0,
-                      training=False):
+                      training=False, plan=None, layer=0):
     """layers.py:565-608 dense branch: pre-LN residual wiring attn -> (cross) -> mlp, then the gradient normaliser."""
     if causal:
         L = x.size(-2)
@@ -127,15 +151,15 @@ def transformer_block(sd: SD, p: str, x, n_head: int, causal: bool, mem, add_mas
         cm = torch.zeros((L, L), dtype=x.dtype).masked_fill(~tri, NEG_INF)[None, None]
         add_mask = cm if add_mask is None else add_mask + cm
     x = x + self_attention(sd, f'{p}.attn', layer_norm(x, sd[f'{p}.ln_1.weight'], _get(sd, f'{p}.ln_1.bias')),
-                           n_head, add_mask, dropout, attn_dropout, training)
+                           n_head, add_mask, dropout, attn_dropout, training, plan, layer)
     if mem is not None:
         if f'{p}.cross_attn.in_proj_weight' not in sd:
             raise ValueError('Model not configured for cross attn inputs!!!')        # layers.py:598-599
         x = x + cross_attention(sd, f'{p}.cross_attn',
                                 layer_norm(x, sd[f'{p}.ln_3.weight'], _get(sd, f'{p}.ln_3.bias')), mem, n_head,
-                                dropout, training)
+                                dropout, training, plan, layer)
     x = x + gelu_mlp(sd, f'{p}.mlp', layer_norm(x, sd[f'{p}.ln_2.weight'], _get(sd, f'{p}.ln_2.bias')), dropout,
-                     training)
+                     training, plan, layer)
     return _UnitNormGrad.apply(x)
 
 
@@ -147,7 +171,7 @@ def _sub(sd: SD, prefix: str) -> SD:
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def vit_encoder(sd: SD, cfg, images, training=False):
+def vit_encoder(sd: SD, cfg, images, training=False, plan=None):
     """encoder.py:163-178.  ``sd`` keys are relative to the VisionTransformerEncoder module.
 
     conv stack -> FLAT reshape to (n, P^2, C*ph*pw) (a chunking of the contiguous CHW buffer, not spatial patches,
@@ -164,23 +188,24 @@ def vit_encoder(sd: SD, cfg, images, training=False):
     x = x + sd['transformer.wpe.weight'][:P2].unsqueeze(0)
     x = layer_norm(x, sd['ln_input.weight'], _get(sd, 'ln_input.bias'))
     x = torch.cat((sd['cls_token'].expand(n, -1, -1), x), dim=1)
-    x = _drop(x, ac.dropout, training)
+    x = _planned(plan.get(0, 'emb'), x) if plan is not None else _drop(x, ac.dropout, training)
     for i in range(cfg.n_layer):
         x = transformer_block(sd, f'transformer.h.{i}', x, ac.n_head, cfg.transformer_config.is_causal, None, None,
-                              ac.dropout, ac.attn_dropout, training)
+                              ac.dropout, ac.attn_dropout, training, plan, i)
     return layer_norm(x[:, :cfg.n_cls].contiguous(), sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
 
 
-def encode(sd: SD, cfg, images, training=False):
+def encode(sd: SD, cfg, images, training=False, plan=None):
     """vision_encoder_decoder.py:26-39,58-59: encoder, then the bias-free bridge Linear when the widths differ
     (state-dict keys then carry the nn.Sequential prefixes ``encoder.0.`` / ``encoder.1.``)."""
     if 'encoder.1.weight' in sd:
-        y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training)
+        y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training, plan)
         return F.linear(y, sd['encoder.1.weight'])
-    return vit_encoder(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images, training)
+    return vit_encoder(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images, training, plan)
 
 
-def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=None, attn_msk=None, training=False):
+def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=None, attn_msk=None, training=False, plan=None,
+                pos_offset=0):
     """decoder.py:214-256.  ``sd`` keys relative to TransformerDecoder.  Returns (logits, hidden)."""
     assert (idx is None) != (inputs_embeds is None)
     ac = cfg.transformer_config.attn_config
@@ -188,11 +213,12 @@ def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=Non
         inputs_embeds = sd['transformer.wte.weight'][idx]
     t = inputs_embeds.size(1)
     assert t <= cfg.block_size, f'Cannot forward sequence of length {t}, block size is only {cfg.block_size}'
-    x = _drop(inputs_embeds + sd['transformer.wpe.weight'][:t], ac.dropout, training)
+    x = inputs_embeds + sd['transformer.wpe.weight'][pos_offset:pos_offset + t]
+    x = _planned(plan.get(0, 'emb'), x) if plan is not None else _drop(x, ac.dropout, training)
     for depth in range(cfg.n_layer):
         mem = cross_attn_embeds if (depth % 2 == 0 or not cfg.skip_alternate_cross_attn) else None
         x = transformer_block(sd, f'transformer.h.{depth}', x, ac.n_head, cfg.transformer_config.is_causal, mem,
-                              attn_msk, ac.dropout, ac.attn_dropout, training)
+                              attn_msk, ac.dropout, ac.attn_dropout, training, plan, depth)
     x = layer_norm(x, sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
     return F.linear(x, sd['transformer.wte.weight']), x          # lm_head is tied to wte (decoder.py:189-204)
 
@@ -256,6 +282,23 @@ def forward(sd: SD, cfg, images, ids, attn_msk=None, encoder_output=None, traini
                                  cross_attn_embeds=encoder_output if cfg.use_cross_attn else None,
                                  attn_msk=add, training=training)
     return encoder_output, logits, hidden
+
+
+def lm_step_text_segment(sd: SD, cfg, images, labels, tokenizer, plans=(None, None), ignore_index=-100, temperature=1.0):
+    """The factorisation the HIP path runs (engine.py): because text rows never see prompt columns and prompt-row
+    logits are sliced off, the loss only needs the TEXT segment -- a plain causal pass over the ids with the position
+    embedding offset by n_cls and cross-attention on the encoder output.  Without dropout this equals ``lm_step``
+    (test_oracle_golden); with ``plans`` = (encoder DropPlan, decoder DropPlan) it applies the HIP path's exact masks."""
+    ids, _ = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
+    enc = encode(sd, cfg, images, True, plans[0])
+    off = enc.size(1) if cfg.use_soft_prompting else 0
+    logits, _ = gpt_decoder(_sub(sd, 'decoder.'), cfg.decoder_config, idx=ids,
+                            cross_attn_embeds=enc if cfg.use_cross_attn else None, attn_msk=None, training=True,
+                            plan=plans[1], pos_offset=off)
+    w = loss_weights(labels, ignore_index)
+    ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)) / temperature, labels.reshape(-1), ignore_index=ignore_index,
+                         reduction='none')
+    return (ce * w.reshape(-1)).sum()
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -31,7 +31,8 @@ def ctype_of(decl: str):
             return C.POINTER(C.c_void_p)
         return C.c_void_p
     base = decl.rsplit(' ', 1)[0].strip()
-    return {'int': C.c_int, 'long': C.c_long, 'float': C.c_float, 'int64_t': C.c_int64, 'size_t': C.c_size_t}[base]
+    return {'int': C.c_int, 'long': C.c_long, 'float': C.c_float, 'int64_t': C.c_int64, 'size_t': C.c_size_t,
+            'unsigned': C.c_uint}[base]
 
 
 @pytest.fixture(scope='module')
@@ -67,6 +68,6 @@ def test_binding_matches_header_argument_types(built):
 def test_error_channel(built):
     lib = i2tlib.load()
     # argument validation happens before any HIP call: a null operand must be refused with a message
-    rc = lib.i2t_gemm_bf16(None, None, 8, 0, None, 8, 0, None, 8, 0, 1, 1, 8, 1.0, None, 0, None, 0, None, 0, None, 0, 0)
+    rc = lib.i2t_gemm_bf16(None, None, 8, 0, None, 8, 0, None, 8, 0, 1, 1, 8, 1.0, None, 0, None, 0, None, 0, None, 0, 0, 0, 0, 0, 1.0)
     assert rc == -1
     assert 'null operand' in i2tlib.last_error()

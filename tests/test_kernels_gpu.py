@@ -520,3 +520,62 @@ def test_conv6_mfma_stack(ops, B, H, W, chans):
             ref_dx = a2.grad * gelu_grad(ys[i - 1].float().permute(0, 3, 1, 2))
             check(f'conv6 dX layer {i}', dx.float().permute(0, 3, 1, 2), ref_dx, 2e-2 * float(ref_dx.abs().max()), 1 / 32)
             dy, dy_layout = dx, 2
+
+
+# ------------------------------------------------------------------------------------------------------ dropout
+def test_dropout_rule_matches_host_replica(ops):
+    from image2text_amd import rng
+    key, thr = rng.site_key(123456789012345, 4099), rng.threshold(0.1)
+    x = torch.ones(300, 768, device=dev())
+    ops.dropout_apply(x, 300, 768, (1, key, thr, 1 / 0.9))
+    m = rng.keep_mask(key, 300 * 768, thr).view(300, 768)
+    assert torch.equal(x.cpu() != 0, m) and abs(float(m.float().mean()) - 0.9) < 5e-3
+    check('scale', x.cpu()[m], torch.full((int(m.sum()),), 1 / 0.9), 1e-6, 0)
+    y = torch.ones(64, 3 * 128, dtype=BF16, device=dev())
+    ops.dropout_apply(y, 64, 384, (2, key, thr, 1 / 0.9))
+    for t in range(3):
+        mt = rng.keep_mask((key + t) & 0xFFFFFFFF, 64, thr)
+        assert torch.equal((y[:, t * 128:(t + 1) * 128].float().cpu() != 0), mt[:, None].expand(64, 128))
+
+
+def test_gemm_epilogue_dropout(ops):
+    from image2text_amd import rng
+    M, N, K = 200, 384, 128
+    a, b = rnd(M, K, dtype=BF16, seed=160), rnd(N, K, dtype=BF16, seed=161, scale=0.2)
+    bias, res = rnd(N, seed=162), rnd(M, N, seed=163)
+    key, thr, sc = rng.site_key(77, 5), rng.threshold(0.25), 1 / 0.75
+    base = a.float() @ b.float().t() + bias
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(a, b, out, M, N, K, bias=bias, residual=res, drop=(1, key, thr, sc))
+    m = rng.keep_mask(key, M * N, thr).view(M, N).to(dev())
+    check('resid dropout', out, res + base * m * sc, 2e-3, 2e-3)
+    outb = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, outb, M, N, K, bias=bias, drop=(2, key, thr, sc))
+    mult = torch.stack([rng.keep_mask((key + t) & 0xFFFFFFFF, M, thr) for t in range(3)], 1).float().to(dev()) * sc     # (M, 3)
+    check('qkv multipliers', outb, base * mult.repeat_interleave(N // 3, dim=1), 2e-2, 1 / 128)
+
+
+@pytest.mark.parametrize('B,H,Tq,Tk,causal', [(2, 2, 64, 64, True), (2, 3, 100, 40, False)])
+def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
+    from image2text_amd import rng
+    d = 64 * H
+    q, k, v = rnd(B, Tq, d, dtype=BF16, seed=170), rnd(B, Tk, d, dtype=BF16, seed=171), rnd(B, Tk, d, dtype=BF16, seed=172)
+    key, thr, sc = rng.site_key(99, 18), rng.threshold(0.2), 1 / 0.8
+    mask = rng.keep_mask(key, B * H * Tq * Tk, thr).view(B, H, Tq, Tk).to(dev())
+    qr, kr, vr = (t.float().reshape(B, -1, H, 64).permute(0, 2, 1, 3).double().requires_grad_(True) for t in (q, k, v))
+    s = qr @ kr.transpose(-1, -2) / 8.0
+    if causal:
+        i, j = torch.arange(Tq, device=dev())[:, None], torch.arange(Tk, device=dev())[None, :]
+        s = s.masked_fill(j > i + (Tk - Tq), float('-inf'))
+    p = torch.softmax(s, -1) * mask * sc
+    o_ref = (p @ vr).permute(0, 2, 1, 3)
+    o, lse = torch.empty(B, Tq, d, dtype=BF16, device=dev()), torch.empty(B, H, Tq, device=dev())
+    ops.attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=(1, key, thr, sc))
+    check('attn dropout out', o.reshape(B, Tq, H, 64), o_ref, 1e-2, 1 / 128)
+    do = rnd(B, Tq, d, dtype=BF16, seed=173)
+    o_ref.backward(do.double().reshape(B, Tq, H, 64))
+    dq, dk, dv = (torch.zeros_like(t) for t in (q, k, v))
+    ops.attention_bwd(q, k, v, o, do, lse, torch.empty(B, H, Tq, device=dev()), dq, dk, dv, B, H, Tq, Tk, causal, drop=(1, key, thr, sc))
+    sc_ = float(do.float().abs().max())
+    for name, got, ref in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
+        check(f'attn dropout {name}', got.reshape(B, -1, H, 64), ref.permute(0, 2, 1, 3), 3e-2 * sc_, 1 / 32)

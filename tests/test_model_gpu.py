@@ -360,3 +360,47 @@ def test_nano224_greedy_tokens(nano224_golden):
         for n in (2, 3, 4, 5):
             grams = [tuple(row[i:i + n]) for i in range(len(row) - n + 1)]
             assert len(grams) == len(set(grams)), f'repeated {n}-gram in greedy output'
+
+
+def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
+    """Dropout 0.1 / attn_dropout 0.1 in both towers: the oracle is fed the exact masks of the HIP step (rebuilt on the host
+    from the step's DropPlans), so loss and every gradient must agree as in the dropout-free case; a second step must draw
+    different masks; eval mode must be dropout-free."""
+    from oracle import reference_model as orc
+    cfg = tiny_config(dropout=0.1)
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    w = _wrapper(cfg)
+    det_init_(w.model, seed=0)
+    sd = {k: v.detach().cpu().clone() for k, v in w.model.state_dict().items()}
+    w.train()
+    images, labels = synthetic_batch(4, 32, 16, cfg.decoder_config.vocab_size, seed=9)
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    eng = w.model._engine
+    plans = (eng.enc_drop, eng.dec_drop)
+    assert plans[0] is not None and plans[1] is not None
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'decoder.lm_head.weight'}
+    osd['decoder.lm_head.weight'] = osd['decoder.transformer.wte.weight']
+    oloss = orc.lm_step_text_segment(osd, cfg, images, labels, tok, plans)
+    oloss.backward()
+    REPORT['tiny_dropout.train_loss'] = {'got': float(loss.detach()), 'ref': float(oloss)}
+    assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * float(oloss)
+    fails = []
+    for name, p in w.model.named_parameters():
+        try:
+            grad_close(f'tiny_dropout.{name}', p.grad, osd[name].grad.numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    # the dropout-free loss differs (masks really were applied) and a new step draws new masks
+    with torch.no_grad():
+        clean = orc.lm_step_text_segment(sd, cfg, images, labels, tok)
+    assert abs(float(clean) - float(oloss)) > 1e-3
+    w.zero_grad()
+    loss2, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    assert abs(float(loss2.detach()) - float(loss.detach())) > 1e-4
+    w.eval()
+    with torch.no_grad():
+        v1, _ = w.val_step(images.to(dev()), labels.to(dev()))
+        v2, _ = w.val_step(images.to(dev()), labels.to(dev()))
+    assert float(v1) == float(v2) and abs(float(v1) - float(clean)) <= 1e-2 * float(clean)

@@ -117,3 +117,13 @@ def test_nano224_full_size(nano224_golden):
     assert abs(vloss.item() - float(g['val_loss'])) < 1e-4
     gids = orc.generate_greedy(sd, cfg, images, torch.full((2, 1), tok.bos_token_id), 4)
     assert np.array_equal(gids.numpy(), g['greedy_ids'][:, :5])
+
+
+def test_text_segment_factorisation_equals_full_sequence(tiny_weights, tiny_forward, tiny_train):
+    """The text-only pass the HIP path runs is the same function as the reference's full prompt+text sequence."""
+    cfg = tiny_config()
+    f = tiny_forward
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    with torch.no_grad():
+        a = orc.lm_step_text_segment(tiny_weights, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['labels']), tok)
+    assert abs(a.item() - float(tiny_train['loss'])) < 1e-6
