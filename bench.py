@@ -34,7 +34,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
+    ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=64, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
     ap.add_argument('--decode-streams', type=int, default=8, help='independent caption batches decoded concurrently')
@@ -124,7 +125,7 @@ def main():
     from image2text_amd.training.optim import FusedAdamW
     from image2text_amd.training.wrapper import ModelTrainerWrapper
 
-    cfg = nano224_config(dropout=0.0)
+    cfg = nano224_config(dropout=args.dropout)
     V = cfg.decoder_config.vocab_size
     torch.manual_seed(0)
     wrapper = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
@@ -208,7 +209,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'nano-224 (6x512 ViT encoder + 12x768 nanoGPT decoder, 224x224x3 images, 64-token captions)',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'caption_len': 64,
-                       'parallelism': f'dp{world}', 'dropout': 0.0, 'optimizer': 'AdamW lr 6e-4 betas (0.9,0.95)',
+                       'parallelism': f'dp{world}', 'dropout': args.dropout, 'optimizer': 'AdamW lr 6e-4 betas (0.9,0.95)',
                        'weights': 'random init (reference distributions)'},
             'greedy_captions_per_sec': None if cap_s is None else round(cap_s, 2),
             'greedy_config': {'captions_per_batch': args.decode_batch, 'concurrent_batches_per_gpu': args.decode_streams,

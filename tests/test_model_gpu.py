@@ -403,4 +403,4 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
     with torch.no_grad():
         v1, _ = w.val_step(images.to(dev()), labels.to(dev()))
         v2, _ = w.val_step(images.to(dev()), labels.to(dev()))
-    assert float(v1) == float(v2) and abs(float(v1) - float(clean)) <= 1e-2 * float(clean)
+    assert abs(float(v1) - float(v2)) < 1e-5 and abs(float(v1) - float(clean)) <= 1e-2 * float(clean)   # (atomic loss sum: last-bit jitter)
