@@ -73,12 +73,16 @@ class GemmTimer:
                     tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, gflop_per_launch=fl / max(1, len(self.records)) / 1e9)
 
 
-def cpu_baseline(batch=8, steps=2):
+def cpu_baseline(batch=8, steps=2, dropout=0.1):
     """The fp32 oracle port (oracle/reference_model.py) timed on the host cores: train step + torch AdamW."""
     from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
     from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch
     from oracle import reference_model as orc
-    cfg = nano224_config(dropout=0.0)
+    try:
+        torch.set_num_threads(len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    cfg = nano224_config(dropout=dropout)
     torch.manual_seed(0)
     model = VisionEncoderDecoder(cfg)                       # parameter container only: supplies reference-style init
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items() if k != 'decoder.lm_head.weight'}
@@ -101,7 +105,7 @@ def cpu_baseline(batch=8, steps=2):
         orc.generate_greedy({k: v.detach() for k, v in sd.items()}, cfg, images[:4], torch.full((4, 1), tok.bos_token_id), 8)
     dec = time.perf_counter() - t0
     return dict(value=batch / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle fp32 train step (fwd+bwd+AdamW), nano-224, batch {batch}, 1 warm-up + {steps} timed steps',
+                sample=f'oracle fp32 train step (fwd+bwd+AdamW), nano-224, dropout {dropout}, batch {batch}, 1 warm-up + {steps} timed steps',
                 greedy_captions_per_sec_8tok=4 / dec,
                 greedy_sample='4 captions x 8 new tokens, cache-free loop as the reference runs it (cost grows O(t^2))')
 
@@ -225,7 +229,7 @@ def main():
                                'avg_launch_us': round(gemm['avg_us'], 2), 'gflop_per_launch': round(gemm['gflop_per_launch'], 3),
                                'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(dropout=args.dropout)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
