@@ -52,6 +52,27 @@ struct GemmParams {
     float drop_scale;
 };
 
+// Tile order inside an XCD's contiguous chunk of the grid.  PMC (round 1, B = 256): with M fastest the GEMM family moved
+// 742 MB per launch against ~100 MB algorithmic (4.2 TB/s: bandwidth-bound) -- every 128-row activation tile was re-read
+// for each of the N/128 column tiles, tens of MB apart.  Now N is the fast index inside groups of up to GN column tiles
+// whose weight panels (GN x 128 x K bf16, <= ~3 MB) stay in the XCD's 4 MiB L2: an activation tile is fetched once per
+// group and reused GN times from L2; the weight group is re-read (from L2) for every row tile.
+constexpr int GN_MAX = 16;
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int swz, int& tile_m, int& tile_n) {
+    const int gn = p.tiles_n < GN_MAX ? p.tiles_n : GN_MAX;
+    const int per_group = p.tiles_m * gn;
+    int grp = swz / per_group;
+    const int ngroups = (p.tiles_n + gn - 1) / gn;
+    int rem = swz - grp * per_group, width = gn;
+    if (grp >= ngroups - 1) {                      // the last group may be narrower
+        grp = ngroups - 1;
+        rem = swz - grp * per_group;
+        width = p.tiles_n - grp * gn;
+    }
+    tile_m = rem / width;
+    tile_n = grp * gn + rem % width;
+}
+
 // One operand's staging registers: 4 x 16-byte chunks per thread per K-step.
 struct Stage {
     u32x4 v[4];
@@ -239,7 +260,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    int tile_m, tile_n;
+    tile_coords(p, swz, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x4 acc[4][4];
@@ -368,7 +390,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    int tile_m, tile_n;
+    tile_coords(p, swz, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x4 acc[4][4];
@@ -479,7 +502,8 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmParams p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = swz % p.tiles_m, tile_n = swz / p.tiles_m;
+    int tile_m, tile_n;
+    tile_coords(p, swz, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x4 acc[4][4];
