@@ -25,7 +25,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int R_ROW_BYTES = 128;                 // 64 bf16
 constexpr int CF_ROW_BYTES = 288;                // 128 bf16 + 32 B pad
-constexpr int OPERAND_BYTES = 64 * CF_ROW_BYTES; // 18432 >= 128 * 128 (R image 16384)
+constexpr int OPERAND_BYTES = 128 * 128;         // 16 KiB: R image [128][64] or Cf image [64][128], both unpadded
 constexpr int STAGE_BYTES = 2 * OPERAND_BYTES;   // A + B
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // double buffer: 73728
 
@@ -99,7 +99,12 @@ __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* __restrict__ 
     }
 }
 
-template <bool KMAJOR>
+// Cf image of the v1 kernel: [k-row][16 chunks of 16 B], unpadded, chunk ^= swz(k) << 1 (see the DMA kernel's comment):
+// conflict-free transposed reads for BOTH k orders (PMC round 1: the padded image cost 20 % LDS conflict cycles in dX).
+template <bool PK>
+__device__ __forceinline__ int cf_swz_v1(int kr) { return PK ? (kr & 7) : ((kr & 3) | (((kr >> 3) & 1) << 2)); }
+
+template <bool KMAJOR, bool PK = false>
 __device__ __forceinline__ void stage_store(const Stage& s, unsigned char* lds, int tid) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -110,7 +115,7 @@ __device__ __forceinline__ void stage_store(const Stage& s, unsigned char* lds, 
             off = r * R_ROW_BYTES + ((kc ^ (r & 7)) << 4);
         } else {
             int kr = c >> 4, rc = c & 15;
-            off = kr * CF_ROW_BYTES + (rc << 4);
+            off = kr * 256 + ((rc ^ (cf_swz_v1<PK>(kr) << 1)) << 4);
         }
         *reinterpret_cast<u32x4*>(lds + off) = s.v[u];
     }
@@ -132,9 +137,10 @@ __device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, in
         return __builtin_bit_cast(bf16x8, v);
     } else {
         const int q = i >> 2, p = i & 3;
-        const unsigned char* a0 = lds + (ks * 32 + (PERMUTE_K ? 4 : 8) * g + q) * CF_ROW_BYTES + (r0 + 4 * p) * 2;
-        s16x4 lo = lds_read_tr16(a0);
-        s16x4 hi = lds_read_tr16(a0 + (PERMUTE_K ? 16 : 4) * CF_ROW_BYTES);
+        const int kr0 = ks * 32 + (PERMUTE_K ? 4 : 8) * g + q, kr1 = kr0 + (PERMUTE_K ? 16 : 4);
+        const int ch = (r0 >> 3) + (p >> 1), half = (p & 1) * 8;
+        s16x4 lo = lds_read_tr16(lds + kr0 * 256 + ((ch ^ (cf_swz_v1<PERMUTE_K>(kr0) << 1)) << 4) + half);
+        s16x4 hi = lds_read_tr16(lds + kr1 * 256 + ((ch ^ (cf_swz_v1<PERMUTE_K>(kr1) << 1)) << 4) + half);
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     Stage sa, sb;
     stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
     stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
-    stage_store<A_KMAJOR>(sa, smem, tid);
-    stage_store<B_KMAJOR>(sb, smem + OPERAND_BYTES, tid);
+    stage_store<A_KMAJOR, PK>(sa, smem, tid);
+    stage_store<B_KMAJOR, PK>(sb, smem + OPERAND_BYTES, tid);
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
@@ -310,8 +316,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         }
         if (more) {
             unsigned char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
-            stage_store<A_KMAJOR>(sa, na, tid);
-            stage_store<B_KMAJOR>(sb, na + OPERAND_BYTES, tid);
+            stage_store<A_KMAJOR, PK>(sa, na, tid);
+            stage_store<B_KMAJOR, PK>(sb, na + OPERAND_BYTES, tid);
         }
         __syncthreads();
     }
