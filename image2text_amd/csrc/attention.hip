@@ -32,6 +32,15 @@ struct AttnPtr {
     int rs;    // row stride (elements)
 };
 
+// Packed variable-length batches: sequence b owns rows [cu[b], cu[b+1]) of a [total, width] tensor (batch stride unused).
+// cu_q / cu_k may be given independently (cross-attention: packed queries against fixed-length memories).
+// With cu_q the per-row statistics (lse, delta) are laid out [H][total_q].
+struct VarLen {
+    const int* cu_q;
+    const int* cu_k;
+    int total_q;
+};
+
 // stage rows [r0, r0+64) x 64 columns of one (b, h) slice into a P160 tile; rows >= nrows are zero-filled
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, int rs, int r0, int nrows, int tid) {
 #pragma unroll
@@ -86,18 +95,33 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // ================================================================================================== forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O,
-                                                       long o_bs, int o_rs, float* __restrict__ lse, int H, int Tq,
-                                                       int Tk, int causal, unsigned drop_key, unsigned drop_thr,
-                                                       float drop_scale) {
+                                                       long o_bs, int o_rs, float* __restrict__ lse, int H, int TqMax,
+                                                       int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
+                                                       float drop_scale, VarLen vl) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* kt_lds = smem;
     unsigned char* vt_lds = smem + TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
-    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
-    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
+    int Tq = TqMax, Tk = TkMax;
+    size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, ooff = (size_t)b * o_bs;
+    size_t stat_base = ((size_t)b * H + h) * TqMax;
+    if (vl.cu_q) {
+        const int s0 = vl.cu_q[b];
+        Tq = vl.cu_q[b + 1] - s0;
+        qoff = (size_t)s0 * Q.rs; ooff = (size_t)s0 * o_rs;
+        stat_base = (size_t)h * vl.total_q + s0;
+    }
+    if (vl.cu_k) {
+        const int s0 = vl.cu_k[b];
+        Tk = vl.cu_k[b + 1] - s0;
+        koff = (size_t)s0 * K.rs; voff = (size_t)s0 * V.rs;
+    }
+    if (qt * 64 >= Tq) return;                      // workgroup-uniform
+    const bf16_t* qb = Q.p + qoff + h * 64;
+    const bf16_t* kb = K.p + koff + h * 64;
+    const bf16_t* vb = V.p + voff + h * 64;
     const int q0 = qt * 64 + w * 16;
     const int qrow = q0 + li;                       // this lane's query row
     const int shift = Tk - Tq;                      // causal: key j visible iff j <= q + shift
@@ -113,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;                   // running max (log2 domain) and this lane's partial row sum
     const int qlim = causal ? (min(qrow, Tq - 1) + shift) : (Tk - 1);
-    const unsigned drow = (((unsigned)b * H + h) * Tq + min(qrow, Tq - 1)) * (unsigned)Tk;    // dropout index of (b, h, q, key 0)
+    const unsigned drow = (((unsigned)b * H + h) * TqMax + min(qrow, Tq - 1)) * (unsigned)TkMax;   // dropout index of (b, h, q, key 0)
 
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
@@ -165,13 +189,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
     l = quad_sum(l);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     if (qrow < Tq) {
-        bf16_t* op = O + (size_t)b * o_bs + (size_t)qrow * o_rs + h * 64;
+        bf16_t* op = O + ooff + (size_t)qrow * o_rs + h * 64;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
             *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = pk;
         }
-        if (g == 0 && lse) lse[((size_t)b * H + h) * Tq + qrow] = (m + log2f(l)) * LN2;
+        if (g == 0 && lse) lse[stat_base + qrow] = (m + log2f(l)) * LN2;
     }
 }
 
@@ -179,12 +203,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, long o_bs, int o_rs,
                                                          const bf16_t* __restrict__ dO, long do_bs, int do_rs,
-                                                         float* __restrict__ delta, int H, int Tq, int total) {
+                                                         float* __restrict__ delta, int H, int Tq, int total, int total_q) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (b, q, h) with h fastest -> adjacent 128-B segments
     if (idx >= total) return;
-    const int h = idx % H, q = (idx / H) % Tq, b = idx / (H * Tq);
-    const u32x4* po = reinterpret_cast<const u32x4*>(O + (size_t)b * o_bs + (size_t)q * o_rs + h * 64);
-    const u32x4* pd = reinterpret_cast<const u32x4*>(dO + (size_t)b * do_bs + (size_t)q * do_rs + h * 64);
+    const int h = idx % H;
+    size_t orow, drow_, slot;
+    if (total_q > 0) {                                 // packed rows: stats laid out [H][total_q]
+        const int row = idx / H;
+        orow = (size_t)row * o_rs; drow_ = (size_t)row * do_rs; slot = (size_t)h * total_q + row;
+    } else {
+        const int q = (idx / H) % Tq, b = idx / (H * Tq);
+        orow = (size_t)b * o_bs + (size_t)q * o_rs; drow_ = (size_t)b * do_bs + (size_t)q * do_rs; slot = ((size_t)b * H + h) * Tq + q;
+    }
+    const u32x4* po = reinterpret_cast<const u32x4*>(O + orow + h * 64);
+    const u32x4* pd = reinterpret_cast<const u32x4*>(dO + drow_ + h * 64);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -192,25 +224,40 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(d[e]) + bf16hi(a[e]) * bf16hi(d[e]);
     }
-    delta[((size_t)b * H + h) * Tq + q] = s;
+    delta[slot] = s;
 }
 
 // dQ: one workgroup per (q tile, h, b); loops over key tiles.  Scores transposed (lane owns a query column).
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int Tq,
-                                                          int Tk, int causal, unsigned drop_key, unsigned drop_thr,
-                                                          float drop_scale) {
+                                                          bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int TqMax,
+                                                          int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
+                                                          float drop_scale, VarLen vl) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* kt_lds = smem;
     unsigned char* vt_lds = smem + TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
-    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
-    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
-    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    int Tq = TqMax, Tk = TkMax;
+    size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, dooff = (size_t)b * dO.bs, dqoff = (size_t)b * dq_bs;
+    size_t stat_base = ((size_t)b * H + h) * TqMax;
+    if (vl.cu_q) {
+        const int s0 = vl.cu_q[b];
+        Tq = vl.cu_q[b + 1] - s0;
+        qoff = (size_t)s0 * Q.rs; dooff = (size_t)s0 * dO.rs; dqoff = (size_t)s0 * dq_rs;
+        stat_base = (size_t)h * vl.total_q + s0;
+    }
+    if (vl.cu_k) {
+        const int s0 = vl.cu_k[b];
+        Tk = vl.cu_k[b + 1] - s0;
+        koff = (size_t)s0 * K.rs; voff = (size_t)s0 * V.rs;
+    }
+    if (qt * 64 >= Tq) return;
+    const bf16_t* qb = Q.p + qoff + h * 64;
+    const bf16_t* kb = K.p + koff + h * 64;
+    const bf16_t* vb = V.p + voff + h * 64;
+    const bf16_t* dob = dO.p + dooff + h * 64;
     const int q0 = qt * 64 + w * 16;
     const int qrow = q0 + li;
     const int shift = Tk - Tq;
@@ -219,13 +266,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     const bf16x8 df0 = global_row_frag(dob, dO.rs, q0, Tq, 0, lane);
     const bf16x8 df1 = global_row_frag(dob, dO.rs, q0, Tq, 1, lane);
     const int qc = min(qrow, Tq - 1);
-    const float lse2 = lse[((size_t)b * H + h) * Tq + qc] * LOG2E;
-    const float dl = delta[((size_t)b * H + h) * Tq + qc];
+    const float lse2 = lse[stat_base + qc] * LOG2E;
+    const float dl = delta[stat_base + qc];
     int last_key = Tk - 1;
     if (causal) last_key = min(last_key, qt * 64 + 63 + shift);
     const int nkt = last_key / 64 + 1;
     const int qlim = causal ? (qc + shift) : (Tk - 1);
-    const unsigned drow = (((unsigned)b * H + h) * Tq + qc) * (unsigned)Tk;
+    const unsigned drow = (((unsigned)b * H + h) * TqMax + qc) * (unsigned)TkMax;
 
     f32x4 acc[4];
 #pragma unroll
@@ -262,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
         }
     }
     if (qrow < Tq) {
-        bf16_t* op = dQ + (size_t)b * dq_bs + (size_t)qrow * dq_rs + h * 64;
+        bf16_t* op = dQ + dqoff + (size_t)qrow * dq_rs + h * 64;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             u32x2 pk = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
@@ -277,9 +324,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dK, long dk_bs, int dk_rs,
-                                                           bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq,
-                                                           int Tk, int causal, unsigned drop_key, unsigned drop_thr,
-                                                           float drop_scale) {
+                                                           bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int TqMax,
+                                                           int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
+                                                           float drop_scale, VarLen vl) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * 64 * 4];
     unsigned char* q_lds = smem;
     unsigned char* do_lds = smem + TILE_BYTES;
@@ -288,10 +335,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const bf16_t* qb = Q.p + (size_t)b * Q.bs + h * 64;
-    const bf16_t* kb = K.p + (size_t)b * K.bs + h * 64;
-    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
-    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    int Tq = TqMax, Tk = TkMax;
+    size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, dooff = (size_t)b * dO.bs;
+    size_t dkoff = (size_t)b * dk_bs, dvoff = (size_t)b * dv_bs;
+    size_t stat_base = ((size_t)b * H + h) * TqMax;
+    if (vl.cu_q) {
+        const int s0 = vl.cu_q[b];
+        Tq = vl.cu_q[b + 1] - s0;
+        qoff = (size_t)s0 * Q.rs; dooff = (size_t)s0 * dO.rs;
+        stat_base = (size_t)h * vl.total_q + s0;
+    }
+    if (vl.cu_k) {
+        const int s0 = vl.cu_k[b];
+        Tk = vl.cu_k[b + 1] - s0;
+        koff = (size_t)s0 * K.rs; voff = (size_t)s0 * V.rs; dkoff = (size_t)s0 * dk_rs; dvoff = (size_t)s0 * dv_rs;
+    }
+    if (kt * 64 >= Tk) return;
+    const bf16_t* qb = Q.p + qoff + h * 64;
+    const bf16_t* kb = K.p + koff + h * 64;
+    const bf16_t* vb = V.p + voff + h * 64;
+    const bf16_t* dob = dO.p + dooff + h * 64;
     const int k0 = kt * 64 + w * 16;
     const int key = k0 + li;                         // this lane's key column
     const int shift = Tk - Tq;
@@ -313,8 +376,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
         stage_tile(do_lds, dob, dO.rs, qt * 64, Tq, tid);
         if (tid < 64) {
             int q = min(qt * 64 + tid, Tq - 1);
-            lse_lds[tid] = lse[((size_t)b * H + h) * Tq + q] * LOG2E;
-            dl_lds[tid] = delta[((size_t)b * H + h) * Tq + q];
+            lse_lds[tid] = lse[stat_base + q] * LOG2E;
+            dl_lds[tid] = delta[stat_base + q];
         }
         __syncthreads();
         f32x4 p[4], ds[4];
@@ -335,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                 float pv = vis ? exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
                 float pd = pv, dpr = dp[r];
                 if (drop_thr) {
-                    const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * Tq + min(q, Tq - 1)) * (unsigned)Tk + key, drop_thr);
+                    const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * TqMax + min(q, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
                     pd = keep ? pv * drop_scale : 0.f;     // dV sees the dropped probabilities
                     dpr = keep ? dpr * drop_scale : 0.f;
                 }
@@ -354,8 +417,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
         }
     }
     if (key < Tk) {
-        bf16_t* pk_ = dK + (size_t)b * dk_bs + (size_t)key * dk_rs + h * 64;
-        bf16_t* pv_ = dV + (size_t)b * dv_bs + (size_t)key * dv_rs + h * 64;
+        bf16_t* pk_ = dK + dkoff + (size_t)key * dk_rs + h * 64;
+        bf16_t* pv_ = dV + dvoff + (size_t)key * dv_rs + h * 64;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             u32x2 a = {pack_bf16x2(adk[dt][0], adk[dt][1]), pack_bf16x2(adk[dt][2], adk[dt][3])};
@@ -372,8 +435,10 @@ bool strides_ok(const void* p, long bs, int rs) { return p && ALIGNED16(p) && (b
 
 extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                                  const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse, int B,
-                                 int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale) {
+                                 int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                                 const int* cu_q, const int* cu_k, int total_q) {
     I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_fwd: dropout index overflows 32 bits");
+    I2T_REQUIRE(!cu_q || total_q > 0, "i2t_attention_fwd: packed queries need total_q");
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "i2t_attention_fwd: empty problem");
     I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
                     strides_ok(o, o_bs, o_rs),
@@ -383,7 +448,7 @@ extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_r
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     dim3 grid((Tq + 63) / 64, H, B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
-                       Tq, Tk, causal, drop_key, drop_thr, drop_scale);
+                       Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q});
     I2T_CHECK_LAUNCH("i2t_attention_fwd");
     return I2T_OK;
 }
@@ -392,8 +457,10 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                                  const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
                                  const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws, void* dq,
                                  long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs, void* dv, long dv_bs, int dv_rs,
-                                 int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale) {
+                                 int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                                 const int* cu_q, const int* cu_k, int total_q) {
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && lse && delta_ws, "i2t_attention_bwd: bad args");
+    I2T_REQUIRE(!cu_q || total_q > 0, "i2t_attention_bwd: packed queries need total_q");
     I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_bwd: dropout index overflows 32 bits");
     I2T_REQUIRE(strides_ok(q, q_bs, q_rs) && strides_ok(k, k_bs, k_rs) && strides_ok(v, v_bs, v_rs) &&
                     strides_ok(o, o_bs, o_rs) && strides_ok(d_o, do_bs, do_rs) && strides_ok(dq, dq_bs, dq_rs) &&
@@ -403,13 +470,14 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     hipStream_t s = (hipStream_t)stream;
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
-    const int total = B * H * Tq;
+    const int total = cu_q ? total_q * H : B * H * Tq;
+    const VarLen vl{cu_q, cu_k, total_q};
     hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)o, o_bs, o_rs,
-                       (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total);
+                       (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total, cu_q ? total_q : 0);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale);
+                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale);
+                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl);
     I2T_CHECK_LAUNCH("i2t_attention_bwd");
     return I2T_OK;
 }

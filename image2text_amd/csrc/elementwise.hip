@@ -8,10 +8,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------- embeddings
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ wte,
                                                         const float* __restrict__ wpe, float* __restrict__ x, int T,
-                                                        int d, int pos_offset, int vocab, int rows) {
+                                                        int d, int pos_offset, int vocab, int rows,
+                                                        const int* __restrict__ pos) {
     const int d4 = d >> 2;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int t = row % T;
+        const int t = pos ? pos[row] : row % T;
         long id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const f32x4* e = reinterpret_cast<const f32x4*>(wte + (size_t)id * d);
@@ -273,24 +274,36 @@ int grid_for(long work_items, int cap = 2048) {
 
 }  // namespace
 
+// dwpe[pos[row] + off][:] += dx[row][:] for packed rows (positions repeat across sequences -> atomics)
+__global__ __launch_bounds__(256) void embed_bwd_wpe_packed_kernel(const int* __restrict__ pos, const float* __restrict__ dx,
+                                                                   float* __restrict__ dwpe, int d, int pos_offset, int rows) {
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* g = dx + (size_t)row * d;
+        float* o = dwpe + (size_t)(pos[row] + pos_offset) * d;
+        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);
+    }
+}
+
 extern "C" int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte, const float* wpe, float* x, int B, int T,
-                             int d, int pos_offset, int vocab) {
+                             int d, int pos_offset, int vocab, const int* pos) {
     I2T_REQUIRE(ids && wte && wpe && x && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_fwd: bad args");
     const int rows = B * T;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, ids, wte, wpe, x,
-                       T, d, pos_offset, vocab, rows);
+                       T, d, pos_offset, vocab, rows, pos);
     I2T_CHECK_LAUNCH("i2t_embed_fwd");
     return I2T_OK;
 }
 
 extern "C" int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dwte, float* dwpe, int B, int T,
-                             int d, int pos_offset, int vocab) {
+                             int d, int pos_offset, int vocab, const int* pos) {
     I2T_REQUIRE(ids && dx && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_bwd: bad args");
     const int rows = B * T;
     hipStream_t s = (hipStream_t)stream;
     if (dwte)
         hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, ids, dx, dwte, d, vocab, rows);
-    if (dwpe) {
+    if (dwpe && pos) {
+        hipLaunchKernelGGL(embed_bwd_wpe_packed_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, pos, dx, dwpe, d, pos_offset, rows);
+    } else if (dwpe) {
         const long items = (long)T * (d >> 2);
         hipLaunchKernelGGL(sum_over_batch_kernel, dim3((items + 255) / 256), dim3(256), 0, s, dx, (long)T * d,
                            dwpe + (size_t)pos_offset * d, B, T, d, 1);

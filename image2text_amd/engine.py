@@ -195,20 +195,26 @@ class HotPath:
         return torch.empty(*shape, dtype=dtype, device=self.arena.device)
 
     # ------------------------------------------------------------------------------------------------ block
-    def block_fwd(self, pfx: str, x, B, T, d, H, ff, causal, mem_bf, S, save: bool, plan: Optional[DropPlan] = None, layer: int = 0):
+    def block_fwd(self, pfx: str, x, B, T, d, H, ff, causal, mem_bf, S, save: bool, plan: Optional[DropPlan] = None, layer: int = 0,
+                  vl=None):
+        """vl (packed variable-length rows): namespace(cu=int32[B+1] device, total=rows, ...) -- then x is [total, d], T is the
+        maximum length and attention walks each sequence's own rows."""
         a = self.arena
-        M = B * T
+        M = vl.total if vl is not None else B * T
+        cu = vl.cu if vl is not None else None
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))      # attention operand views
         dr = {k: (plan.get(layer, k) if plan is not None else None) for k in ('qkv', 'sdpa', 'resid', 'xattn', 'mlp')}
         sv = SimpleNamespace(x=x, cross=False, dr=dr)
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
-        qkv = self._empty(B, T, 3 * d, dtype=BF16)
-        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv.view(M, 3 * d), M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'),
-                 drop=dr['qkv'])
-        ao, lse = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
-        ops.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ao, lse, B, H, T, T, causal, drop=dr['sdpa'])
+        qkv = self._empty(M, 3 * d, dtype=BF16)
+        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv, M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'), drop=dr['qkv'])
+        ao, lse = self._empty(M, d, dtype=BF16), self._empty(H * M)
+        q3 = v3(qkv, 3 * d)
+        ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], v3(ao, d), lse, B, H, T, T, causal, drop=dr['sdpa'],
+                          cu_q=cu, cu_k=cu, total_q=M)
         x1 = self._empty(M, d)
-        ops.gemm(ao.view(M, d), a.W(f'{pfx}.attn.c_proj.weight'), x1, M, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=x,
+        ops.gemm(ao, a.W(f'{pfx}.attn.c_proj.weight'), x1, M, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=x,
                  drop=dr['resid'])
         sv.ln1, sv.m1, sv.r1, sv.qkv, sv.ao, sv.lse, sv.x1 = ln1, m1, r1, qkv, ao, lse, x1
         x2 = x1
@@ -218,14 +224,15 @@ class HotPath:
             win, bin_ = a.W(f'{pfx}.cross_attn.in_proj_weight'), a.P(f'{pfx}.cross_attn.in_proj_bias')
             ln3, m3, r3 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
             ops.layernorm_fwd(x1, a.P(f'{pfx}.ln_3.weight'), a.P(f'{pfx}.ln_3.bias'), ln3, m3, r3, M, d)
-            q = self._empty(B, T, d, dtype=BF16)
-            ops.gemm(ln3, win[:d], q.view(M, d), M, d, d, bias=bin_[:d])
+            q = self._empty(M, d, dtype=BF16)
+            ops.gemm(ln3, win[:d], q, M, d, d, bias=bin_[:d])
             kv = self._empty(B, S, 2 * d, dtype=BF16)
             ops.gemm(mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, 2 * d, d, bias=bin_[d:])
-            co, lse_c = self._empty(B, T, d, dtype=BF16), self._empty(B, H, T)
-            ops.attention_fwd(q, kv[..., :d], kv[..., d:], co, lse_c, B, H, T, S, False, drop=dr['xattn'])
+            co, lse_c = self._empty(M, d, dtype=BF16), self._empty(H * M)
+            ops.attention_fwd(v3(q, d), kv[..., :d], kv[..., d:], v3(co, d), lse_c, B, H, T, S, False, drop=dr['xattn'],
+                              cu_q=cu, total_q=M)
             x2 = self._empty(M, d)
-            ops.gemm(co.view(M, d), a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
+            ops.gemm(co, a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
                      bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1)
             sv.cross, sv.ln3, sv.m3, sv.r3, sv.q, sv.kv, sv.co, sv.lse_c, sv.mem = True, ln3, m3, r3, q, kv, co, lse_c, mem_bf
         ln2, m2, r2 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
@@ -250,12 +257,14 @@ class HotPath:
             ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
         return dx_out
 
-    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool):
+    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None):
         """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output, already normalised.  On return dx (and
         dxb when emit_last_bf16) hold the gradient w.r.t. the block input."""
         a = self.arena
-        M = B * T
-        ws = self._empty(B, H, T)
+        M = vl.total if vl is not None else B * T
+        cu = vl.cu if vl is not None else None
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
+        ws = self._empty(H * M)
         dr = sv.dr
         # ---- MLP: x3 = x2 + drop(c_proj(gelu(c_fc(ln_2 x2))))
         if dr['mlp'] is not None:
@@ -272,13 +281,13 @@ class HotPath:
         if sv.cross:
             win = a.W(f'{pfx}.cross_attn.in_proj_weight')
             gin, gbin = a.G(f'{pfx}.cross_attn.in_proj_weight'), a.G(f'{pfx}.cross_attn.in_proj_bias')
-            dco = self._empty(B, T, d, dtype=BF16)
-            self._linear_bwd(dxb, M, d, d, sv.co.view(M, d), f'{pfx}.cross_attn.out_proj.weight', f'{pfx}.cross_attn.out_proj.bias',
-                             dx_out=dco.view(M, d))
-            dq, dkv = self._empty(B, T, d, dtype=BF16), self._empty(B, S, 2 * d, dtype=BF16)
-            ops.attention_bwd(sv.q, sv.kv[..., :d], sv.kv[..., d:], sv.co, dco, sv.lse_c, ws, dq, dkv[..., :d], dkv[..., d:],
-                              B, H, T, S, False, drop=dr['xattn'])
-            dqf, dkvf = dq.view(M, d), dkv.view(B * S, 2 * d)
+            dco = self._empty(M, d, dtype=BF16)
+            self._linear_bwd(dxb, M, d, d, sv.co, f'{pfx}.cross_attn.out_proj.weight', f'{pfx}.cross_attn.out_proj.bias',
+                             dx_out=dco)
+            dq, dkv = self._empty(M, d, dtype=BF16), self._empty(B, S, 2 * d, dtype=BF16)
+            ops.attention_bwd(v3(sv.q, d), sv.kv[..., :d], sv.kv[..., d:], v3(sv.co, d), v3(dco, d), sv.lse_c, ws, v3(dq, d),
+                              dkv[..., :d], dkv[..., d:], B, H, T, S, False, drop=dr['xattn'], cu_q=cu, total_q=M)
+            dqf, dkvf = dq, dkv.view(B * S, 2 * d)
             ops.colsum(dqf, gbin[:d], M, d, accumulate=True)
             ops.gemm(dqf, sv.ln3, gin[:d], d, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
             ops.gemm(dqf, win[:d], dln, M, d, d, b_kmajor=True)
@@ -290,25 +299,26 @@ class HotPath:
         # ---- self attention: x1 = x + drop(c_proj(attn(mult * c_attn(ln_1 x))))
         if dr['resid'] is not None:
             ops.dropout_apply(dxb, M, d, dr['resid'])
-        dao = self._empty(B, T, d, dtype=BF16)
-        self._linear_bwd(dxb, M, d, d, sv.ao.view(M, d), f'{pfx}.attn.c_proj.weight',
-                         f'{pfx}.attn.c_proj.bias' if a.G(f'{pfx}.attn.c_proj.bias') is not None else None, dx_out=dao.view(M, d))
-        dqkv = self._empty(B, T, 3 * d, dtype=BF16)
-        q, k, v = sv.qkv[..., :d], sv.qkv[..., d:2 * d], sv.qkv[..., 2 * d:]
-        ops.attention_bwd(q, k, v, sv.ao, dao, sv.lse, ws, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, T, T, causal,
-                          drop=dr['sdpa'])
+        dao = self._empty(M, d, dtype=BF16)
+        self._linear_bwd(dxb, M, d, d, sv.ao, f'{pfx}.attn.c_proj.weight',
+                         f'{pfx}.attn.c_proj.bias' if a.G(f'{pfx}.attn.c_proj.bias') is not None else None, dx_out=dao)
+        dqkv = self._empty(M, 3 * d, dtype=BF16)
+        q3, g3 = v3(sv.qkv, 3 * d), v3(dqkv, 3 * d)
+        ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], v3(sv.ao, d), v3(dao, d), sv.lse, ws, g3[..., :d],
+                          g3[..., d:2 * d], g3[..., 2 * d:], B, H, T, T, causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M)
         if dr['qkv'] is not None:
             ops.dropout_apply(dqkv, M, 3 * d, dr['qkv'])       # gradient w.r.t. the un-multiplied q/k/v
-        self._linear_bwd(dqkv.view(M, 3 * d), M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
+        self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
                          f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
         ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
                           a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None)
 
-    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem):
-        dxb = self._empty(B * T, d, dtype=BF16)
+    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None):
+        dxb = self._empty(dx.shape[0], d, dtype=BF16)
         for l in reversed(range(len(saves))):
             ops.grad_normalize(dx, self._ws[:1], dxb)          # normalize_gradients at the block output
-            self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False)
+            self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
+                           vl=vl)
 
     # ------------------------------------------------------------------------------------------------ encoder
     def encode(self, images: torch.Tensor, save: bool):
@@ -426,19 +436,23 @@ class HotPath:
         ops.cast_f32_bf16(enc_out.contiguous(), mem)
         return mem
 
-    def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0):
-        """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [B*T,d], hidden bf16, ctx)."""
+    def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0, vl=None):
+        """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [M,d], hidden bf16, ctx), M = B*T, or
+        M = vl.total for packed variable-length rows (vl = namespace(cu, pos, total): ids is then the packed 1-D id list)."""
         a, dc = self.arena, self.dec
         if T + pos_offset > dc.block:
             raise AssertionError(f'Cannot forward sequence of length {T + pos_offset}, block size is only {dc.block}')
-        d, M = dc.d, B * T
+        d, M = dc.d, (vl.total if vl is not None else B * T)
         x = self._empty(M, d)
         wpe = a.P(f'{self.dp}transformer.wpe.weight')
         plan = self.dec_drop if save else None
         emb_drop = plan.get(0, 'emb') if plan is not None else None
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()
-            ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
+            if vl is not None:
+                ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, M, 1, d, pos_offset, dc.V, pos=vl.pos)
+            else:
+                ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
             if emb_drop is not None:
                 ops.dropout_apply(x, M, d, emb_drop)
         else:
@@ -447,13 +461,13 @@ class HotPath:
         saves, cur = [], x
         for l in range(dc.L):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
-            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l)
+            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l, vl)
             saves.append(sv)
         hid, mf, rf = self._empty(M, d), self._empty(M), self._empty(M)
         ops.layernorm_fwd(cur, a.P(f'{self.dp}transformer.ln_f.weight'), a.P(f'{self.dp}transformer.ln_f.bias'), hid, mf, rf, M, d)
         hb = self._empty(M, d, dtype=BF16)
         ops.cast_f32_bf16(hid, hb)
-        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset,
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset, vl=vl, M=M,
                               emb_drop=emb_drop if ids is not None else None) if save else None
         return hid, hb, ctx
 
@@ -462,19 +476,22 @@ class HotPath:
         ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), out, M, self.dec.V, self.dec.d)
         return out
 
-    def logits_bf16(self, hb: torch.Tensor, M: int):
-        """bf16 logits [M, Vp] in a cached buffer whose pad columns are zero and are never written."""
-        buf = self._logits_cache.get(M)
+    def logits_bf16(self, hb: torch.Tensor, M: int, capacity: Optional[int] = None):
+        """bf16 logits [M, Vp] in a cached buffer (of `capacity` >= M rows) whose pad columns are zero and never written."""
+        cap = capacity or M
+        buf = self._logits_cache.get(cap)
         if buf is None:
-            buf = torch.zeros(M, self.dec.Vp, dtype=BF16, device=self.arena.device)
-            self._logits_cache[M] = buf
+            self._logits_cache.clear()
+            buf = torch.zeros(cap, self.dec.Vp, dtype=BF16, device=self.arena.device)
+            self._logits_cache[cap] = buf
+        buf = buf[:M]
         ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), buf, M, self.dec.V, self.dec.d)
         return buf
 
     def decode_backward(self, ctx, dlogits_bf: Optional[torch.Tensor], dhid: Optional[torch.Tensor], dmem):
         """dlogits_bf: bf16 [M, Vp] (pads zero) or None; dhid: fp32 [M, d] or None; dmem: fp32 [B*S, d] accumulator."""
         a, dc = self.arena, self.dec
-        B, T, d, M = ctx.B, ctx.T, dc.d, ctx.B * ctx.T
+        B, T, d, M = ctx.B, ctx.T, dc.d, ctx.M
         wte = f'{self.dp}transformer.wte.weight'
         dh = torch.zeros(M, d, dtype=F32, device=a.device) if dlogits_bf is None else self._empty(M, d)
         if dlogits_bf is not None:
@@ -485,11 +502,14 @@ class HotPath:
         dx = self._empty(M, d)
         ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
-        self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem)
+        self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl)
         if ctx.ids is not None:
             if ctx.emb_drop is not None:
                 ops.dropout_apply(dx, M, d, ctx.emb_drop)
-            ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), B, T, d, ctx.pos_offset, dc.V)
+            if ctx.vl is not None:
+                ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
+            else:
+                ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), B, T, d, ctx.pos_offset, dc.V)
             return None
         ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)
         return dx      # gradient w.r.t. the embeddings fed in

@@ -93,38 +93,40 @@ def layernorm_nd_bwd(dy, dy_batch_stride, x, add, gamma, stats, dx, dgamma, dbet
 
 
 def _bs_rs(t: torch.Tensor):
-    """(batch stride, row stride) in elements of a [B, T, *] view whose last dim is contiguous."""
+    """(batch stride, row stride) in elements of a [B, T, *] view whose last dim is contiguous; a packed [rows, *] view
+    has no batch stride (0)."""
     assert t.stride(-1) == 1
-    return t.stride(0), t.stride(1)
+    return (0, t.stride(0)) if t.dim() == 2 else (t.stride(0), t.stride(1))
 
 
-def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=None):
-    """q,k,v,o: bf16 [B, T, >=64H] views (last dim contiguous; heads at 64-column steps)."""
+def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0):
+    """q,k,v,o: bf16 [B, T, >=64H] views (last dim contiguous; heads at 64-column steps), or packed [rows, >=64H] views
+    together with cu_q / cu_k (device int32 [B+1])."""
     _need_cuda(q, k, v, o)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o)
     _l.check(_lib().i2t_attention_fwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(lse), B, H, Tq,
-                                      Tk, int(causal), *_drop(drop)[1:]), 'i2t_attention_fwd')
+                                      Tk, int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q)), 'i2t_attention_fwd')
     return o
 
 
-def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None):
+def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0):
     _need_cuda(q, k, v, o, do, dq, dk, dv)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
     dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
     _l.check(_lib().i2t_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
                                       _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
-                                      int(causal), *_drop(drop)[1:]), 'i2t_attention_bwd')
+                                      int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q)), 'i2t_attention_bwd')
 
 
-def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab):
+def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab, pos=None):
     _need_cuda(ids, wte, x)
-    _l.check(_lib().i2t_embed_fwd(_stream(), _p(ids), _p(wte), _p(wpe), _p(x), B, T, d, pos_offset, vocab), 'i2t_embed_fwd')
+    _l.check(_lib().i2t_embed_fwd(_stream(), _p(ids), _p(wte), _p(wpe), _p(x), B, T, d, pos_offset, vocab, _p(pos)), 'i2t_embed_fwd')
     return x
 
 
-def embed_bwd(ids, dx, dwte, dwpe, B, T, d, pos_offset, vocab):
+def embed_bwd(ids, dx, dwte, dwpe, B, T, d, pos_offset, vocab, pos=None):
     _need_cuda(ids, dx)
-    _l.check(_lib().i2t_embed_bwd(_stream(), _p(ids), _p(dx), _p(dwte), _p(dwpe), B, T, d, pos_offset, vocab), 'i2t_embed_bwd')
+    _l.check(_lib().i2t_embed_bwd(_stream(), _p(ids), _p(dx), _p(dwte), _p(dwpe), B, T, d, pos_offset, vocab, _p(pos)), 'i2t_embed_bwd')
 
 
 def ce_fwd(logits, ld, labels, w, inv_temp, ignore_index, lse, loss, M, V):

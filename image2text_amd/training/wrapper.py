@@ -30,26 +30,32 @@ class _LMLossFunction(torch.autograd.Function):
         mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
         off = ncls if cfg.use_soft_prompting else 0
         T = min(L, eng.dec.block - off)
-        _, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids[:, :T], pos_offset=off)
-        M = B * T
-        logits = eng.logits_bf16(hb, M)
-        lab = labels[:, :T].contiguous().view(M)
-        w = weights[:, :T].contiguous().view(M)
+        vl = wrapper._pack_rows(labels[:, :T], B, T) if wrapper.pack_rows else None
+        if vl is not None:      # rows past each caption's last label are dead (causal + zero loss weight): not computed
+            M = vl.total
+            _, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids[:, :T][vl.mask], pos_offset=off, vl=vl)
+            lab, w = labels[:, :T][vl.mask].contiguous(), weights[:, :T][vl.mask].contiguous()
+        else:
+            M = B * T
+            _, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids[:, :T], pos_offset=off)
+            lab = labels[:, :T].contiguous().view(M)
+            w = weights[:, :T].contiguous().view(M)
+        logits = eng.logits_bf16(hb, M, capacity=B * T)
         lse = torch.empty(M, dtype=F32, device=a.device)
         loss = torch.zeros(1, dtype=F32, device=a.device)
         inv_t = 1.0 / wrapper.temperature
         ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, eng.dec.V)
-        ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, T, ncls) if save else None
+        ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls) if save else None
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, T, ncls = ctx.pack
+        wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls = ctx.pack
         eng: HotPath = wrapper.model._engine
         a = eng.arena
         a.begin_backward()
         gscale = g.reshape(1).to(F32).contiguous()              # stays on the device: no host sync
-        ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, B * T, eng.dec.V)
+        ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, M, eng.dec.V)
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
         eng.decode_backward(dctx, logits, None, dmem)
         eng.notify_grads_ready('decoder')
@@ -81,6 +87,26 @@ class ModelTrainerWrapper(nn.Module):
         self.temperature = tc.training_temperature
         self.weight_fn = tc.weight_fn
         self.eos_token_weight = tc.eos_token_weight
+        self.pack_rows = True      # skip the dead caption rows past the last label (result-preserving; see _pack_rows)
+
+    def _pack_rows(self, labels, B: int, T: int):
+        """Row packing for the decoder: with the causal mask a text row only sees earlier rows, and rows past a caption's last
+        non-ignored label carry zero loss weight, so nothing they compute can reach the loss or any gradient.  Returns the
+        packed-row description (cumulative lengths, positions, row mask) or None when every row is live.  Needs the lengths on
+        the host: one small device->host copy at the very start of the step."""
+        valid = labels != self.ignore_index
+        idx = torch.arange(1, T + 1, device=labels.device)
+        lens = (valid * idx).amax(dim=1)                       # last live position + 1 (0: no label at all)
+        lens_host = lens.tolist()
+        total = int(sum(lens_host))
+        if total == B * T or total == 0:
+            return None
+        cu = torch.zeros(B + 1, dtype=torch.int32, device=labels.device)
+        cu[1:] = torch.cumsum(lens, 0)
+        mask = idx[None, :] <= lens[:, None]
+        pos = (idx - 1).to(torch.int32).expand(B, T)[mask].contiguous()
+        from types import SimpleNamespace
+        return SimpleNamespace(cu=cu, pos=pos, total=total, mask=mask)
 
     def copy_momentum_params(self):
         return

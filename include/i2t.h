@@ -100,27 +100,34 @@ int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch_stride, co
  *   Packed c_attn output: q=base, k=base+d, v=base+2d, row stride 3d.  lse f32 [B][H][Tq] (natural log).
  *   causal: key j visible to query i iff j <= i + (Tk - Tq)   (Tk == Tq in training; Tk > Tq with a KV cache)
  *   bwd: dq/dk/dv written (not accumulated), same strides convention as their forward operands.
+ *   packed variable-length batches (training skips the caption rows past the last label: they are dead under the causal
+ *   mask and carry zero loss weight): cu_q / cu_k (device int[B+1], nullable) give sequence b the rows [cu[b], cu[b+1]) of
+ *   a packed [total, width] tensor (batch strides then unused; Tq/Tk = the maxima); with cu_q, lse/delta are [H][total_q].
  *   dropout on the attention probabilities (SDPA dropout_p, layers.py:465; nn.MultiheadAttention dropout): drop_thr = p*2^32
  *   (0 = off), probability (b,h,q,key) kept iff hash(drop_key, ((b*H+h)*Tq+q)*Tk+key) >= drop_thr, scaled by drop_scale.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                       const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
-                      int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale);
+                      int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                      const int* cu_q, const int* cu_k, int total_q);
 int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                       const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
                       const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,
                       void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
                       void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal,
-                      unsigned drop_key, unsigned drop_thr, float drop_scale);
+                      unsigned drop_key, unsigned drop_thr, float drop_scale,
+                      const int* cu_q, const int* cu_k, int total_q);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token + position embedding (decoder.py:231-243): x[b][t] = wte[ids[b][t]] + wpe[t + pos_offset]  (f32)
  *   bwd: dwte[ids] += dx (atomics), dwpe[t+pos_offset] += sum_b dx[b][t]
+ *   pos (device int[B*T], nullable): explicit position of every row for packed variable-length batches (then B*T is just
+ *   the row count and the wpe gradient is accumulated with atomics).
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte, const float* wpe, float* x,
-                  int B, int T, int d, int pos_offset, int vocab);
+                  int B, int T, int d, int pos_offset, int vocab, const int* pos);
 int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dwte, float* dwpe,
-                  int B, int T, int d, int pos_offset, int vocab);
+                  int B, int T, int d, int pos_offset, int vocab, const int* pos);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Weighted cross-entropy over bf16 logits (wrapper.py:147-151: F.cross_entropy(logits/T, labels, ignore_index,

@@ -579,3 +579,62 @@ def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
     sc_ = float(do.float().abs().max())
     for name, got, ref in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
         check(f'attn dropout {name}', got.reshape(B, -1, H, 64), ref.permute(0, 2, 1, 3), 3e-2 * sc_, 1 / 32)
+
+
+def test_attention_packed_varlen(ops):
+    """Packed variable-length self-attention (causal) and packed-query cross-attention == per-sequence dense calls."""
+    H, d = 2, 128
+    lens = [5, 64, 0, 37, 16]
+    B, total, Tmax = len(lens), sum(lens), 64
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    qkv = rnd(total, 3 * d, dtype=BF16, seed=180)
+    do = rnd(total, d, dtype=BF16, seed=181)
+    o, lse = torch.zeros(total, d, dtype=BF16, device=dev()), torch.zeros(H * total, device=dev())
+    ops.attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, B, H, Tmax, Tmax, True, cu_q=cu, cu_k=cu, total_q=total)
+    dqkv = torch.zeros(total, 3 * d, dtype=BF16, device=dev())
+    ops.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, torch.empty(H * total, device=dev()),
+                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, Tmax, Tmax, True, cu_q=cu, cu_k=cu, total_q=total)
+    mem = rnd(B, 24, 2 * d, dtype=BF16, seed=182)
+    oc, lsec = torch.zeros(total, d, dtype=BF16, device=dev()), torch.zeros(H * total, device=dev())
+    ops.attention_fwd(qkv[:, :d], mem[..., :d], mem[..., d:], oc, lsec, B, H, Tmax, 24, False, cu_q=cu, total_q=total)
+    dqc, dmem = torch.zeros(total, d, dtype=BF16, device=dev()), torch.zeros(B, 24, 2 * d, dtype=BF16, device=dev())
+    ops.attention_bwd(qkv[:, :d], mem[..., :d], mem[..., d:], oc, do, lsec, torch.empty(H * total, device=dev()), dqc,
+                      dmem[..., :d], dmem[..., d:], B, H, Tmax, 24, False, cu_q=cu, total_q=total)
+    for b, n in enumerate(lens):
+        s0 = int(cu[b])
+        if n == 0:
+            assert float(dmem[b].float().abs().max()) == 0.0
+            continue
+        seg = qkv[s0:s0 + n].unsqueeze(0).contiguous()
+        o1, l1 = torch.empty(1, n, d, dtype=BF16, device=dev()), torch.empty(1, H, n, device=dev())
+        ops.attention_fwd(seg[..., :d], seg[..., d:2 * d], seg[..., 2 * d:], o1, l1, 1, H, n, n, True)
+        assert torch.equal(o1[0], o[s0:s0 + n]), f'self fwd seq {b}'
+        check(f'lse seq {b}', lse.view(H, total)[:, s0:s0 + n], l1[0], 1e-6, 1e-6)
+        g1 = torch.zeros(1, n, 3 * d, dtype=BF16, device=dev())
+        dseg = do[s0:s0 + n].unsqueeze(0).contiguous()
+        ops.attention_bwd(seg[..., :d], seg[..., d:2 * d], seg[..., 2 * d:], o1, dseg, l1, torch.empty(1, H, n, device=dev()),
+                          g1[..., :d], g1[..., d:2 * d], g1[..., 2 * d:], 1, H, n, n, True)
+        assert torch.equal(g1[0], dqkv[s0:s0 + n]), f'self bwd seq {b}'
+        qd = seg[..., :d].contiguous()
+        oc1, lc1 = torch.empty(1, n, d, dtype=BF16, device=dev()), torch.empty(1, H, n, device=dev())
+        ops.attention_fwd(qd, mem[b:b + 1, :, :d], mem[b:b + 1, :, d:], oc1, lc1, 1, H, n, 24, False)
+        assert torch.equal(oc1[0], oc[s0:s0 + n]), f'cross fwd seq {b}'
+        dq1, dm1 = torch.zeros(1, n, d, dtype=BF16, device=dev()), torch.zeros(1, 24, 2 * d, dtype=BF16, device=dev())
+        ops.attention_bwd(qd, mem[b:b + 1, :, :d], mem[b:b + 1, :, d:], oc1, dseg, lc1, torch.empty(1, H, n, device=dev()), dq1,
+                          dm1[..., :d], dm1[..., d:], 1, H, n, 24, False)
+        assert torch.equal(dq1[0], dqc[s0:s0 + n]) and torch.equal(dm1[0], dmem[b]), f'cross bwd seq {b}'
+
+
+def test_embed_packed_positions(ops):
+    rows, d, V, off = 37, 128, 384, 8
+    ids = torch.randint(0, V, (rows,), device=dev())
+    pos = torch.randint(0, 16, (rows,), dtype=torch.int32, device=dev())
+    wte, wpe = rnd(V, d, seed=190), rnd(48, d, seed=191)
+    x = torch.empty(rows, d, device=dev())
+    ops.embed_fwd(ids, wte, wpe, x, rows, 1, d, off, V, pos=pos)
+    check('packed embed fwd', x, wte[ids] + wpe[pos.long() + off], 0, 0)
+    dx = rnd(rows, d, seed=192)
+    dwte, dwpe = torch.zeros(V, d, device=dev()), torch.zeros(48, d, device=dev())
+    ops.embed_bwd(ids, dx, dwte, dwpe, rows, 1, d, off, V, pos=pos)
+    check('packed dwte', dwte, torch.zeros(V, d, device=dev()).index_add_(0, ids, dx), 1e-5, 1e-5)
+    check('packed dwpe', dwpe, torch.zeros(48, d, device=dev()).index_add_(0, pos.long() + off, dx), 1e-5, 1e-5)

@@ -370,6 +370,7 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
     cfg = tiny_config(dropout=0.1)
     tok = fake_tokenizer(cfg.decoder_config.vocab_size)
     w = _wrapper(cfg)
+    w.pack_rows = False          # the host-side mask replica indexes rows densely (b, t); packing only renumbers the draws
     det_init_(w.model, seed=0)
     sd = {k: v.detach().cpu().clone() for k, v in w.model.state_dict().items()}
     w.train()
@@ -404,3 +405,26 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
         v1, _ = w.val_step(images.to(dev()), labels.to(dev()))
         v2, _ = w.val_step(images.to(dev()), labels.to(dev()))
     assert abs(float(v1) - float(v2)) < 1e-5 and abs(float(v1) - float(clean)) <= 1e-2 * float(clean)   # (atomic loss sum: last-bit jitter)
+
+
+def test_row_packing_is_result_preserving():
+    """Skipping the caption rows past the last label (packed variable-length decoder pass) must not change the loss or any
+    gradient: ragged captions, including one with no label at all and one that fills the window."""
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    images, labels = synthetic_batch(6, 32, 16, V, seed=21)
+    labels[1, :] = -100                                   # nothing to predict
+    labels[2, :] = torch.randint(0, V - 1, (16,))         # full window, no EOS
+    labels[3, 5] = -100                                   # a hole inside a caption: rows before the LAST label stay live
+    res = {}
+    for pack in (True, False):
+        w = _wrapper(cfg)
+        det_init_(w.model, seed=0)
+        w.pack_rows = pack
+        w.train()
+        loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+        loss.backward()
+        res[pack] = (float(loss.detach()), {n: p.grad.detach().float().cpu().numpy().copy() for n, p in w.model.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) <= 2e-4 * abs(res[False][0])
+    for n, g in res[False][1].items():
+        grad_close(f'pack.{n}', torch.from_numpy(res[True][1][n]), g, rel=2e-2, cos=0.9995)
