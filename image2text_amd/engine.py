@@ -412,6 +412,10 @@ class HotPath:
                          f'{self.ep}projector.bias' if a.G(f'{self.ep}projector.bias') is not None else None, dx_out=dflat)
         dy = dflat.view(B, self.conv[-1][2], ctx.Hh, ctx.Ww)
         dy_layout = ops.LAYOUT_NCHW_BF16
+        if self.conv_mfma and self.conv[-1][2] % 8 == 0:       # one coalesced transpose beats two 2-byte-scatter stagings
+            dyt = self._empty(B, ctx.Hh, ctx.Ww, self.conv[-1][2], dtype=BF16)
+            ops.nchw_to_nhwc(dy, dyt, B, self.conv[-1][2], ctx.Hh, ctx.Ww)
+            dy, dy_layout = dyt, ops.LAYOUT_NHWC_BF16
         for i in reversed(range(len(self.conv))):
             nm, cin, cout = self.conv[i]
             xin = ctx.images if i == 0 else ctx.acts[i - 1]

@@ -32,6 +32,7 @@ SIGNATURES = {
     'i2t_conv6_fwd': [P, P, I, I, P, P, P, I, P, I, I, I, I, I],
     'i2t_conv6_bwd_data': [P, P, I, P, P, P, P, I, I, I, I, I],
     'i2t_conv6_bwd_weight': [P, P, I, P, I, I, P, P, P, I, I, I, I, I],
+    'i2t_nchw_to_nhwc_bf16': [P, P, P, I, I, I, I],
     'i2t_cast_f32_bf16': [P, P, P, L],
     'i2t_dropout_apply': [P, P, I, L, I, I, U, U, F],
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],

@@ -197,6 +197,12 @@ def dropout_apply(x, rows, cols, drop):
     return x
 
 
+def nchw_to_nhwc(src, dst, B, C, H, W):
+    _need_cuda(src, dst)
+    _l.check(_lib().i2t_nchw_to_nhwc_bf16(_stream(), _p(src), _p(dst), B, C, H, W), 'i2t_nchw_to_nhwc_bf16')
+    return dst
+
+
 def cast_f32_bf16(src, dst, n=None):
     _need_cuda(src, dst)
     _l.check(_lib().i2t_cast_f32_bf16(_stream(), _p(src), _p(dst), src.numel() if n is None else n), 'i2t_cast_f32_bf16')

@@ -175,6 +175,8 @@ int i2t_conv6_bwd_data(void* stream, const void* dy, int dy_layout, const float*
                        void* w_ws, int B, int Cin, int Cout, int H, int W);
 int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout, const void* x, int x_layout, int in_gelu,
                          float* dw, float* db, float* scratch, int B, int Cin, int Cout, int H, int W);
+/* dst[b][y][x][c] = src[b][c][y][x] (bf16, C <= 32): the flat-patch gradient of the last conv layer -> channels-last */
+int i2t_nchw_to_nhwc_bf16(void* stream, const void* src, void* dst, int B, int C, int H, int W);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Elementwise / arena utilities

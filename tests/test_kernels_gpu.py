@@ -638,3 +638,10 @@ def test_embed_packed_positions(ops):
     ops.embed_bwd(ids, dx, dwte, dwpe, rows, 1, d, off, V, pos=pos)
     check('packed dwte', dwte, torch.zeros(V, d, device=dev()).index_add_(0, ids, dx), 1e-5, 1e-5)
     check('packed dwpe', dwpe, torch.zeros(48, d, device=dev()).index_add_(0, pos.long() + off, dx), 1e-5, 1e-5)
+
+
+def test_nchw_to_nhwc(ops):
+    x = rnd(2, 32, 20, 70, dtype=BF16, seed=200)
+    y = torch.empty(2, 20, 70, 32, dtype=BF16, device=dev())
+    ops.nchw_to_nhwc(x, y, 2, 32, 20, 70)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
