@@ -57,7 +57,8 @@ class GemmTimer:
             e0.record(torch.cuda.current_stream())
             r = self.orig(a, b, out, M, N, K, **kw)
             e1.record(torch.cuda.current_stream())
-            self.records.append((e0, e1, 2.0 * M * N * K))
+            c_bytes = 4 if out.dtype == torch.float32 else 2
+            self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + c_bytes * M * N))
             return r
         self.ops.gemm = timed
         return self
@@ -67,10 +68,12 @@ class GemmTimer:
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        by = sum(r[3] for r in self.records)
         return dict(launches=len(self.records), total_ms=ms, avg_us=1e3 * ms / max(1, len(self.records)),
-                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, gflop_per_launch=fl / max(1, len(self.records)) / 1e9)
+                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, gflop_per_launch=fl / max(1, len(self.records)) / 1e9,
+                    bytes_per_launch=by / max(1, len(self.records)))
 
 
 def cpu_baseline(batch=8, steps=2, dropout=0.1):
@@ -219,13 +222,20 @@ def main():
             'greedy_config': {'captions_per_batch': args.decode_batch, 'concurrent_batches_per_gpu': args.decode_streams,
                               'new_tokens': 64, 'ngrams': [2, 3, 4, 5], 'includes': 'encoder forward + KV-cache decode (hipGraph replay)'},
             'final_loss': round(final_loss, 4),
-            'step_tflops': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
-            'step_frac_of_mfma_peak': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
+            # nominal = SURVEY 8(d) required-output count (98 GFLOP/image); the step executes less: padded caption rows are skipped
+            'step_nominal_tflops': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
         }
+        traffic = None
+        try:      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same batch only
+            with open(os.path.join(ROOT, 'profiles', f'pmc_traffic_b{args.batch}.json')) as fh:
+                traffic = json.load(fh)['gemm_bf16_kernel']['hbm_bytes_per_launch']
+        except Exception:
+            pass
         if gemm is not None:
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all layouts)', 'achieved': round(gemm['tflops'], 1),
                                'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gemm['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4),
-                               'traffic': None, 'launches_per_step': gemm['launches'] // 2,
+                               'traffic': traffic, 'traffic_unit': 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)',
+                               'algorithmic_bytes_per_launch': round(gemm['bytes_per_launch']), 'launches_per_step': gemm['launches'] // 2,
                                'avg_launch_us': round(gemm['avg_us'], 2), 'gflop_per_launch': round(gemm['gflop_per_launch'], 3),
                                'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
         if world == 1 and not args.no_cpu_baseline:

@@ -427,4 +427,4 @@ def test_row_packing_is_result_preserving():
         res[pack] = (float(loss.detach()), {n: p.grad.detach().float().cpu().numpy().copy() for n, p in w.model.named_parameters()})
     assert abs(res[True][0] - res[False][0]) <= 2e-4 * abs(res[False][0])
     for n, g in res[False][1].items():
-        grad_close(f'pack.{n}', torch.from_numpy(res[True][1][n]), g, rel=2e-2, cos=0.9995)
+        grad_close(f'pack.{n}', torch.from_numpy(res[True][1][n]), g, rel=3e-2, cos=0.999)
