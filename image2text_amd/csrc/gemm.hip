@@ -755,13 +755,16 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     // K-steps long.  v1 is the default; I2T_GEMM=dma|64x3|32x4|32x3 selects the others for A/B runs.
     static const char* sel = getenv("I2T_GEMM");
     static const bool use_v1 = !sel || !strcmp(sel, "v1");
-    static const int pipe_mode = !sel ? 0 : (!strcmp(sel, "64x3") ? 1 : (!strcmp(sel, "32x4") ? 2 : (!strcmp(sel, "32x3") ? 3 : 0)));
+    static const int pipe_mode = !sel ? 0 : (!strcmp(sel, "64x3") ? 1 : (!strcmp(sel, "32x4") ? 2 : (!strcmp(sel, "32x3") ? 3 :
+                                 (!strcmp(sel, "32x2") ? 4 : (!strcmp(sel, "64x2") ? 5 : 0)))));
     if (!use_v1 && pipe_mode) {
         // the split heuristic counts 64-deep K-steps; the kernels derive their own step count from BKT
         if (splits > 1) grid.y = splits;
         if (pipe_mode == 1) launch_pipe<64, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
         else if (pipe_mode == 2) launch_pipe<32, 4>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        else launch_pipe<32, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        else if (pipe_mode == 3) launch_pipe<32, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        else if (pipe_mode == 4) launch_pipe<32, 2>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
+        else launch_pipe<64, 2>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(pipe)");
         return I2T_OK;
     }
