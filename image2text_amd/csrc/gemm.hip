@@ -47,6 +47,7 @@ struct GemmParams {
     int c_is_f32;
     int accumulate;
     int tiles_m, tiles_n;
+    int epi_lds;              // 1: coalesced epilogue through LDS (A/B switch)
     int drop_mode;            // 0 none | 1 elementwise (idx = m*N + n) | 2 per (row, third of N) -- the q/k/v token multipliers
     unsigned drop_key, drop_thr;
     float drop_scale;
@@ -169,6 +170,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+    // bias depends on the column quad only: 4 float4 loads per lane for the whole tile (it used to be 64 scalar loads,
+    // which alone cost 30 % on K = 768 problems)
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
+        bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            if (n4 + 3 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + n4);
+            else for (int r = 0; r < 4; ++r) if (n4 + r < p.N) bias4[j][r] = p.bias[n4 + r];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + li;
@@ -181,11 +194,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
             const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
-            if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nv) v[r] += p.bias[n4 + r];
-            }
+            for (int r = 0; r < 4; ++r) v[r] += bias4[j][r];
             if (p.aux_out) {
                 bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
                 if (nv == 4 && (p.ld_aux_out & 3) == 0) {
@@ -409,7 +419,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 
     if (SPLITK) gemm_epilogue<true>(p, acc, m0, n0, wm, wn, lane);
-    else gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);     // the K loop ended on a barrier: LDS is free
+    else if (p.epi_lds) gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);   // opt-in (I2T_GEMM_EPI=lds): slower on K <= 768
+    else gemm_epilogue<false>(p, acc, m0, n0, wm, wn, lane);
 }
 
 
@@ -528,7 +539,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
         __syncthreads();      // drains this wave's DMA (vmcnt(0)) and fences the buffer swap
     }
     if (SPLITK) gemm_epilogue<true>(p, acc, m0, n0, wm, wn, lane);
-    else gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);     // the K loop ended on a barrier: LDS is free
+    else if (p.epi_lds) gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);   // opt-in (I2T_GEMM_EPI=lds): slower on K <= 768
+    else gemm_epilogue<false>(p, acc, m0, n0, wm, wn, lane);
 }
 
 
@@ -805,6 +817,8 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_in = (const bf16_t*)aux_in; p.ld_aux_in = ld_aux_in;
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
+    static const bool epi_lds = getenv("I2T_GEMM_EPI") && !strcmp(getenv("I2T_GEMM_EPI"), "lds");
+    p.epi_lds = epi_lds;
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
     I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
