@@ -47,7 +47,6 @@ struct GemmParams {
     int c_is_f32;
     int accumulate;
     int tiles_m, tiles_n;
-    int epi_lds;              // 1: coalesced epilogue through LDS (A/B switch)
     int drop_mode;            // 0 none | 1 elementwise (idx = m*N + n) | 2 per (row, third of N) -- the q/k/v token multipliers
     unsigned drop_key, drop_thr;
     float drop_scale;
@@ -170,18 +169,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
-    // bias depends on the column quad only: 4 float4 loads per lane for the whole tile (it used to be 64 scalar loads,
-    // which alone cost 30 % on K = 768 problems)
-    f32x4 bias4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
-        bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            if (n4 + 3 < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + n4);
-            else for (int r = 0; r < 4; ++r) if (n4 + r < p.N) bias4[j][r] = p.bias[n4 + r];
-        }
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + li;
@@ -194,8 +181,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
             const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
+            if (p.bias) {
+                if (nv == 4) {      // one 16-byte load (n4 % 4 == 0) instead of four scalar ones
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n4);
+                    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+                } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bias4[j][r];
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nv) v[r] += p.bias[n4 + r];
+                }
+            }
             if (p.aux_out) {
                 bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
                 if (nv == 4 && (p.ld_aux_out & 3) == 0) {
@@ -255,92 +250,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     for (int r = 0; r < nv; ++r) c[r] = f32_to_bf16(v[r]);
                 }
             }
-        }
-    }
-}
-
-// Coalesced epilogue through LDS (replaces the per-lane epilogue above wherever 64 KiB of LDS are free after the K loop).
-// Measured on the register epilogue (16384 x 768 x 768): plain bf16 store 513 TFLOP/s, + bias 358, + bias + fp32 residual
-// 299 -- every lane issued 64 scalar bias loads and the residual / C accesses were 64-byte fragments of 16 different rows.
-// Here each wave parks its 64 x 64 accumulators in a [128][128] fp32 LDS tile (16-byte chunk index XOR (row & 31):
-// conflict-free writes, any permutation within a row is conflict-free for the row-wise reads), then every thread owns ONE
-// 16-byte column chunk and walks 16 rows: a wave touches 2 full 512-byte rows per instruction (residual read, C write,
-// pre-activation / GELU' side streams), and bias is one float4 per thread for the whole tile.
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane,
-                                                  int tid, unsigned char* smem) {
-    float* ct = reinterpret_cast<float*>(smem);
-    const int g = lane >> 4, li = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + li;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = wn * 16 + j * 4 + g;                          // 16-byte chunk index within the 128-wide row
-            *reinterpret_cast<f32x4*>(ct + r * 128 + ((c ^ (r & 31)) << 2)) = acc[i][j];
-        }
-    }
-    __syncthreads();
-    const int c = tid & 31, n4 = n0 + 4 * c;
-    if (n4 >= p.N) return;
-    const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
-    const bool full = nv == 4;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-        if (full) bias = *reinterpret_cast<const f32x4*>(p.bias + n4);      // bias + n4 is 16-byte aligned: n4 % 4 == 0
-        else for (int e = 0; e < nv; ++e) bias[e] = p.bias[n4 + e];
-    }
-    const bool c_vec = full && (p.ldc & 3) == 0;
-    const bool r_vec = full && (p.ldr & 3) == 0;
-    const unsigned third = p.drop_mode == 2 ? (unsigned)n4 / (unsigned)(p.N / 3) : 0u;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int r = (tid >> 5) + 8 * k;
-        const int m = m0 + r;
-        if (m >= p.M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * 128 + ((c ^ (r & 31)) << 2));
-        v = v * p.alpha + bias;
-        if (p.aux_out) {
-            bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
-            if (full && (p.ld_aux_out & 3) == 0) *reinterpret_cast<u32x2*>(ao) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            else for (int e = 0; e < nv; ++e) ao[e] = f32_to_bf16(v[e]);
-        }
-        if (p.act == I2T_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-        } else if (p.act == I2T_ACT_DGELU) {
-            const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
-            if (full && (p.ld_aux_in & 3) == 0) {
-                const u32x2 pk = *reinterpret_cast<const u32x2*>(ai);
-                v[0] *= gelu_tanh_grad(bf16lo(pk[0])); v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
-                v[2] *= gelu_tanh_grad(bf16lo(pk[1])); v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
-            } else {
-                for (int e = 0; e < nv; ++e) v[e] *= gelu_tanh_grad(bf16_to_f32(ai[e]));
-            }
-        }
-        if (p.drop_mode == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[e] = dropout_keep(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)(n4 + e), p.drop_thr) ? v[e] * p.drop_scale : 0.f;
-        } else if (p.drop_mode == 2) {
-            v = v * (dropout_keep(p.drop_key + third, (unsigned)m, p.drop_thr) ? p.drop_scale : 0.f);
-        }
-        if (p.residual) {
-            const float* rr = p.residual + (size_t)m * p.ldr + n4;
-            if (r_vec) v += *reinterpret_cast<const f32x4*>(rr);
-            else for (int e = 0; e < nv; ++e) v[e] += rr[e];
-        }
-        if (p.c_is_f32) {
-            float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n4;
-            if (c_vec) {
-                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
-                *reinterpret_cast<f32x4*>(cp) = v;
-            } else {
-                for (int e = 0; e < nv; ++e) cp[e] = p.accumulate ? cp[e] + v[e] : v[e];
-            }
-        } else {
-            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n4;
-            if (c_vec) *reinterpret_cast<u32x2*>(cp) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            else for (int e = 0; e < nv; ++e) cp[e] = f32_to_bf16(v[e]);
         }
     }
 }
@@ -418,9 +327,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    if (SPLITK) gemm_epilogue<true>(p, acc, m0, n0, wm, wn, lane);
-    else if (p.epi_lds) gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);   // opt-in (I2T_GEMM_EPI=lds): slower on K <= 768
-    else gemm_epilogue<false>(p, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
 }
 
 
@@ -538,9 +445,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
         }
         __syncthreads();      // drains this wave's DMA (vmcnt(0)) and fences the buffer swap
     }
-    if (SPLITK) gemm_epilogue<true>(p, acc, m0, n0, wm, wn, lane);
-    else if (p.epi_lds) gemm_epilogue_lds(p, acc, m0, n0, wm, wn, lane, tid, smem);   // opt-in (I2T_GEMM_EPI=lds): slower on K <= 768
-    else gemm_epilogue<false>(p, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
 }
 
 
@@ -817,8 +722,6 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_in = (const bf16_t*)aux_in; p.ld_aux_in = ld_aux_in;
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
-    static const bool epi_lds = getenv("I2T_GEMM_EPI") && !strcmp(getenv("I2T_GEMM_EPI"), "lds");
-    p.epi_lds = epi_lds;
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
     I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
