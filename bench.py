@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=512, help='images per GPU per step')
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=64, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
@@ -76,13 +76,19 @@ class GemmTimer:
                     bytes_per_launch=by / max(1, len(self.records)))
 
 
-def cpu_baseline(batch=8, steps=2, dropout=0.1):
+def log(msg):
+    """Progress on stderr (rank 0): the JSON line on stdout stays the only stdout output."""
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def cpu_baseline(batch=8, steps=6, dropout=0.1):
     """The fp32 oracle port (oracle/reference_model.py) timed on the host cores: train step + torch AdamW."""
     from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
     from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch
     from oracle import reference_model as orc
-    try:
-        torch.set_num_threads(len(os.sched_getaffinity(0)))
+    try:       # the GPU box grants ~16 CPUs per GPU (cgroup quota) while the affinity mask shows every core: more threads than that
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))      # only spin against the quota
     except Exception:
         pass
     cfg = nano224_config(dropout=dropout)
@@ -96,6 +102,7 @@ def cpu_baseline(batch=8, steps=2, dropout=0.1):
     images, labels = synthetic_batch(batch, 224, 64, cfg.decoder_config.vocab_size, seed=1)
     times = []
     for i in range(steps + 1):
+        log(f'cpu_baseline: oracle train step {i}/{steps}')
         t0 = time.perf_counter()
         loss = orc.lm_step(sd, cfg, images, labels, tok, training=True)
         loss.backward()
@@ -103,6 +110,7 @@ def cpu_baseline(batch=8, steps=2, dropout=0.1):
         opt.zero_grad()
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / steps
+    log('cpu_baseline: oracle greedy decode')
     t0 = time.perf_counter()
     with torch.no_grad():
         orc.generate_greedy({k: v.detach() for k, v in sd.items()}, cfg, images[:4], torch.full((4, 1), tok.bos_token_id), 8)
@@ -160,6 +168,7 @@ def main():
         wrapper.train_step(images[:1], labels[:1])[0].backward()     # builds the arena
         opt.zero_grad()
         dp.broadcast_parameters()
+    log(f'train: batch {args.batch}/gpu, {args.warmup} warm-up + {args.steps} timed steps')
     for _ in range(args.warmup):
         loss = step()
     fence()
@@ -168,7 +177,8 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    log(f'train: {1e3 * elapsed / args.steps:.2f} ms/step')
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,8 +203,10 @@ def main():
         dimgs = [synthetic_batch(Bd, 224, 64, V, seed=100 + rank * S + i)[0].to(dev) for i in range(S)]
         prompts = [torch.full((Bd, 1), V - 1, dtype=torch.long, device=dev) for _ in range(S)]
         cdec = ConcurrentGreedyDecoder(wrapper.model, S)
+        log(f'decode: {S} concurrent batches x {Bd} captions, warm-up + graph capture')
         cdec.generate(dimgs, prompts, 64)                                      # warm-up + graph capture
         fence()
+        log('decode: timed runs')
         t0 = time.perf_counter()
         for _ in range(args.decode_reps):
             outs = cdec.generate(dimgs, prompts, 64)
