@@ -166,14 +166,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
         const float alpha = exp2f(m - m_safe);      // m = -inf -> 0
         float rs = 0.f;
 #pragma unroll
-        for (int kj = 0; kj < 4; ++kj)
+        for (int kj = 0; kj < 4; ++kj) {
+            bool keep[4] = {true, true, true, true};
+            if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = exp2f(s[kj][r] - m_safe);
                 rs += p;                               // the softmax denominator is dropout-free
-                if (drop_thr) p = dropout_keep(drop_key, drow + kt * 64 + kj * 16 + 4 * g + r, drop_thr) ? p * drop_scale : 0.f;
+                if (drop_thr) p = keep[r] ? p * drop_scale : 0.f;
                 s[kj][r] = p;
             }
+        }
         l = l * alpha + rs;
         m = m_new;
 #pragma unroll
@@ -291,12 +294,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 0, lane), df0, dp, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 1, lane), df1, dp, 0, 0, 0);
+            bool keep[4] = {true, true, true, true};
+            if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 64 + kj * 16 + 4 * g + r;
                 float p = (key <= qlim && key < Tk) ? exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
                 float dpr = dp[r];                     // gradient w.r.t. the dropped probabilities -> undo the mask
-                if (drop_thr) dpr = dropout_keep(drop_key, drow + key, drop_thr) ? dpr * drop_scale : 0.f;
+                if (drop_thr) dpr = keep[r] ? dpr * drop_scale : 0.f;
                 ds[kj][r] = p * (dpr - dl) * SCALE;
             }
         }

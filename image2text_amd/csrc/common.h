@@ -48,31 +48,47 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// ---- GELU(tanh) as torch computes it: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) ----
-__device__ __forceinline__ float gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(1+exp(2u)); exp overflow -> inf -> t = 1, fine
-    float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-    return 0.5f * x * (1.0f + t);
+// ---- GELU(tanh): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), evaluated as x * sigmoid(2u): one v_exp_f32 and
+// one v_rcp_f32 (1 ulp each) instead of an IEEE division -- the epilogue VALU work of a K = 512 GEMM rivals its MFMA work,
+// so every instruction here is paid per output element.
+__device__ __forceinline__ float gelu_sigmoid_(float x, float x2) {      // sigmoid(2u)
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * (c0 + c1 * x2));          // exp(-2u); +inf for very negative x -> s = 0
+    return __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ float gelu_tanh_grad(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float x2 = x * x;
-    float u = k0 * (x + k1 * x * x2);
-    float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-    float du = k0 * (1.0f + 3.0f * k1 * x2);
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+__device__ __forceinline__ float gelu_tanh(float x) { return x * gelu_sigmoid_(x, x * x); }
+__device__ __forceinline__ float gelu_tanh_grad(float x) {               // s + x s (1 - s) d(2u)/dx
+    const float d0 = 2.0f * 0.7978845608028654f, d1 = d0 * 3.0f * 0.044715f;
+    const float x2 = x * x, s = gelu_sigmoid_(x, x2);
+    return s + (x * s) * (1.0f - s) * (d0 + d1 * x2);
 }
 
-// ---- counter-based dropout: keep element idx of site `key` iff hash(key, idx) >= thr (thr = p * 2^32); the same
-// function is evaluated in forward and backward, so no mask is ever stored.  (lowbias32 mixer)
-__device__ __forceinline__ unsigned dropout_hash(unsigned key, unsigned idx) {
-    unsigned x = idx ^ key;
+// ---- counter-based dropout: one lowbias32 hash of (site key, idx >> 1) yields two 16-bit uniforms; element idx of
+// site `key` is kept iff its field >= thr16 (thr16 = round(p * 65536), so the effective p is thr16 / 65536 and the host
+// scales by 65536 / (65536 - thr16)).  The same function is evaluated in forward and backward: no mask is ever stored.
+// Two decisions per hash because v_mul_lo_u32 is quarter rate -- per-element hashing cost more than a K = 512 MFMA loop.
+__device__ __forceinline__ unsigned dropout_hash(unsigned key, unsigned pair) {
+    unsigned x = pair ^ key;
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned idx, unsigned thr) { return dropout_hash(key, idx) >= thr; }
+__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned idx, unsigned thr16) {
+    const unsigned h = dropout_hash(key, idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;
+}
+// keep[r] for the 4 consecutive elements idx0 .. idx0 + 3 (2 hashes when idx0 is even, 3 otherwise)
+__device__ __forceinline__ void dropout_keep4(unsigned key, unsigned idx0, unsigned thr16, bool (&keep)[4]) {
+    const unsigned p0 = idx0 >> 1;
+    const unsigned h0 = dropout_hash(key, p0), h1 = dropout_hash(key, p0 + 1);
+    if (idx0 & 1u) {
+        const unsigned h2 = dropout_hash(key, p0 + 2);
+        keep[0] = (h0 >> 16) >= thr16; keep[1] = (h1 & 0xffffu) >= thr16;
+        keep[2] = (h1 >> 16) >= thr16; keep[3] = (h2 & 0xffffu) >= thr16;
+    } else {
+        keep[0] = (h0 & 0xffffu) >= thr16; keep[1] = (h0 >> 16) >= thr16;
+        keep[2] = (h1 & 0xffffu) >= thr16; keep[3] = (h1 >> 16) >= thr16;
+    }
+}
 
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {

@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(void* __restrict__ x
             const float f = dropout_keep(key + c / (unsigned)(cols / 3), r, thr) ? scale : 0.f;
             m[0] = m[1] = m[2] = m[3] = f;
         } else {
+            bool keep[4];
+            dropout_keep4(key, (unsigned)e0, thr, keep);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = dropout_keep(key, (unsigned)(e0 + e), thr) ? scale : 0.f;
+            for (int e = 0; e < 4; ++e) m[e] = keep[e] ? scale : 0.f;
         }
         if (F32) {
             f32x4 v = reinterpret_cast<f32x4*>(x)[i];

@@ -205,14 +205,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
             } else if (p.act == I2T_ACT_DGELU) {
                 const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
+                if (nv == 4 && (p.ld_aux_in & 3) == 0) {      // one 8-byte load of the 4 pre-activations
+                    const u32x2 pk = *reinterpret_cast<const u32x2*>(ai);
+                    v[0] *= gelu_tanh_grad(bf16lo(pk[0])); v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
+                    v[2] *= gelu_tanh_grad(bf16lo(pk[1])); v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
+                }
             }
             if (p.drop_mode == 1) {
+                bool keep[4];
+                dropout_keep4(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)n4, p.drop_thr, keep);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = dropout_keep(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)(n4 + r), p.drop_thr) ? v[r] * p.drop_scale : 0.f;
+                for (int r = 0; r < 4; ++r) v[r] = keep[r] ? v[r] * p.drop_scale : 0.f;
             } else if (p.drop_mode == 2) {
                 const unsigned third = (unsigned)n4 / (unsigned)(p.N / 3);
                 const float mult = dropout_keep(p.drop_key + third, (unsigned)m, p.drop_thr) ? p.drop_scale : 0.f;
@@ -269,8 +276,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     // XCD-aware, bijective remap of the 1-D grid (cdna_hip_programming.md 5, "XCD swizzle must be bijective")
     const int nwg = gridDim.x;
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int swz, split = 0;
+    if (SPLITK) {
+        // Workgroups go to the 8 XCDs round-robin in linear grid order.  split = linear % splits puts every tile of one
+        // K-slice on the same XCD(s), so a slice of A and B is fetched from HBM once and shared through that XCD's L2
+        // (PMC, round 1: with the slices spread over all XCDs the dW GEMMs read 2.3-7x their operand bytes).
+        const int lin = bid + (int)blockIdx.y * nwg, splits = (int)gridDim.y;
+        split = lin % splits;
+        swz = lin / splits;
+    } else {
+        const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
     int tile_m, tile_n;
     tile_coords(p, swz, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
     const int nk_all = (p.K + BK - 1) / BK;
     const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
-    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
+    const int kt0 = SPLITK ? split * nk_per : 0;
     const int nk = min(nk_per, nk_all - kt0);
     if (nk <= 0) return;                                     // block-uniform
 

@@ -58,7 +58,7 @@ class DropPlan:
         if p <= 0.0:
             return None
         site = self.tower * 4096 + layer * 16 + self.KINDS[kind]
-        return (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), 1.0 / (1.0 - p))
+        return (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), rng.scale(rng.threshold(p)))
 
 
 class ParamArena:

@@ -21,15 +21,23 @@ def site_key(seed: int, site: int) -> int:
 
 
 def threshold(p: float) -> int:
-    return min(M32, int(round(p * 4294967296.0)))
+    """16-bit threshold thr16 = round(p * 65536): an element is dropped iff its 16-bit uniform < thr16."""
+    return max(0, min(65536, int(round(p * 65536.0))))
+
+
+def scale(thr16: int) -> float:
+    """1 / (1 - p_eff) for the probability the kernels actually realise, p_eff = thr16 / 65536."""
+    return 65536.0 / max(1, 65536 - thr16)
 
 
 def keep_mask(key: int, n: int, thr: int, offset: int = 0) -> torch.Tensor:
-    """bool[n]: element i kept iff hash(key, offset + i) >= thr (vectorised replica of dropout_keep)."""
-    x = (torch.arange(offset, offset + n, dtype=torch.int64) ^ key) & M32
+    """bool[n]: element i kept iff the 16-bit field (i & 1) of hash(key, (offset + i) >> 1) >= thr (replica of dropout_keep)."""
+    idx = torch.arange(offset, offset + n, dtype=torch.int64)
+    x = ((idx >> 1) ^ key) & M32
     x ^= x >> 16
     x = (x * 0x7FEB352D) & M32
     x ^= x >> 15
     x = (x * 0x846CA68B) & M32
     x ^= x >> 16
-    return x >= thr
+    bits = torch.where((idx & 1) == 1, x >> 16, x & 0xFFFF)
+    return bits >= thr
