@@ -19,6 +19,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 namespace {
 
@@ -58,8 +59,8 @@ struct GemmParams {
 // whose weight panels (GN x 128 x K bf16, <= ~3 MB) stay in the XCD's 4 MiB L2: an activation tile is fetched once per
 // group and reused GN times from L2; the weight group is re-read (from L2) for every row tile.
 constexpr int GN_MAX = 16;
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int swz, int& tile_m, int& tile_n) {
-    const int gn = p.tiles_n < GN_MAX ? p.tiles_n : GN_MAX;
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int swz, int& tile_m, int& tile_n, int gn_max = GN_MAX) {
+    const int gn = p.tiles_n < gn_max ? p.tiles_n : gn_max;
     const int per_group = p.tiles_m * gn;
     int grp = swz / per_group;
     const int ngroups = (p.tiles_n + gn - 1) / gn;
@@ -146,8 +147,16 @@ __device__ __forceinline__ bf16x8 frag_read(const unsigned char* lds, int r0, in
     }
 }
 
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 // Epilogue shared by the GEMM kernels.  SPLITK: un-swapped accumulators, float atomics; else fused bias / GELU /
 // GELU' / residual / accumulate with 8-/16-byte vector stores.
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int lane);
+
 template <bool SPLITK>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
     const int g = lane >> 4, li = lane & 15;
@@ -167,98 +176,257 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         return;
     }
-    // ---- epilogue: lane holds C[m][n4 .. n4+3], m = m0 + wm*64 + 16 i + (lane&15), n4 = n0 + wn*64 + 16 j + 4 (lane>>4)
-    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+    epilogue_tile<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// The fused epilogue for ONE lane's 4 consecutive columns C[m][n4 .. n4+3] (a4 = raw accumulators); m < M and n4 < N.
+__device__ __forceinline__ void epilogue_quad(const GemmParams& p, const f32x4 a4, int m, int n4, bool vec_ok) {
+    float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + li;
-        if (m >= p.M) continue;
+    for (int r = 0; r < 4; ++r) v[r] = a4[r] * p.alpha;
+    const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
+    if (p.bias) {
+        if (nv == 4) {      // one 16-byte load (n4 % 4 == 0) instead of four scalar ones
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n4);
+            v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n4 = n0 + wn * 64 + j * 16 + 4 * g;
-            if (n4 >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
-            if (p.bias) {
-                if (nv == 4) {      // one 16-byte load (n4 % 4 == 0) instead of four scalar ones
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n4);
-                    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nv) v[r] += p.bias[n4 + r];
-                }
-            }
-            if (p.aux_out) {
-                bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
-                if (nv == 4 && (p.ld_aux_out & 3) == 0) {
-                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(ao) = pk;
-                } else {
-                    for (int r = 0; r < nv; ++r) ao[r] = f32_to_bf16(v[r]);
-                }
-            }
-            if (p.act == I2T_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
-            } else if (p.act == I2T_ACT_DGELU) {
-                const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
-                if (nv == 4 && (p.ld_aux_in & 3) == 0) {      // one 8-byte load of the 4 pre-activations
-                    const u32x2 pk = *reinterpret_cast<const u32x2*>(ai);
-                    v[0] *= gelu_tanh_grad(bf16lo(pk[0])); v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
-                    v[2] *= gelu_tanh_grad(bf16lo(pk[1])); v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
-                }
-            }
-            if (p.drop_mode == 1) {
-                bool keep[4];
-                dropout_keep4(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)n4, p.drop_thr, keep);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = keep[r] ? v[r] * p.drop_scale : 0.f;
-            } else if (p.drop_mode == 2) {
-                const unsigned third = (unsigned)n4 / (unsigned)(p.N / 3);
-                const float mult = dropout_keep(p.drop_key + third, (unsigned)m, p.drop_thr) ? p.drop_scale : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= mult;
-            }
-            if (p.residual) {
-                const float* rr = p.residual + (size_t)m * p.ldr + n4;
-                if (nv == 4 && vec_ok) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(rr);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += t[r];
-                } else {
-                    for (int r = 0; r < nv; ++r) v[r] += rr[r];
-                }
-            }
-            if (p.c_is_f32) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n4;
-                if (nv == 4 && vec_ok) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate) {
-                        f32x4 t = *reinterpret_cast<const f32x4*>(c);
-                        o += t;
-                    }
-                    *reinterpret_cast<f32x4*>(c) = o;
-                } else {
-                    for (int r = 0; r < nv; ++r) c[r] = p.accumulate ? c[r] + v[r] : v[r];
-                }
-            } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n4;
-                if (nv == 4 && vec_ok) {
-                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(c) = pk;
-                } else {
-                    for (int r = 0; r < nv; ++r) c[r] = f32_to_bf16(v[r]);
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+                if (r < nv) v[r] += p.bias[n4 + r];
         }
     }
+    if (p.aux_out) {
+        bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
+        if (nv == 4 && (p.ld_aux_out & 3) == 0) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(ao) = pk;
+        } else {
+            for (int r = 0; r < nv; ++r) ao[r] = f32_to_bf16(v[r]);
+        }
+    }
+    if (p.act == I2T_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+    } else if (p.act == I2T_ACT_DGELU) {
+        const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
+        if (nv == 4 && (p.ld_aux_in & 3) == 0) {      // one 8-byte load of the 4 pre-activations
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(ai);
+            v[0] *= gelu_tanh_grad(bf16lo(pk[0])); v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
+            v[2] *= gelu_tanh_grad(bf16lo(pk[1])); v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nv) v[r] *= gelu_tanh_grad(bf16_to_f32(ai[r]));
+        }
+    }
+    if (p.drop_mode == 1) {
+        bool keep[4];
+        dropout_keep4(p.drop_key, (unsigned)m * (unsigned)p.N + (unsigned)n4, p.drop_thr, keep);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = keep[r] ? v[r] * p.drop_scale : 0.f;
+    } else if (p.drop_mode == 2) {
+        const unsigned third = (unsigned)n4 / (unsigned)(p.N / 3);
+        const float mult = dropout_keep(p.drop_key + third, (unsigned)m, p.drop_thr) ? p.drop_scale : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= mult;
+    }
+    if (p.residual) {
+        const float* rr = p.residual + (size_t)m * p.ldr + n4;
+        if (nv == 4 && vec_ok) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += t[r];
+        } else {
+            for (int r = 0; r < nv; ++r) v[r] += rr[r];
+        }
+    }
+    if (p.c_is_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n4;
+        if (nv == 4 && vec_ok) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (p.accumulate) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(c);
+                o += t;
+            }
+            *reinterpret_cast<f32x4*>(c) = o;
+        } else {
+            for (int r = 0; r < nv; ++r) c[r] = p.accumulate ? c[r] + v[r] : v[r];
+        }
+    } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n4;
+        if (nv == 4 && vec_ok) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(c) = pk;
+        } else {
+            for (int r = 0; r < nv; ++r) c[r] = f32_to_bf16(v[r]);
+        }
+    }
+}
+
+// Fast form for 4 quads at once (all vector-aligned: N % 4 == 0 and every leading dimension % 4 == 0).  Per-quad code
+// waits on each load before the next one is issued (a residual GEMM spent 30-60 us per 256^2 tile that way); here the
+// loads of each KIND are issued back to back for the 4 quads -- from clamped, always-valid addresses, so that no
+// predication splits them -- and only the stores are predicated.
+__device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
+    return (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
+           (!p.aux_out || (p.ld_aux_out & 3) == 0);
+}
+__device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
+    bool ok[4];
+    int mc[4], nc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ok[q] = m[q] < p.M && n4[q] < p.N;
+        mc[q] = min(m[q], p.M - 1);
+        nc[q] = min(n4[q], p.N - 4);
+    }
+    // one set of addend registers serves residual and accumulate (both at once is rare: the second then waits on the first)
+    f32x4 v[4], bv[4], add[4];
+    u32x2 ax[4];
+    if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nc[q]);
+    }
+    if (p.act == I2T_ACT_DGELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
+    }
+    if (p.residual) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) add[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mc[q] * p.ldr + nc[q]);
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)mc[q] * p.ldc + nc[q]);
+            add[q] = p.residual ? add[q] + c : c;
+        }
+    }
+    const bool has_add = p.residual || p.accumulate;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = a[q] * p.alpha;
+        if (p.bias) v[q] += bv[q];
+    }
+    if (p.aux_out) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ok[q]) {
+                const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
+                *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]) = pk;
+            }
+    }
+    if (p.act == I2T_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q][r] = gelu_tanh(v[q][r]);
+    } else if (p.act == I2T_ACT_DGELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q][0] *= gelu_tanh_grad(bf16lo(ax[q][0])); v[q][1] *= gelu_tanh_grad(bf16hi(ax[q][0]));
+            v[q][2] *= gelu_tanh_grad(bf16lo(ax[q][1])); v[q][3] *= gelu_tanh_grad(bf16hi(ax[q][1]));
+        }
+    }
+    if (p.drop_mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bool keep[4];
+            dropout_keep4(p.drop_key, (unsigned)m[q] * (unsigned)p.N + (unsigned)n4[q], p.drop_thr, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q][r] = keep[r] ? v[q][r] * p.drop_scale : 0.f;
+        }
+    } else if (p.drop_mode == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned third = (unsigned)nc[q] / (unsigned)(p.N / 3);
+            v[q] *= dropout_keep(p.drop_key + third, (unsigned)m[q], p.drop_thr) ? p.drop_scale : 0.f;
+        }
+    }
+    if (has_add) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += add[q];
+    }
+    if (p.c_is_f32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ok[q]) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m[q] * p.ldc + n4[q]) = v[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ok[q]) {
+                const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m[q] * p.ldc + n4[q]) = pk;
+            }
+    }
+}
+
+// Fused epilogue of an (MI x 16) x (NJ x 16) wave tile held in swapped-issue accumulators: lane holds
+// C[m][n4 .. n4+3], m = mbase + 16 i + (lane&15), n4 = nbase + 16 j + 4 (lane>>4).
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+    // compile-time loops (lambdas over integral constants): with MI x NJ = 32 copies of this body hipcc left a
+    // "#pragma unroll" loop rolled and moved the accumulators to scratch for the dynamic index
+    if (NJ == 4 && epilogue_fast_ok(p)) {
+        static_for<MI>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            const int mr = mbase + i * 16 + li;
+            const int m[4] = {mr, mr, mr, mr};
+            const int n4[4] = {nbase + 4 * g, nbase + 16 + 4 * g, nbase + 32 + 4 * g, nbase + 48 + 4 * g};
+            const f32x4 a[4] = {acc[i][0], acc[i][1 % NJ], acc[i][2 % NJ], acc[i][3 % NJ]};
+            epilogue_batch4(p, a, m, n4);
+        });
+        return;
+    }
+    static_for<MI>([&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+        const int m = mbase + i * 16 + li;
+        if (m >= p.M) return;
+        static_for<NJ>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            const int n4 = nbase + j * 16 + 4 * g;
+            if (n4 >= p.N) return;
+            epilogue_quad(p, acc[i][j], m, n4, vec_ok);
+        });
+    });
+}
+
+// Same epilogue through a wave-private 4 KiB LDS transpose (16 rows x 64 fp32, 16-byte chunks XOR-swizzled by row & 7:
+// conflict-free ds_write_b128 and ds_read_b128): afterwards a lane holds C[m][4c .. 4c+3] with m = 4k + (lane>>4),
+// c = lane&15, so one store instruction covers 4 rows x 128 B (bf16) / 256 B (f32) of FULL cache lines instead of 16 rows
+// x 32 / 64 B.  Measured need (round 1, K sweep): the direct form cost a fixed ~18 us per 256^2 tile -- 16 distinct lines
+// per store instruction, row strides of 1-4 KiB camping on a few L2 channels.
+template <int MI>
+__device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int lane,
+                                                 unsigned char* wave_lds) {
+    const int g = lane >> 4, li = lane & 15;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+    const bool fast = epilogue_fast_ok(p);
+    static_for<MI>([&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(wave_lds + li * 256 + (((4 * j + g) ^ (li & 7)) << 4)) = acc[i][j];
+        f32x4 a[4];
+        int m[4], n4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = 4 * k + g;
+            a[k] = *reinterpret_cast<const f32x4*>(wave_lds + row * 256 + ((li ^ (row & 7)) << 4));
+            m[k] = mbase + i * 16 + row;
+            n4[k] = nbase + 4 * li;
+        }
+        if (fast) {
+            epilogue_batch4(p, a, m, n4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m[k] < p.M && n4[k] < p.N) epilogue_quad(p, a[k], m[k], n4[k], vec_ok);
+        }
+    });
 }
 
 // SPLITK: gridDim.y slices of the reduction; every slice adds its partial tile into the fp32 C with float atomics
@@ -602,6 +770,241 @@ void launch_pipe(hipStream_t s, dim3 grid, const GemmParams& p, int a_kmajor, in
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 outputs each), one workgroup per CU: the large-tile kernel for the
+// non-split problems (cdna_hip_programming.md 5: the 128^2 two-barrier structure tops out near 0.9 PF on zeros; what
+// breaks that ceiling is ~1 block/CU, all-DMA staging kept in flight across raw barriers with counted vmcnt, and a
+// per-phase interleave of LDS reads, DMA issue and MFMA).  Own schedule, built from those rules:
+//
+//   * a K-tile is staged as 4 UNITS of 16 KiB (128 rows x 64 k): e = 0 A-sub0, 1 B-first, 2 B-second, 3 A-sub1, where
+//     sub s of A holds rows {wr*128 + s*64 + 0..63} (wr = wave row) and sub s of B holds columns {wc*64 + s*32 +
+//     0..31}: every wave finds the 64 x 64-k (A) or 32 x 64-k (B) register subtile of a phase in ONE unit.  LDS = 2
+//     tiles x 4 units = 128 KiB; unit q = 4 T + e (T = K-tile) lives in slot (T & 1) * 4 + e.
+//   * a tile is 4 PHASES of 16 MFMA per wave (one 64 x 32 quadrant x K = 64) in snake order, so three of the four
+//     register subtiles carry over:  even tile (A0,B0) (A0,B1) (A1,B1) (A1,B0);  odd tile (A0,B1) (A0,B0) (A1,B0)
+//     (A1,B1)  ->  "B-first" is sub 0 on even tiles and sub 1 on odd ones.
+//   * fragments are prefetched in registers so that no MFMA waits on an LDS read issued less than half a phase (8 MFMA)
+//     earlier: B has two register sets (B0, B1: the next one is read a phase ahead); A has ONE (32 VGPR), refilled
+//     by k-half: the k 0..31 half is re-read in the middle of the phase that last uses it, the k 32..63 half at the
+//     start of the next phase.  Unit q is therefore read in phases q-2 .. q.
+//   * phase P DMA-stages unit P + 6 into the slot whose previous tenant (unit P - 2) was last read in phase P - 2 (WAR:
+//     a counted lgkmcnt before this phase's barrier retires those reads in every wave) and waits -- vmcnt(6): three
+//     younger units stay in flight -- for unit P + 2, issued four phases earlier and first read after this barrier
+//     (RAW: counted vmcnt, then a barrier the reader has passed).  vmcnt is never 0 inside the loop.
+//   * operands go through buffer descriptors (buffer_load_dwordx4 ... lds): one loop-invariant 32-bit voffset per
+//     thread and chunk, the K advance in the scalar offset, out-of-range rows / K-tail served as zeros by the range
+//     check -- no 64-bit address math or predicates in the loop (the first version spilled 250+ VGPRs on them).
+constexpr int G2_UNIT = 128 * 128;                     // 16 KiB
+constexpr int G2_SMEM = 8 * G2_UNIT + 8 * 4096;        // 128 KiB of staging slots + a 4 KiB epilogue transpose pad per wave
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct G2Tile {                       // wave-uniform description of one output tile's operand panels
+    const bf16_t* a;
+    const bf16_t* b;
+    unsigned a_bytes, b_bytes;
+    int m0, n0;
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+struct G2 {
+    static constexpr bool PK = A_KMAJOR && B_KMAJOR;
+    static constexpr int FA = A_KMAJOR ? 2 : 1, FB = B_KMAJOR ? 2 : 1;      // LGKM ops per fragment read
+    static constexpr int cap(int n) { return n > 15 ? 15 : n; }
+    static constexpr int LG0 = cap(4 * FA + 4 * FB), LG1 = cap(4 * FA), LG2 = cap(4 * FA), LG3 = cap(4 * FA + 4 * FB);
+
+    unsigned char* smem;
+    int lane, wr, wc, wave_off, nk;
+    int va[2][2], vb[2][2];          // voffset[sub][chunk]
+    unsigned step_a, step_b;         // bytes per K-tile
+    G2Tile cur, nxt;                 // the tile being computed and the one whose first units are already being staged
+
+    __device__ __forceinline__ static G2Tile tile_desc(const GemmParams& p, int idx, int ntiles) {
+        G2Tile d;
+        if (idx >= ntiles) {           // past the end: zero-sized panels, every DMA returns zeros
+            d.a = p.A; d.b = p.B; d.a_bytes = 0; d.b_bytes = 0; d.m0 = 0; d.n0 = 0;
+            return d;
+        }
+        int tile_m, tile_n;
+        tile_coords(p, idx, tile_m, tile_n, 8);
+        d.m0 = tile_m * 256; d.n0 = tile_n * 256;
+        if (!A_KMAJOR) {
+            d.a = p.A + (size_t)d.m0 * p.lda;
+            d.a_bytes = (unsigned)(min(p.M - d.m0, 256) * p.lda * 2);
+        } else {
+            d.a = p.A + d.m0;
+            d.a_bytes = (unsigned)(((size_t)(p.K - 1) * p.lda + min(((p.M + 7) & ~7) - d.m0, 256)) * 2);
+        }
+        if (!B_KMAJOR) {
+            d.b = p.B + (size_t)d.n0 * p.ldb;
+            d.b_bytes = (unsigned)(min(p.N - d.n0, 256) * p.ldb * 2);
+        } else {
+            d.b = p.B + d.n0;
+            d.b_bytes = (unsigned)(((size_t)(p.K - 1) * p.ldb + min(((p.N + 7) & ~7) - d.n0, 256)) * 2);
+        }
+        return d;
+    }
+
+    __device__ __forceinline__ void init(const GemmParams& p, unsigned char* smem_, int tid) {
+        smem = smem_; lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        wr = wave >> 2; wc = wave & 3; wave_off = wave * 1024;
+        nk = (p.K + 63) >> 6;
+        step_a = A_KMAJOR ? 128u * (unsigned)p.lda : 128u;
+        step_b = B_KMAJOR ? 128u * (unsigned)p.ldb : 128u;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = u * 512 + tid;
+                if (!A_KMAJOR) {
+                    const int r = c >> 3, kc = (c & 7) ^ (r & 7);
+                    va[sub][u] = ((r >> 6) * 128 + sub * 64 + (r & 63)) * p.lda * 2 + kc * 16;
+                } else {
+                    const int kr = c >> 4, ul = ((c & 15) ^ (cf_swz<PK>(kr) << 1)) * 8;
+                    va[sub][u] = (kr * p.lda + (ul >> 6) * 128 + sub * 64 + (ul & 63)) * 2;
+                }
+                if (!B_KMAJOR) {
+                    const int r = c >> 3, kc = (c & 7) ^ (r & 7);
+                    vb[sub][u] = ((r >> 5) * 64 + sub * 32 + (r & 31)) * p.ldb * 2 + kc * 16;
+                } else {
+                    const int kr = c >> 4, ul = ((c & 15) ^ (cf_swz<PK>(kr) << 1)) * 8;
+                    vb[sub][u] = (kr * p.ldb + (ul >> 5) * 64 + sub * 32 + (ul & 31)) * 2;
+                }
+            }
+    }
+
+    // unit e (0 A-sub0 | 1 B-first | 2 B-second | 3 A-sub1) of K-tile T, whose parity is PAR -> slot PAR*4 + e.
+    // T >= nk continues into the NEXT output tile (nk is even, so slot parities carry over): no pipeline drain between tiles.
+    template <int PAR, int E>
+    __device__ __forceinline__ void stage(int T) {
+        unsigned char* slot = smem + (PAR * 4 + E) * G2_UNIT + wave_off;
+        constexpr int sub = (E == 0) ? 0 : (E == 3) ? 1 : (E == 1) ? PAR : (PAR ^ 1);
+        const bool nx = T >= nk;
+        const int Te = nx ? T - nk : T;
+        if (E == 0 || E == 3) {
+            const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? nxt.a : cur.a), 0, nx ? nxt.a_bytes : cur.a_bytes, 0x00020000);
+            const unsigned so = (unsigned)Te * step_a;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot), 16, va[sub][0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot + 8192), 16, va[sub][1], so, 0, 0);
+        } else {
+            const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? nxt.b : cur.b), 0, nx ? nxt.b_bytes : cur.b_bytes, 0x00020000);
+            const unsigned so = (unsigned)Te * step_b;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot), 16, vb[sub][0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot + 8192), 16, vb[sub][1], so, 0, 0);
+        }
+    }
+    template <int SLOT, int KS>
+    __device__ __forceinline__ void read_a(bf16x8 (&ra)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<A_KMAJOR, PK>(smem + SLOT * G2_UNIT, wr * 64 + i * 16, KS, lane);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void read_b(bf16x8 (&rb)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rb[ks * 2 + j] = dma_frag_read<B_KMAJOR, PK>(smem + SLOT * G2_UNIT, wc * 32 + j * 16, ks, lane);
+    }
+    template <int SUBA, int SUBB, int KS>
+    __device__ __forceinline__ void mma(f32x4 (&acc)[8][4], const bf16x8 (&ra)[8], const bf16x8 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[SUBA * 4 + i][SUBB * 2 + j] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
+    }
+    template <int LG>
+    __device__ __forceinline__ void fence() {     // my part of unit P+2 landed, my reads of phase P-2 retired; then everyone's
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(%0)" ::"n"(LG) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // 8 phases = K-tiles t (even) and t + 1 (odd).  Slot = parity * 4 + e.  LAST (the output tile's final pair) leaves the
+    // two reads that belong to the next output tile's K-tile 0 to the caller (next_tile_reads, after the epilogue), so
+    // that the fragment registers are dead while the epilogue needs its own.
+    template <bool LAST>
+    __device__ __forceinline__ void two_tiles(int t, f32x4 (&acc)[8][4], bf16x8 (&ra)[8], bf16x8 (&rb0)[4], bf16x8 (&rb1)[4]) {
+        // ---- even tile: B-first = sub 0 (rb0), B-second = sub 1 (rb1)
+        fence<LG3>();  read_a<0, 1>(ra);  read_b<2>(rb1);  stage<1, 2>(t + 1);
+        mma<0, 0, 0>(acc, ra, rb0);  mma<0, 0, 1>(acc, ra, rb0);
+        fence<LG0>();  stage<1, 3>(t + 1);
+        mma<0, 1, 0>(acc, ra, rb1);  read_a<3, 0>(ra);  mma<0, 1, 1>(acc, ra, rb1);
+        fence<LG1>();  read_a<3, 1>(ra);  stage<0, 0>(t + 2);
+        mma<1, 1, 0>(acc, ra, rb1);  mma<1, 1, 1>(acc, ra, rb1);
+        fence<LG2>();  read_b<5>(rb1);  stage<0, 1>(t + 2);
+        mma<1, 0, 0>(acc, ra, rb0);  read_a<4, 0>(ra);  mma<1, 0, 1>(acc, ra, rb0);
+        // ---- odd tile: B-first = sub 1 (rb1), B-second = sub 0 (rb0)
+        fence<LG3>();  read_a<4, 1>(ra);  read_b<6>(rb0);  stage<0, 2>(t + 2);
+        mma<0, 1, 0>(acc, ra, rb1);  mma<0, 1, 1>(acc, ra, rb1);
+        fence<LG0>();  stage<0, 3>(t + 2);
+        mma<0, 0, 0>(acc, ra, rb0);  read_a<7, 0>(ra);  mma<0, 0, 1>(acc, ra, rb0);
+        fence<LG1>();  read_a<7, 1>(ra);  stage<1, 0>(t + 3);
+        mma<1, 0, 0>(acc, ra, rb0);  mma<1, 0, 1>(acc, ra, rb0);
+        fence<LG2>();  if (!LAST) read_b<1>(rb0);  stage<1, 1>(t + 3);
+        mma<1, 1, 0>(acc, ra, rb1);  if (!LAST) read_a<0, 0>(ra);  mma<1, 1, 1>(acc, ra, rb1);
+    }
+    __device__ __forceinline__ void next_tile_reads(bf16x8 (&ra)[8], bf16x8 (&rb0)[4]) {
+        read_b<1>(rb0);
+        read_a<0, 0>(ra);
+    }
+};
+
+// Persistent: gridDim.x = min(#CUs, tiles) workgroups, each walks tiles idx, idx + grid, ... ; the DMA stream runs 6
+// units ahead of the MFMAs and simply continues into the next tile, so the next tile's first K-tiles land while this
+// tile's epilogue runs.  XCD x (workgroups = x mod 8) takes a contiguous chunk of every round of tiles.
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G2_SMEM];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x, bid = blockIdx.x, ntiles = p.tiles_m * p.tiles_n;
+    const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
+    const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+
+    G2<A_KMAJOR, B_KMAJOR> g;
+    g.init(p, smem, tid);
+    g.cur = g.tile_desc(p, first, ntiles);
+    g.nxt = g.tile_desc(p, first + G, ntiles);
+    f32x4 acc[8][4];
+    bf16x8 ra[8], rb0[4], rb1[4];
+
+    // prologue: units 0..5 (K-tile 0 and the first half of K-tile 1), then the reads that precede phase 0
+    g.template stage<0, 0>(0); g.template stage<0, 1>(0); g.template stage<0, 2>(0); g.template stage<0, 3>(0);
+    g.template stage<1, 0>(1); g.template stage<1, 1>(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    g.template read_b<1>(rb0);
+    g.template read_a<0, 0>(ra);
+
+    for (int idx = first; idx < ntiles; idx += G) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < g.nk - 2; t += 2) g.template two_tiles<false>(t, acc, ra, rb0, rb1);
+        g.template two_tiles<true>(g.nk - 2, acc, ra, rb0, rb1);
+        const int m0 = g.cur.m0, n0 = g.cur.n0;
+        g.cur = g.nxt;
+        g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
+        epilogue_tile_tr<8>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, g.lane, smem + 8 * G2_UNIT + (g.wave_off << 2));
+        g.next_tile_reads(ra, rb0);      // units 0, 1 of the next tile landed before the last fence; same LGKM count as in-loop
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+void launch_g256(hipStream_t s, GemmParams p) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<A_KMAJOR, B_KMAJOR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, p);
+}
+
 // out[n] (+)= sum_m X[m][n]: 16-byte loads (8 columns per lane, 512 columns per wave-row), the 4 waves of a
 // workgroup stride the rows of its slice, LDS combine, one float atomic per column per workgroup.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
@@ -804,6 +1207,19 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
             else hipLaunchKernelGGL((gemm_dma_kernel<true, false, false>), grid, block, 0, s, p);
         }
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(dma)");
+        return I2T_OK;
+    }
+    // large-tile kernel for the non-split problems with enough 256^2 tiles to occupy the chip (I2T_GEMM=v1 keeps the 128^2 one)
+    static const bool no_g256 = sel && !strcmp(sel, "v1");
+    // K % 128 == 0: K-tiles run in pairs and the DMA stream chains output tiles; k-major panels must fit a 32-bit byte offset
+    const bool g256_ok = K % 128 == 0 && (!a_kmajor || (size_t)(K + 512) * lda * 2 < (1ull << 32)) &&
+                         (!b_kmajor || (size_t)(K + 512) * ldb * 2 < (1ull << 32));
+    if (splits == 1 && !no_g256 && g256_ok && !(a_kmajor && b_kmajor) /* that form spills at 256 VGPRs */ && (long)((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+        if (!a_kmajor && !b_kmajor) launch_g256<false, false>(s, p);
+        else if (!a_kmajor && b_kmajor) launch_g256<false, true>(s, p);
+        else if (a_kmajor && b_kmajor) launch_g256<true, true>(s, p);
+        else launch_g256<true, false>(s, p);
+        I2T_CHECK_LAUNCH("i2t_gemm_bf16(256)");
         return I2T_OK;
     }
     if (splits > 1) {

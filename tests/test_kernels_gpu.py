@@ -115,6 +115,56 @@ def test_gemm_vocab_shapes(ops):
     check('dW', dw, dl[:, :V].float().t() @ h.float(), 2e-3, 3e-3)
 
 
+@pytest.mark.parametrize('M,N,K', [(2560, 2560, 512), (2500, 2440, 768), (3000, 2304, 128), (2304, 4104, 1536)])
+@pytest.mark.parametrize('a_km,b_km', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_large_tile_layouts(ops, M, N, K, a_km, b_km):
+    """Shapes with >= 96 tiles of 256 x 256: the 8-wave large-tile kernel (ragged M / N edges, K = 2..24 K-tiles)."""
+    if (a_km and M % 8) or (b_km and N % 8):
+        pytest.skip('k-major operand needs a leading dimension padded to 8')
+    a = rnd(M, K, dtype=BF16, seed=21)
+    b = rnd(N, K, dtype=BF16, seed=22)
+    ref = a.float() @ b.float().t()
+    a_in = a.t().contiguous() if a_km else a
+    b_in = b.t().contiguous() if b_km else b
+    out = torch.full((M, N), float('nan'), dtype=F32, device=dev())
+    ops.gemm(a_in, b_in, out, M, N, K, a_kmajor=a_km, b_kmajor=b_km)
+    check(f'large gemm f32 {M}x{N}x{K} a_km={a_km} b_km={b_km}', out, ref, 2e-3 * math.sqrt(K) / 8, 2e-3)
+    for _ in range(3):          # the DMA pipeline has no data-dependent path: repeated launches must agree bit for bit
+        again = torch.empty(M, N, dtype=F32, device=dev())
+        ops.gemm(a_in, b_in, again, M, N, K, a_kmajor=a_km, b_kmajor=b_km)
+        assert torch.equal(again, out)
+
+
+def test_gemm_large_tile_epilogues(ops):
+    from image2text_amd import rng
+    M, N, K = 2900, 2304, 512
+    a, b = rnd(M, K, dtype=BF16, seed=23), rnd(N, K, dtype=BF16, seed=24, scale=0.1)
+    bias, res = rnd(N, seed=25), rnd(M, N, seed=26)
+    base = a.float() @ b.float().t()
+    out = torch.empty(M, N, dtype=BF16, device=dev())
+    pre = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M, N, K, bias=bias, act=1, aux_out=pre)
+    check('pre-activation', pre, base + bias, 1e-2, 1 / 128)
+    check('gelu(bias + ab)', out, F.gelu(base + bias, approximate='tanh'), 1e-2, 1 / 128)
+    key, thr = rng.site_key(5, 9), rng.threshold(0.1)
+    sc = rng.scale(thr)
+    o32 = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a, b, o32, M, N, K, alpha=0.5, bias=bias, residual=res, drop=(1, key, thr, sc))
+    m = rng.keep_mask(key, M * N, thr).view(M, N).to(dev())
+    check('alpha/bias/dropout/residual', o32, res + (0.5 * base + bias) * m * sc, 2e-3, 2e-3)
+    acc = res.clone()
+    ops.gemm(a, b, acc, M, N, K, accumulate=True)
+    check('accumulate', acc, base + res, 2e-3, 2e-3)
+    aux = rnd(M, N, dtype=BF16, seed=27)
+    od = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, od, M, N, K, act=2, aux_in=aux)
+    check('dgelu', od, base * gelu_grad(aux.float()), 2e-2, 1 / 128)
+    outq = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, outq, M, N, K, bias=bias, drop=(2, key, thr, sc))
+    mult = torch.stack([rng.keep_mask((key + t) & 0xFFFFFFFF, M, thr) for t in range(3)], 1).float().to(dev()) * sc
+    check('qkv multipliers', outq, (base + bias) * mult.repeat_interleave(N // 3, dim=1), 2e-2, 1 / 128)
+
+
 def test_colsum(ops):
     x = rnd(5000, 200, dtype=BF16, seed=11)
     out = torch.zeros(200, device=dev())
