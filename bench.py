@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM table on stderr (2 timed steps)')
     return ap.parse_args()
 
 
@@ -58,13 +59,32 @@ class GemmTimer:
             r = self.orig(a, b, out, M, N, K, **kw)
             e1.record(torch.cuda.current_stream())
             c_bytes = 4 if out.dtype == torch.float32 else 2
-            self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + c_bytes * M * N))
+            # algorithmic bytes: both operands once, C once, plus every epilogue operand the call names
+            extra = (4 if kw.get('residual') is not None else 0) + (4 if kw.get('accumulate') else 0) + \
+                    (2 if kw.get('aux_in') is not None else 0) + (2 if kw.get('aux_out') is not None else 0)
+            kind = ('A^T' if kw.get('a_kmajor') else 'A') + ('.B' if kw.get('b_kmajor') else '.B^T') + \
+                   (' f32' if c_bytes == 4 else ' bf16') + ('+res' if kw.get('residual') is not None else '') + \
+                   ('+acc' if kw.get('accumulate') else '') + {0: '', 1: '+gelu', 2: '+dgelu'}[int(kw.get('act', 0))] + \
+                   ('+drop' if kw.get('drop') is not None else '')
+            self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + (c_bytes + extra) * M * N, (M, N, K, kind)))
             return r
         self.ops.gemm = timed
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
+
+    def breakdown(self):
+        """Per (shape, layout, epilogue) table: launches, avg us, TFLOP/s, algorithmic TB/s."""
+        torch.cuda.synchronize()
+        g = {}
+        for e0, e1, fl, by, key in self.records:
+            t = g.setdefault(key, [0, 0.0, 0.0, 0.0])
+            t[0] += 1; t[1] += e0.elapsed_time(e1); t[2] += fl; t[3] += by
+        lines = []
+        for key, (n, ms, fl, by) in sorted(g.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f'{ms:8.3f} ms {n:4d}x avg {1e3 * ms / n:8.1f} us {fl / ms / 1e9:7.1f} TF {by / ms / 1e9:6.2f} TB/s  M={key[0]} N={key[1]} K={key[2]} {key[3]}')
+        return lines
 
     def summary(self):
         torch.cuda.synchronize()
@@ -192,6 +212,9 @@ def main():
             for _ in range(2):
                 step()
         gemm = gt.summary()
+        if args.gemm_breakdown and rank == 0:
+            for ln in gt.breakdown():
+                log(ln)
     fence()
 
     # ---- greedy decode: B captions x 64 new tokens per run (encoder + KV-cache decode under hipGraph replay)

@@ -271,7 +271,23 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
     return (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
            (!p.aux_out || (p.ld_aux_out & 3) == 0);
 }
+// EPI selects a compile-time epilogue class (the generic form keeps ~30 uniform values and every path alive: in the
+// 256^2 kernel that cost SGPR and VGPR spills whose serialized scratch reloads were ~10 us per tile):
+//   0 generic (all flags at run time)          1 bf16 C, optional bias, optional per-row/third dropout (mode 2)
+//   2 bf16 C, bias + GELU + pre-activation out  3 f32 C, optional bias, optional dropout (mode 1), + residual
+//   4 bf16 C, GELU' of aux_in                   5 f32 C accumulate
+template <int EPI>
 __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
+    constexpr bool GEN = EPI == 0;
+    const bool f_bias = (GEN || EPI == 1 || EPI == 3) ? (p.bias != nullptr) : (EPI == 2);
+    const bool f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
+    const bool f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
+    const bool f_auxout = GEN ? (p.aux_out != nullptr) : (EPI == 2);
+    const bool f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
+    const bool f_drop2 = (GEN || EPI == 1) ? (p.drop_mode == 2) : false;
+    const bool f_res = GEN ? (p.residual != nullptr) : (EPI == 3);
+    const bool f_acc = GEN ? (p.accumulate != 0) : (EPI == 5);
+    const bool f_f32 = GEN ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
     bool ok[4];
     int mc[4], nc[4];
 #pragma unroll
@@ -283,32 +299,32 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
     // one set of addend registers serves residual and accumulate (both at once is rare: the second then waits on the first)
     f32x4 v[4], bv[4], add[4];
     u32x2 ax[4];
-    if (p.bias) {
+    if (f_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nc[q]);
     }
-    if (p.act == I2T_ACT_DGELU) {
+    if (f_dgelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
     }
-    if (p.residual) {
+    if (f_res) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) add[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mc[q] * p.ldr + nc[q]);
     }
-    if (p.accumulate) {
+    if (f_acc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)mc[q] * p.ldc + nc[q]);
-            add[q] = p.residual ? add[q] + c : c;
+            add[q] = f_res ? add[q] + c : c;
         }
     }
-    const bool has_add = p.residual || p.accumulate;
+    const bool has_add = f_res || f_acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         v[q] = a[q] * p.alpha;
-        if (p.bias) v[q] += bv[q];
+        if (f_bias) v[q] += bv[q];
     }
-    if (p.aux_out) {
+    if (f_auxout) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (ok[q]) {
@@ -316,19 +332,19 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
                 *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]) = pk;
             }
     }
-    if (p.act == I2T_ACT_GELU) {
+    if (f_gelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = gelu_tanh(v[q][r]);
-    } else if (p.act == I2T_ACT_DGELU) {
+    } else if (f_dgelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             v[q][0] *= gelu_tanh_grad(bf16lo(ax[q][0])); v[q][1] *= gelu_tanh_grad(bf16hi(ax[q][0]));
             v[q][2] *= gelu_tanh_grad(bf16lo(ax[q][1])); v[q][3] *= gelu_tanh_grad(bf16hi(ax[q][1]));
         }
     }
-    if (p.drop_mode == 1) {
+    if (f_drop1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bool keep[4];
@@ -336,7 +352,7 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = keep[r] ? v[q][r] * p.drop_scale : 0.f;
         }
-    } else if (p.drop_mode == 2) {
+    } else if (f_drop2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned third = (unsigned)nc[q] / (unsigned)(p.N / 3);
@@ -347,7 +363,7 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += add[q];
     }
-    if (p.c_is_f32) {
+    if (f_f32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (ok[q]) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m[q] * p.ldc + n4[q]) = v[q];
@@ -377,7 +393,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
             const int m[4] = {mr, mr, mr, mr};
             const int n4[4] = {nbase + 4 * g, nbase + 16 + 4 * g, nbase + 32 + 4 * g, nbase + 48 + 4 * g};
             const f32x4 a[4] = {acc[i][0], acc[i][1 % NJ], acc[i][2 % NJ], acc[i][3 % NJ]};
-            epilogue_batch4(p, a, m, n4);
+            epilogue_batch4<0>(p, a, m, n4);
         });
         return;
     }
@@ -399,12 +415,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 // c = lane&15, so one store instruction covers 4 rows x 128 B (bf16) / 256 B (f32) of FULL cache lines instead of 16 rows
 // x 32 / 64 B.  Measured need (round 1, K sweep): the direct form cost a fixed ~18 us per 256^2 tile -- 16 distinct lines
 // per store instruction, row strides of 1-4 KiB camping on a few L2 channels.
-template <int MI>
+template <int MI, int EPI>
 __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int lane,
                                                  unsigned char* wave_lds) {
     const int g = lane >> 4, li = lane & 15;
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
-    const bool fast = epilogue_fast_ok(p);
+    const bool fast = EPI != 0 || epilogue_fast_ok(p);        // the launcher picks a specialised class only when fast_ok holds
     static_for<MI>([&](auto I_) {
         constexpr int i = decltype(I_)::value;
 #pragma unroll
@@ -420,8 +436,8 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
             n4[k] = nbase + 4 * li;
         }
         if (fast) {
-            epilogue_batch4(p, a, m, n4);
-        } else {
+            epilogue_batch4<EPI>(p, a, m, n4);
+        } else if constexpr (EPI == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (m[k] < p.M && n4[k] < p.N) epilogue_quad(p, a[k], m[k], n4[k], vec_ok);
@@ -517,8 +533,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// DMA-staged variant: operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
-// staging and no ds_write pass -- the v1 kernel spent more LDS cycles on ds_write_b128 than on fragment reads).
+// DMA-staged LDS images (used by the 256^2 kernel): operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB
+// per wave-instruction, no VGPR staging and no ds_write pass).
 // A DMA writes LDS linearly (wave-uniform base + lane * 16 B), so the conflict-avoiding permutation moves to the
 // per-lane SOURCE address and the fragment reads apply the same involution (cdna_hip_programming.md rule 21):
 //   R  image: [row][8 chunks of 16 B], chunk ^= row & 7                      (ds_read_b128, as before)
@@ -526,37 +542,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //             k-row: chunk ^= swz(k) << 1 with swz = k & 7 when both operands are k-major (a half-wave reads 8
 //             consecutive k-rows) and swz = (k & 3) | ((k >> 3) & 1) << 2 for the natural k order (rows {0-3, 8-11}):
 //             8 rows -> 8 disjoint 32-byte windows = all 64 banks.
-// Out-of-range chunks (M/N/K tails) are sourced from a 16-byte zero block instead of being predicated off.
-__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+// Out-of-range chunks (M/N/K tails) come back as zeros from the buffer descriptor's range check.
 
-constexpr int DMA_OPERAND_BYTES = 128 * 128;            // 16 KiB per operand tile
-constexpr int DMA_STAGE_BYTES = 2 * DMA_OPERAND_BYTES;
-constexpr int DMA_SMEM_BYTES = 2 * DMA_STAGE_BYTES;     // 64 KiB, double buffered
 
 template <bool PK>
 __device__ __forceinline__ int cf_swz(int kr) { return PK ? (kr & 7) : ((kr & 3) | (((kr >> 3) & 1) << 2)); }
-
-template <bool KMAJOR, bool PK>
-__device__ __forceinline__ void dma_stage(unsigned char* lds_op, const bf16_t* __restrict__ base, int ld, int row0, int rows,
-                                          int k0, int K, int tid, int wave) {
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int c = u * 256 + tid;
-        const bf16_t* src;
-        if (!KMAJOR) {
-            const int r = c >> 3, kc = (c & 7) ^ (r & 7);
-            const int gr = row0 + r, gk = k0 + kc * 8;
-            src = (gr < rows && gk < K) ? base + (size_t)gr * ld + gk : zero;
-        } else {
-            const int kr = c >> 4, rc = (c & 15) ^ (cf_swz<PK>(kr) << 1);
-            const int gk = k0 + kr, gr = row0 + rc * 8;
-            src = (gk < K && gr < rows) ? base + (size_t)gk * ld + gr : zero;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_op + (u * 256 + wave * 64) * 16), 16, 0, 0);
-    }
-}
 
 template <bool KMAJOR, bool PK>
 __device__ __forceinline__ bf16x8 dma_frag_read(const unsigned char* lds, int r0, int ks, int lane) {
@@ -573,200 +563,6 @@ __device__ __forceinline__ bf16x8 dma_frag_read(const unsigned char* lds, int r0
         s16x4 hi = lds_read_tr16(lds + kr1 * 256 + ((ch ^ (cf_swz<PK>(kr1) << 1)) << 4) + half);
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmParams p) {
-    constexpr bool PK = A_KMAJOR && B_KMAJOR;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[DMA_SMEM_BYTES];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    int tile_m, tile_n;
-    tile_coords(p, swz, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
-    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
-    const int nk_all = (p.K + BK - 1) / BK;
-    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
-    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
-    const int nk = min(nk_per, nk_all - kt0);
-    if (nk <= 0) return;
-
-    dma_stage<A_KMAJOR, PK>(smem, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid, wave);
-    dma_stage<B_KMAJOR, PK>(smem + DMA_OPERAND_BYTES, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid, wave);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* la = smem + (t & 1) * DMA_STAGE_BYTES;
-        const unsigned char* lb = la + DMA_OPERAND_BYTES;
-        if (t + 1 < nk) {
-            unsigned char* na = smem + ((t + 1) & 1) * DMA_STAGE_BYTES;
-            dma_stage<A_KMAJOR, PK>(na, p.A, p.lda, m0, a_rows, (kt0 + t + 1) * BK, p.K, tid, wave);
-            dma_stage<B_KMAJOR, PK>(na + DMA_OPERAND_BYTES, p.B, p.ldb, n0, b_rows, (kt0 + t + 1) * BK, p.K, tid, wave);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = dma_frag_read<A_KMAJOR, PK>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = dma_frag_read<B_KMAJOR, PK>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();      // drains this wave's DMA (vmcnt(0)) and fences the buffer swap
-    }
-    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
-}
-
-
-// ----------------------------------------------------------------------------------------------------------------
-// Multi-stage DMA pipeline (the production kernel).  In the training step the operands are COLD (just written by the
-// previous kernel, far beyond L2), so a one-tile-ahead prefetch leaves every K-step waiting a full HBM round trip:
-// the [8192 x 768 x 768] projections ran at 4 us per K-step (200 TFLOP/s) with ~0.25 us of MFMA work in it.  Here
-// NS - 1 tiles of global_load_lds are kept in flight across K-steps: counted `s_waitcnt vmcnt(N)` (never 0 in the
-// steady state) + a raw s_barrier, so the DMA of tiles t+1 .. t+NS-2 stays outstanding while tile t is computed
-// (cdna_hip_programming.md 5, "Pipelining across barriers").  All LDS lives in one __shared__ array.
-//   BKT = 64: 8-chunk rows, swizzle chunk ^= row & 7;   BKT = 32: 4-chunk rows, chunk ^= (-(row >> 2)) & 3
-//   (both conflict-free for the ds_read_b128 lane groups);  Cf images as in the 2-stage kernel.
-template <int BKT>
-__device__ __forceinline__ int r_swz(int r) { return BKT == 64 ? (r & 7) : ((-(r >> 2)) & 3); }
-
-template <bool KMAJOR, bool PK, int BKT>
-__device__ __forceinline__ void pipe_stage(unsigned char* lds_op, const bf16_t* __restrict__ base, int ld, int row0, int rows,
-                                           int k0, int K, int tid, int wave) {
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
-    constexpr int CPT = BKT / 16;                 // 16-byte chunks per thread per operand tile
-    constexpr int CPR = BKT / 8;                  // chunks per row of the R image
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-        const int c = u * 256 + tid;
-        const bf16_t* src;
-        if (!KMAJOR) {
-            const int r = c / CPR, kc = (c % CPR) ^ r_swz<BKT>(r);
-            const int gr = row0 + r, gk = k0 + kc * 8;
-            src = (gr < rows && gk < K) ? base + (size_t)gr * ld + gk : zero;
-        } else {
-            const int kr = c >> 4, rc = (c & 15) ^ (cf_swz<PK>(kr) << 1);
-            const int gk = k0 + kr, gr = row0 + rc * 8;
-            src = (gk < K && gr < rows) ? base + (size_t)gk * ld + gr : zero;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_op + (u * 256 + wave * 64) * 16), 16, 0, 0);
-    }
-}
-
-template <bool KMAJOR, bool PK, int BKT>
-__device__ __forceinline__ bf16x8 pipe_frag_read(const unsigned char* lds, int r0, int ks, int lane) {
-    const int g = lane >> 4, i = lane & 15;
-    if (!KMAJOR) {
-        const int r = r0 + i, kc = ks * 4 + g;
-        u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * (BKT * 2) + ((kc ^ r_swz<BKT>(r)) << 4));
-        return __builtin_bit_cast(bf16x8, v);
-    } else {
-        return dma_frag_read<true, PK>(lds, r0, ks, lane);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <bool A_KMAJOR, bool B_KMAJOR, bool SPLITK, int BKT, int NS>
-__global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmParams p) {
-    constexpr bool PK = A_KMAJOR && B_KMAJOR;
-    constexpr int OPB = 128 * BKT * 2;            // bytes per operand tile
-    constexpr int STG = 2 * OPB;
-    constexpr int PER_TILE = 2 * (BKT / 16);      // DMA instructions per thread per K-tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STG];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    int tile_m, tile_n;
-    tile_coords(p, swz, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int a_rows = A_KMAJOR ? ((p.M + 7) & ~7) : p.M;
-    const int b_rows = B_KMAJOR ? ((p.N + 7) & ~7) : p.N;
-    const int nk_all = (p.K + BKT - 1) / BKT;
-    const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
-    const int kt0 = SPLITK ? (int)blockIdx.y * nk_per : 0;
-    const int nk = min(nk_per, nk_all - kt0);
-    if (nk <= 0) return;
-
-    // prologue: tiles 0 .. NS-2 in flight (tiles past the end are issued as zero tiles so that the counted waits stay exact)
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t) {
-        unsigned char* st = smem + t * STG;
-        const int kk = (t < nk) ? (kt0 + t) * BKT : p.K;      // k >= K -> every chunk comes from the zero block
-        pipe_stage<A_KMAJOR, PK, BKT>(st, p.A, p.lda, m0, a_rows, kk, p.K, tid, wave);
-        pipe_stage<B_KMAJOR, PK, BKT>(st + OPB, p.B, p.ldb, n0, b_rows, kk, p.K, tid, wave);
-    }
-    for (int t = 0; t < nk; ++t) {
-        wait_vmcnt<PER_TILE * (NS - 2)>();        // tile t has landed (this wave's share); younger tiles stay in flight
-        __builtin_amdgcn_s_barrier();             // everyone's share landed; everyone is done with stage (t-1) % NS
-        {
-            const int tn = t + NS - 1;
-            unsigned char* st = smem + (tn % NS) * STG;
-            const int kk = (tn < nk) ? (kt0 + tn) * BKT : p.K;
-            pipe_stage<A_KMAJOR, PK, BKT>(st, p.A, p.lda, m0, a_rows, kk, p.K, tid, wave);
-            pipe_stage<B_KMAJOR, PK, BKT>(st + OPB, p.B, p.ldb, n0, b_rows, kk, p.K, tid, wave);
-        }
-        const unsigned char* la = smem + (t % NS) * STG;
-        const unsigned char* lb = la + OPB;
-#pragma unroll
-        for (int ks = 0; ks < BKT / 32; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = pipe_frag_read<A_KMAJOR, PK, BKT>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = pipe_frag_read<B_KMAJOR, PK, BKT>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = SPLITK ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    wait_vmcnt<0>();                              // the trailing zero tiles
-    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
-}
-
-template <int BKT, int NS>
-void launch_pipe(hipStream_t s, dim3 grid, const GemmParams& p, int a_kmajor, int b_kmajor, bool splitk) {
-    dim3 block(256);
-    if (splitk) {
-        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, true, BKT, NS>), grid, block, 0, s, p);
-        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, true, BKT, NS>), grid, block, 0, s, p);
-        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, true, BKT, NS>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((gemm_pipe_kernel<true, false, true, BKT, NS>), grid, block, 0, s, p);
-    } else {
-        if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, false, BKT, NS>), grid, block, 0, s, p);
-        else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, false, BKT, NS>), grid, block, 0, s, p);
-        else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, false, BKT, NS>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((gemm_pipe_kernel<true, false, false, BKT, NS>), grid, block, 0, s, p);
     }
 }
 
@@ -812,8 +608,12 @@ struct G2 {
     static constexpr int cap(int n) { return n > 15 ? 15 : n; }
     static constexpr int LG0 = cap(4 * FA + 4 * FB), LG1 = cap(4 * FA), LG2 = cap(4 * FA), LG3 = cap(4 * FA + 4 * FB);
 
+    // Physical placement of slot PAR*4 + e: the A units in 16-KiB slots 0-3, the B units in 4-7, so that every A read is
+    // base + immediate (< 64 KiB, the ds offset field) and every B read is (base + 64 KiB) + immediate: 2 + 2 address
+    // VGPRs instead of 4 + 4 (three spilled address registers cost a vmcnt(0) drain per K-loop iteration).
+    static constexpr int phys(int slot) { return ((slot & 3) == 0 || (slot & 3) == 3) ? (slot >> 2) * 2 + ((slot & 3) == 3) : 4 + (slot >> 2) * 2 + ((slot & 3) == 2); }
     unsigned char* smem;
-    int lane, wr, wc, wave_off, nk;
+    int lane, wr, wc, wave_off, nk, tb;
     int va[2][2], vb[2][2];          // voffset[sub][chunk]
     unsigned step_a, step_b;         // bytes per K-tile
     G2Tile cur, nxt;                 // the tile being computed and the one whose first units are already being staged
@@ -845,12 +645,26 @@ struct G2 {
     }
 
     __device__ __forceinline__ void init(const GemmParams& p, unsigned char* smem_, int tid) {
-        smem = smem_; lane = tid & 63;
+        smem = smem_;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         wr = wave >> 2; wc = wave & 3; wave_off = wave * 1024;
         nk = (p.K + 63) >> 6;
         step_a = A_KMAJOR ? 128u * (unsigned)p.lda : 128u;
         step_b = B_KMAJOR ? 128u * (unsigned)p.ldb : 128u;
+        init_lane(p, tid);
+    }
+    // Per-lane K-loop state (DMA voffsets; the fragment read addresses derive from `lane`).  Recomputed after every
+    // epilogue from a LAUNDERED thread id, so that it is not live while the epilogue needs the registers (and the
+    // epilogue's own per-lane constants are not live across the K loop): kept live, the two sets spilled to scratch
+    // and every tile paid ~10 us of serialized scratch reloads.
+    __device__ __forceinline__ void init_lane(const GemmParams& p, int tid) {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        {   // base of the k-major B transposed reads (read_b): k-row 8 g + q, swizzled chunk of columns wc*32 + 4 (i & 3)
+            const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            const int kr = 8 * g4 + q;
+            tb = kr * 256 + ((((wc * 4) + (pp >> 1)) ^ (cf_swz<false>(kr) << 1)) << 4) + (pp & 1) * 8;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -877,7 +691,7 @@ struct G2 {
     // T >= nk continues into the NEXT output tile (nk is even, so slot parities carry over): no pipeline drain between tiles.
     template <int PAR, int E>
     __device__ __forceinline__ void stage(int T) {
-        unsigned char* slot = smem + (PAR * 4 + E) * G2_UNIT + wave_off;
+        unsigned char* slot = smem + phys(PAR * 4 + E) * G2_UNIT + wave_off;
         constexpr int sub = (E == 0) ? 0 : (E == 3) ? 1 : (E == 1) ? PAR : (PAR ^ 1);
         const bool nx = T >= nk;
         const int Te = nx ? T - nk : T;
@@ -896,14 +710,29 @@ struct G2 {
     template <int SLOT, int KS>
     __device__ __forceinline__ void read_a(bf16x8 (&ra)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<A_KMAJOR, PK>(smem + SLOT * G2_UNIT, wr * 64 + i * 16, KS, lane);
+        for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<A_KMAJOR, PK>(smem + phys(SLOT) * G2_UNIT, wr * 64 + i * 16, KS, lane);
     }
     template <int SLOT>
     __device__ __forceinline__ void read_b(bf16x8 (&rb)[4]) {
+        if constexpr (B_KMAJOR && !PK) {
+            // k-major B, natural k order: the XOR swizzle of a lane's chunk does not depend on ks or on the lo/hi half, and
+            // fragment j only flips chunk bit 1, so every address is (tb ^ (j << 5)) + immediate -- written that way the
+            // 8 transposed reads share one VGPR (as "(ch ^ swz) << 4" per fragment hipcc kept 16 and spilled in the K loop)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) rb[ks * 2 + j] = dma_frag_read<B_KMAJOR, PK>(smem + SLOT * G2_UNIT, wc * 32 + j * 16, ks, lane);
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* a = smem + phys(SLOT) * G2_UNIT + ks * 8192 + (tb ^ (j << 5));
+                    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 1024);
+                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    rb[ks * 2 + j] = __builtin_bit_cast(bf16x8, v);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rb[ks * 2 + j] = dma_frag_read<B_KMAJOR, PK>(smem + phys(SLOT) * G2_UNIT, wc * 32 + j * 16, ks, lane);
+        }
     }
     template <int SUBA, int SUBB, int KS>
     __device__ __forceinline__ void mma(f32x4 (&acc)[8][4], const bf16x8 (&ra)[8], const bf16x8 (&rb)[4]) {
@@ -953,7 +782,7 @@ struct G2 {
 // Persistent: gridDim.x = min(#CUs, tiles) workgroups, each walks tiles idx, idx + grid, ... ; the DMA stream runs 6
 // units ahead of the MFMAs and simply continues into the next tile, so the next tile's first K-tiles land while this
 // tile's epilogue runs.  XCD x (workgroups = x mod 8) takes a contiguous chunk of every round of tiles.
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G2_SMEM];
     const int tid = threadIdx.x;
@@ -986,13 +815,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int m0 = g.cur.m0, n0 = g.cur.n0;
         g.cur = g.nxt;
         g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
-        epilogue_tile_tr<8>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, g.lane, smem + 8 * G2_UNIT + (g.wave_off << 2));
+        {
+            int lane_e = tid & 63;
+            asm volatile("" : "+v"(lane_e));
+            epilogue_tile_tr<8, EPI>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+        }
+        g.init_lane(p, tid);
         g.next_tile_reads(ra, rb0);      // units 0, 1 of the next tile landed before the last fence; same LGKM count as in-loop
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+int g256_epilogue_class(const GemmParams& p) {
+    const bool fast = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
+                      (!p.aux_out || (p.ld_aux_out & 3) == 0);
+    if (!fast) return 0;
+    const bool none = p.act == I2T_ACT_NONE && !p.aux_out;
+    if (!p.c_is_f32 && none && !p.residual && !p.accumulate && p.drop_mode != 1) return 1;
+    if (!p.c_is_f32 && p.bias && p.act == I2T_ACT_GELU && p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 2;
+    if (p.c_is_f32 && none && p.residual && !p.accumulate && p.drop_mode != 2) return 3;
+    if (!p.c_is_f32 && p.act == I2T_ACT_DGELU && !p.bias && !p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 4;
+    if (p.c_is_f32 && none && p.accumulate && !p.bias && !p.residual && !p.drop_mode) return 5;
+    return 0;
+}
+
+template <bool B_KMAJOR>
 void launch_g256(hipStream_t s, GemmParams p) {
     static int n_cu = 0;
     if (!n_cu) {
@@ -1002,7 +849,16 @@ void launch_g256(hipStream_t s, GemmParams p) {
     }
     p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm256_kernel<A_KMAJOR, B_KMAJOR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, p);
+    const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
+    // forward GEMMs (B^T form) meet classes 1-3, the dX GEMMs (B form) classes 1, 4, 5; anything else runs the generic one
+    switch (g256_epilogue_class(p)) {
+        case 1: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 1>), grid, block, 0, s, p); break;
+        case 2: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, s, p); break; }
+        case 3: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 3>), grid, block, 0, s, p); break; }
+        case 4: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p); break; }
+        case 5: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 5>), grid, block, 0, s, p); break; }
+        default: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
+    }
 }
 
 // out[n] (+)= sum_m X[m][n]: 16-byte loads (8 columns per lane, 512 columns per wave-row), the 4 waves of a
@@ -1174,51 +1030,15 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
     }
-    // Kernel selection (measured on MI355X, nano-224 shapes, round 1): the register-staged 2-stage kernel (v1) and the
-    // 2-stage DMA kernel tie (3046 vs 2993 images/s end to end); the deeper DMA pipelines lose (64x3: 2290, 32x4: 2721,
-    // 32x3: 2918) because they cut residency to 1-2 workgroups per CU on K = 512..768 problems that are only 8-12
-    // K-steps long.  v1 is the default; I2T_GEMM=dma|64x3|32x4|32x3 selects the others for A/B runs.
     static const char* sel = getenv("I2T_GEMM");
-    static const bool use_v1 = !sel || !strcmp(sel, "v1");
-    static const int pipe_mode = !sel ? 0 : (!strcmp(sel, "64x3") ? 1 : (!strcmp(sel, "32x4") ? 2 : (!strcmp(sel, "32x3") ? 3 :
-                                 (!strcmp(sel, "32x2") ? 4 : (!strcmp(sel, "64x2") ? 5 : 0)))));
-    if (!use_v1 && pipe_mode) {
-        // the split heuristic counts 64-deep K-steps; the kernels derive their own step count from BKT
-        if (splits > 1) grid.y = splits;
-        if (pipe_mode == 1) launch_pipe<64, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        else if (pipe_mode == 2) launch_pipe<32, 4>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        else if (pipe_mode == 3) launch_pipe<32, 3>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        else if (pipe_mode == 4) launch_pipe<32, 2>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        else launch_pipe<64, 2>(s, grid, p, a_kmajor, b_kmajor, splits > 1);
-        I2T_CHECK_LAUNCH("i2t_gemm_bf16(pipe)");
-        return I2T_OK;
-    }
-    if (!use_v1) {
-        if (splits > 1) {
-            grid.y = splits;
-            if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, false, true>), grid, block, 0, s, p);
-            else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, true, true>), grid, block, 0, s, p);
-            else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<true, true, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_dma_kernel<true, false, true>), grid, block, 0, s, p);
-        } else {
-            if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, false, false>), grid, block, 0, s, p);
-            else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<false, true, false>), grid, block, 0, s, p);
-            else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_dma_kernel<true, true, false>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_dma_kernel<true, false, false>), grid, block, 0, s, p);
-        }
-        I2T_CHECK_LAUNCH("i2t_gemm_bf16(dma)");
-        return I2T_OK;
-    }
     // large-tile kernel for the non-split problems with enough 256^2 tiles to occupy the chip (I2T_GEMM=v1 keeps the 128^2 one)
     static const bool no_g256 = sel && !strcmp(sel, "v1");
     // K % 128 == 0: K-tiles run in pairs and the DMA stream chains output tiles; k-major panels must fit a 32-bit byte offset
     const bool g256_ok = K % 128 == 0 && (!a_kmajor || (size_t)(K + 512) * lda * 2 < (1ull << 32)) &&
                          (!b_kmajor || (size_t)(K + 512) * ldb * 2 < (1ull << 32));
-    if (splits == 1 && !no_g256 && g256_ok && !(a_kmajor && b_kmajor) /* that form spills at 256 VGPRs */ && (long)((M + 255) / 256) * ((N + 255) / 256) >= 96) {
-        if (!a_kmajor && !b_kmajor) launch_g256<false, false>(s, p);
-        else if (!a_kmajor && b_kmajor) launch_g256<false, true>(s, p);
-        else if (a_kmajor && b_kmajor) launch_g256<true, true>(s, p);
-        else launch_g256<true, false>(s, p);
+    if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+        if (b_kmajor) launch_g256<true>(s, p);
+        else launch_g256<false>(s, p);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(256)");
         return I2T_OK;
     }
