@@ -51,6 +51,7 @@ struct GemmParams {
     int drop_mode;            // 0 none | 1 elementwise (idx = m*N + n) | 2 per (row, third of N) -- the q/k/v token multipliers
     unsigned drop_key, drop_thr;
     float drop_scale;
+    int g2_splits, g2_nk;     // 256^2 kernel: K slices per output tile and K-tiles per slice (even)
 };
 
 // Tile order inside an XCD's contiguous chunk of the grid.  PMC (round 1, B = 256): with M fastest the GEMM family moved
@@ -598,10 +599,10 @@ struct G2Tile {                       // wave-uniform description of one output 
     const bf16_t* a;
     const bf16_t* b;
     unsigned a_bytes, b_bytes;
-    int m0, n0;
+    int m0, n0, t0;                   // t0: first K-tile of this work item's K slice
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool UNSWAP = false>
 struct G2 {
     static constexpr bool PK = A_KMAJOR && B_KMAJOR;
     static constexpr int FA = A_KMAJOR ? 2 : 1, FB = B_KMAJOR ? 2 : 1;      // LGKM ops per fragment read
@@ -613,19 +614,23 @@ struct G2 {
     // VGPRs instead of 4 + 4 (three spilled address registers cost a vmcnt(0) drain per K-loop iteration).
     static constexpr int phys(int slot) { return ((slot & 3) == 0 || (slot & 3) == 3) ? (slot >> 2) * 2 + ((slot & 3) == 3) : 4 + (slot >> 2) * 2 + ((slot & 3) == 2); }
     unsigned char* smem;
-    int lane, wr, wc, wave_off, nk, tb;
+    int lane, wr, wc, wave_off, nk, tb, ta;
     int va[2][2], vb[2][2];          // voffset[sub][chunk]
     unsigned step_a, step_b;         // bytes per K-tile
+    unsigned lds0;                   // LDS byte address of smem
     G2Tile cur, nxt;                 // the tile being computed and the one whose first units are already being staged
 
     __device__ __forceinline__ static G2Tile tile_desc(const GemmParams& p, int idx, int ntiles) {
         G2Tile d;
         if (idx >= ntiles) {           // past the end: zero-sized panels, every DMA returns zeros
-            d.a = p.A; d.b = p.B; d.a_bytes = 0; d.b_bytes = 0; d.m0 = 0; d.n0 = 0;
+            d.a = p.A; d.b = p.B; d.a_bytes = 0; d.b_bytes = 0; d.m0 = 0; d.n0 = 0; d.t0 = 0;
             return d;
         }
+        // work item = (K slice, output tile), slice-major: an XCD's contiguous chunk of items shares its slice of A and B
+        const int tiles = p.tiles_m * p.tiles_n, slice = idx / tiles;
+        d.t0 = slice * p.g2_nk;
         int tile_m, tile_n;
-        tile_coords(p, idx, tile_m, tile_n, 8);
+        tile_coords(p, idx - slice * tiles, tile_m, tile_n, 8);
         d.m0 = tile_m * 256; d.n0 = tile_n * 256;
         if (!A_KMAJOR) {
             d.a = p.A + (size_t)d.m0 * p.lda;
@@ -646,9 +651,10 @@ struct G2 {
 
     __device__ __forceinline__ void init(const GemmParams& p, unsigned char* smem_, int tid) {
         smem = smem_;
+        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         wr = wave >> 2; wc = wave & 3; wave_off = wave * 1024;
-        nk = (p.K + 63) >> 6;
+        nk = p.g2_nk;
         step_a = A_KMAJOR ? 128u * (unsigned)p.lda : 128u;
         step_b = B_KMAJOR ? 128u * (unsigned)p.ldb : 128u;
         init_lane(p, tid);
@@ -660,10 +666,11 @@ struct G2 {
     __device__ __forceinline__ void init_lane(const GemmParams& p, int tid) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
-        {   // base of the k-major B transposed reads (read_b): k-row 8 g + q, swizzled chunk of columns wc*32 + 4 (i & 3)
+        {   // bases of the k-major transposed reads: k-row (8 or, permuted order, 4) g + q, swizzled chunk of the wave's columns
             const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-            const int kr = 8 * g4 + q;
-            tb = kr * 256 + ((((wc * 4) + (pp >> 1)) ^ (cf_swz<false>(kr) << 1)) << 4) + (pp & 1) * 8;
+            const int kr = (PK ? 4 : 8) * g4 + q;
+            tb = kr * 256 + ((((wc * 4) + (pp >> 1)) ^ (cf_swz<PK>(kr) << 1)) << 4) + (pp & 1) * 8;
+            ta = kr * 256 + ((((wr * 8) + (pp >> 1)) ^ (cf_swz<PK>(kr) << 1)) << 4) + (pp & 1) * 8;
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -689,32 +696,47 @@ struct G2 {
 
     // unit e (0 A-sub0 | 1 B-first | 2 B-second | 3 A-sub1) of K-tile T, whose parity is PAR -> slot PAR*4 + e.
     // T >= nk continues into the NEXT output tile (nk is even, so slot parities carry over): no pipeline drain between tiles.
+    // The DMA is issued from inline asm ON PURPOSE: hipcc orders a builtin LDS-DMA against later LDS reads it cannot
+    // disambiguate -- the transposed-read intrinsics -- with s_waitcnt vmcnt(0), which drained the pipeline 3-4 times per
+    // 8 phases in every k-major variant.  All ordering of these loads is done by hand (fence(), the prologue, the final
+    // vmcnt(0)); the compiler's own vmcnt waits for its epilogue loads stay correct, older or younger DMAs only make them
+    // wait longer.  M0 = LDS byte address of the wave's 1 KiB piece (wave-uniform base + lane * 16).
+    __device__ __forceinline__ void dma2(const bf16_t* base, unsigned bytes, unsigned lds_addr, int v0, int v1, unsigned so) {
+        const unsigned long long b = (unsigned long long)base;
+        const u32x4 rs = {(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %2, %4, %5 offen lds\n\t"
+                     "s_mov_b32 m0, %1\n\tbuffer_load_dwordx4 %3, %4, %5 offen lds"
+                     ::"s"(lds_addr), "s"(lds_addr + 8192u), "v"(v0), "v"(v1), "s"(rs), "s"(so) : "memory");
+    }
     template <int PAR, int E>
     __device__ __forceinline__ void stage(int T) {
-        unsigned char* slot = smem + phys(PAR * 4 + E) * G2_UNIT + wave_off;
+        const unsigned slot = lds0 + phys(PAR * 4 + E) * G2_UNIT + wave_off;
         constexpr int sub = (E == 0) ? 0 : (E == 3) ? 1 : (E == 1) ? PAR : (PAR ^ 1);
         const bool nx = T >= nk;
         const int Te = nx ? T - nk : T;
-        if (E == 0 || E == 3) {
-            const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? nxt.a : cur.a), 0, nx ? nxt.a_bytes : cur.a_bytes, 0x00020000);
-            const unsigned so = (unsigned)Te * step_a;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot), 16, va[sub][0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot + 8192), 16, va[sub][1], so, 0, 0);
-        } else {
-            const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? nxt.b : cur.b), 0, nx ? nxt.b_bytes : cur.b_bytes, 0x00020000);
-            const unsigned so = (unsigned)Te * step_b;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot), 16, vb[sub][0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (lds_ptr_t)(slot + 8192), 16, vb[sub][1], so, 0, 0);
-        }
+        if (E == 0 || E == 3)
+            dma2(nx ? nxt.a : cur.a, nx ? nxt.a_bytes : cur.a_bytes, slot, va[sub][0], va[sub][1], (unsigned)(Te + (nx ? nxt.t0 : cur.t0)) * step_a);
+        else
+            dma2(nx ? nxt.b : cur.b, nx ? nxt.b_bytes : cur.b_bytes, slot, vb[sub][0], vb[sub][1], (unsigned)(Te + (nx ? nxt.t0 : cur.t0)) * step_b);
     }
     template <int SLOT, int KS>
     __device__ __forceinline__ void read_a(bf16x8 (&ra)[8]) {
+        if constexpr (A_KMAJOR) {        // as read_b: fragment i flips chunk bits 1-2, the second half sits 4 (16 if permuted) k-rows on
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<A_KMAJOR, PK>(smem + phys(SLOT) * G2_UNIT, wr * 64 + i * 16, KS, lane);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* a = smem + phys(SLOT) * G2_UNIT + KS * 8192 + (ta ^ (i << 5));
+                const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + (PK ? 4096 : 1024));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                ra[KS * 4 + i] = __builtin_bit_cast(bf16x8, v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<A_KMAJOR, PK>(smem + phys(SLOT) * G2_UNIT, wr * 64 + i * 16, KS, lane);
+        }
     }
     template <int SLOT>
     __device__ __forceinline__ void read_b(bf16x8 (&rb)[4]) {
-        if constexpr (B_KMAJOR && !PK) {
+        if constexpr (B_KMAJOR) {
             // k-major B, natural k order: the XOR swizzle of a lane's chunk does not depend on ks or on the lo/hi half, and
             // fragment j only flips chunk bit 1, so every address is (tb ^ (j << 5)) + immediate -- written that way the
             // 8 transposed reads share one VGPR (as "(ch ^ swz) << 4" per fragment hipcc kept 16 and spilled in the K loop)
@@ -723,7 +745,7 @@ struct G2 {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const unsigned char* a = smem + phys(SLOT) * G2_UNIT + ks * 8192 + (tb ^ (j << 5));
-                    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 1024);
+                    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + (PK ? 4096 : 1024));
                     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     rb[ks * 2 + j] = __builtin_bit_cast(bf16x8, v);
                 }
@@ -740,8 +762,9 @@ struct G2 {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[SUBA * 4 + i][SUBB * 2 + j] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
+                acc[SUBA * 4 + i][SUBB * 2 + j] =     // UNSWAP (atomic epilogue): lane holds C[4 (lane>>4) + r][lane&15] of each 16 x 16 block
+                    UNSWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[KS * 4 + i], rb[KS * 2 + j], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
     }
     template <int LG>
     __device__ __forceinline__ void fence() {     // my part of unit P+2 landed, my reads of phase P-2 retired; then everyone's
@@ -786,11 +809,11 @@ template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G2_SMEM];
     const int tid = threadIdx.x;
-    const int G = gridDim.x, bid = blockIdx.x, ntiles = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x, ntiles = p.tiles_m * p.tiles_n * p.g2_splits;      // work items
     const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
     const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 
-    G2<A_KMAJOR, B_KMAJOR> g;
+    G2<A_KMAJOR, B_KMAJOR, EPI == 6> g;
     g.init(p, smem, tid);
     g.cur = g.tile_desc(p, first, ntiles);
     g.nxt = g.tile_desc(p, first + G, ntiles);
@@ -815,7 +838,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int m0 = g.cur.m0, n0 = g.cur.n0;
         g.cur = g.nxt;
         g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
-        {
+        if constexpr (EPI == 6) {        // split-K partial: fp32 atomics, one wave-instruction = 4 rows x 64 contiguous bytes
+            int lane_e = tid & 63;
+            asm volatile("" : "+v"(lane_e));
+            float* C = reinterpret_cast<float*>(p.C);
+            const int mb = m0 + g.wr * 128 + 4 * (lane_e >> 4), n_ = n0 + g.wc * 64 + (lane_e & 15);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb + i * 16 + r, n = n_ + j * 16;
+                        if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                    }
+        } else {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
             epilogue_tile_tr<8, EPI>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
@@ -839,15 +876,21 @@ int g256_epilogue_class(const GemmParams& p) {
     return 0;
 }
 
-template <bool B_KMAJOR>
-void launch_g256(hipStream_t s, GemmParams p) {
+int g256_cus() {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
         hipDeviceProp_t prop;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
+    return n_cu;
+}
+
+template <bool B_KMAJOR>
+void launch_g256(hipStream_t s, GemmParams p) {
+    const int n_cu = g256_cus();
     p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+    p.g2_splits = 1; p.g2_nk = (((p.K + 63) >> 6) + 1) & ~1;
     const int tiles = p.tiles_m * p.tiles_n;
     const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
     // forward GEMMs (B^T form) meet classes 1-3, the dX GEMMs (B form) classes 1, 4, 5; anything else runs the generic one
@@ -859,6 +902,30 @@ void launch_g256(hipStream_t s, GemmParams p) {
         case 5: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 5>), grid, block, 0, s, p); break; }
         default: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
     }
+}
+
+// dW = A^T . B accumulated into an fp32 C (both operands k-major): K slices spread over the CUs when the output has too
+// few 256^2 tiles, partial tiles combined with float atomics (C already holds the value to accumulate onto); with enough
+// tiles (the tied lm_head / embedding gradient) one slice and a plain read-add-write epilogue.
+bool launch_g256_dw(hipStream_t s, GemmParams p) {
+    const int n_cu = g256_cus();
+    p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+    const int tiles = p.tiles_m * p.tiles_n, nk_all = (p.K + 63) >> 6;
+    if (tiles >= n_cu) {
+        if (g256_epilogue_class(p) != 5) return false;
+        p.g2_splits = 1; p.g2_nk = (nk_all + 1) & ~1;
+        hipLaunchKernelGGL((gemm256_kernel<true, true, 5>), dim3(n_cu), dim3(512), 0, s, p);
+        return true;
+    }
+    int splits = n_cu / tiles;
+    int per = ((nk_all + splits - 1) / splits + 1) & ~1;          // even number of K-tiles per slice
+    if (per < 8) per = 8;
+    splits = (nk_all + per - 1) / per;
+    if (splits < 2) return false;
+    p.g2_splits = splits; p.g2_nk = per;
+    const int items = tiles * splits;
+    hipLaunchKernelGGL((gemm256_kernel<true, true, 6>), dim3(items < n_cu ? items : n_cu), dim3(512), 0, s, p);
+    return true;
 }
 
 // out[n] (+)= sum_m X[m][n]: 16-byte loads (8 columns per lane, 512 columns per wave-row), the 4 waves of a
@@ -999,6 +1066,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
+    p.g2_splits = 1; p.g2_nk = 0;
     I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
@@ -1021,6 +1089,16 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(skinny)");
         return I2T_OK;
     }
+    static const char* sel = getenv("I2T_GEMM");
+    static const bool no_g256 = sel && !strcmp(sel, "v1");
+    const bool kmaj_fits = (size_t)(K + 512) * lda * 2 < (1ull << 32) && (size_t)(K + 512) * ldb * 2 < (1ull << 32);
+    if (!no_g256 && a_kmajor && b_kmajor && accumulate && c_is_f32 && !bias && act == I2T_ACT_NONE && !aux_out && !residual &&
+        !drop_mode && kmaj_fits && M >= 256 && N >= 256 && (ldc & 3) == 0 && (N & 3) == 0) {
+        if (launch_g256_dw(s, p)) {
+            I2T_CHECK_LAUNCH("i2t_gemm_bf16(256 dW)");
+            return I2T_OK;
+        }
+    }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     // split-K for accumulate-into-fp32 problems whose tile grid cannot fill the 256 CUs (the dW = dY^T.X GEMMs: small
     // M x N, very long K): enough slices to reach ~2 workgroups per CU, each slice at least 4 K-steps long
@@ -1030,13 +1108,14 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
     }
-    static const char* sel = getenv("I2T_GEMM");
     // large-tile kernel for the non-split problems with enough 256^2 tiles to occupy the chip (I2T_GEMM=v1 keeps the 128^2 one)
-    static const bool no_g256 = sel && !strcmp(sel, "v1");
     // K % 128 == 0: K-tiles run in pairs and the DMA stream chains output tiles; k-major panels must fit a 32-bit byte offset
     const bool g256_ok = K % 128 == 0 && (!a_kmajor || (size_t)(K + 512) * lda * 2 < (1ull << 32)) &&
                          (!b_kmajor || (size_t)(K + 512) * ldb * 2 < (1ull << 32));
-    if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= 96) {
+    // I2T_G256_MIN_TILES (read per call so that a test can flip it): tile count from which the large-tile kernel takes over
+    const char* mt_env = getenv("I2T_G256_MIN_TILES");
+    const long min_tiles = mt_env ? atol(mt_env) : 96;
+    if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
         if (b_kmajor) launch_g256<true>(s, p);
         else launch_g256<false>(s, p);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(256)");

@@ -210,7 +210,12 @@ def test_fused_adamw_matches_torch_adamw(tiny_weights, tiny_forward):
     assert float((eng.arena.pbf.float() - eng.arena.p32).abs().max()) <= float(eng.arena.p32.abs().max()) / 128
 
 
-def test_nano224_full_size_forward_and_loss(nano224_golden):
+@pytest.mark.parametrize('large_tiles', [False, True])
+def test_nano224_full_size_forward_and_loss(nano224_golden, large_tiles, monkeypatch):
+    """large_tiles: route every eligible GEMM through the persistent 256 x 256 kernel (at batch 2 the default heuristic
+    keeps the 128 x 128 one), so that the kernel the full-size bench runs on is held to the same golden."""
+    if large_tiles:
+        monkeypatch.setenv('I2T_G256_MIN_TILES', '1')
     g = nano224_golden
     cfg = nano224_config()
     w = _wrapper(cfg)
