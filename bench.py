@@ -263,11 +263,11 @@ def main():
         traffic = None
         try:      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same batch only
             with open(os.path.join(ROOT, 'profiles', f'pmc_traffic_b{args.batch}.json')) as fh:
-                traffic = json.load(fh)['gemm_bf16_kernel']['hbm_bytes_per_launch']
+                traffic = json.load(fh)['gemm_all']['hbm_bytes_per_launch']
         except Exception:
             pass
         if gemm is not None:
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all layouts)', 'achieved': round(gemm['tflops'], 1),
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel + gemm_bf16_kernel (every i2t_gemm_bf16 launch of the step)', 'achieved': round(gemm['tflops'], 1),
                                'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gemm['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4),
                                'traffic': traffic, 'traffic_unit': 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)',
                                'algorithmic_bytes_per_launch': round(gemm['bytes_per_launch']), 'launches_per_step': gemm['launches'] // 2,

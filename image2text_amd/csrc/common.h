@@ -43,7 +43,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    // one v_cvt_pk_bf16_f32 for the pair (two scalar casts compile to two of them plus an SDWA or)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
 __device__ __forceinline__ float bf16lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }

@@ -16,7 +16,8 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name']
-        k = 'gemm_bf16_kernel' if 'gemm_bf16_kernel' in k else k.split('(')[0][-60:]
+        k = k.replace('(anonymous namespace)::', '')
+        k = 'gemm_all' if ('gemm_bf16_kernel' in k or 'gemm256_kernel' in k) else k.split('(')[0].split('<')[0][-60:]
         tot[k] = tot.get(k, 0.0) + float(r['Counter_Value'])
         n[k] = n.get(k, 0) + 1
     return tot, n
