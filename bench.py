@@ -205,6 +205,20 @@ def main():
         elapsed = float(t)
     img_s = world * args.batch * args.steps / elapsed
 
+    # ---- the same step with the batch handed over as HOST buffers (pinned): PCIe-inclusive rate, reported beside `value`
+    pcie_img_s = None
+    if not args.no_kernel_timing:
+        h_images, h_labels = images.cpu().pin_memory(), labels.cpu().pin_memory()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            images.copy_(h_images, non_blocking=True)
+            labels.copy_(h_labels, non_blocking=True)
+            step()
+        fence()
+        pcie_img_s = world * args.batch * 3 / (time.perf_counter() - t1)
+        del h_images, h_labels
+
     # ---- per-kernel timing of the dominant kernel (bf16 MFMA GEMM) with HIP events, 2 extra steps
     gemm = None
     if not args.no_kernel_timing:
@@ -257,6 +271,7 @@ def main():
             'greedy_config': {'captions_per_batch': args.decode_batch, 'concurrent_batches_per_gpu': args.decode_streams,
                               'new_tokens': 64, 'ngrams': [2, 3, 4, 5], 'includes': 'encoder forward + KV-cache decode (hipGraph replay)'},
             'final_loss': round(final_loss, 4),
+            'host_input_images_per_sec': None if pcie_img_s is None else round(pcie_img_s, 1),     # H2D copy of the batch inside the step
             # nominal = SURVEY 8(d) required-output count (98 GFLOP/image); the step executes less: padded caption rows are skipped
             'step_nominal_tflops': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
         }
