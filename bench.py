@@ -36,9 +36,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=512, help='images per GPU per step')
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
-    ap.add_argument('--decode-batch', type=int, default=64, help='captions per GPU per greedy run')
+    ap.add_argument('--decode-batch', type=int, default=4096, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
-    ap.add_argument('--decode-streams', type=int, default=8, help='independent caption batches decoded concurrently')
+    ap.add_argument('--decode-streams', type=int, default=2, help='independent caption batches decoded concurrently')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')

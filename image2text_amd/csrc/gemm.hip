@@ -275,17 +275,18 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 // EPI selects a compile-time epilogue class (the generic form keeps ~30 uniform values and every path alive: in the
 // 256^2 kernel that cost SGPR and VGPR spills whose serialized scratch reloads were ~10 us per tile):
 //   0 generic (all flags at run time)          1 bf16 C, optional bias, optional per-row/third dropout (mode 2)
-//   2 bf16 C, bias + GELU + pre-activation out  3 f32 C, optional bias, optional dropout (mode 1), + residual
+//   2 bf16 C, bias + GELU (+ pre-activation out) 3 f32 C, optional bias, optional dropout (mode 1), + residual
 //   4 bf16 C, GELU' of aux_in                   5 f32 C accumulate
+//   7 = 1 with N % 4 != 0 (the lm_head's 50257 columns): the quad that straddles N is stored element-wise, [N, ldc) untouched
 template <int EPI>
 __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
     constexpr bool GEN = EPI == 0;
-    const bool f_bias = (GEN || EPI == 1 || EPI == 3) ? (p.bias != nullptr) : (EPI == 2);
+    const bool f_bias = (GEN || EPI == 1 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : (EPI == 2);
     const bool f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
     const bool f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
-    const bool f_auxout = GEN ? (p.aux_out != nullptr) : (EPI == 2);
+    const bool f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
     const bool f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
-    const bool f_drop2 = (GEN || EPI == 1) ? (p.drop_mode == 2) : false;
+    const bool f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
     const bool f_res = GEN ? (p.residual != nullptr) : (EPI == 3);
     const bool f_acc = GEN ? (p.accumulate != 0) : (EPI == 5);
     const bool f_f32 = GEN ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
@@ -295,7 +296,7 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
     for (int q = 0; q < 4; ++q) {
         ok[q] = m[q] < p.M && n4[q] < p.N;
         mc[q] = min(m[q], p.M - 1);
-        nc[q] = min(n4[q], p.N - 4);
+        nc[q] = min(n4[q], ((p.N + 3) & ~3) - 4);        // EPI 7: the straddling quad loads bias from [N-1 .. N+2]: inside the 16-B padded vector
     }
     // one set of addend registers serves residual and accumulate (both at once is rare: the second then waits on the first)
     f32x4 v[4], bv[4], add[4];
@@ -373,8 +374,13 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (ok[q]) {
-                const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m[q] * p.ldc + n4[q]) = pk;
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m[q] * p.ldc + n4[q];
+                if (EPI == 7 && n4[q] + 4 > p.N) {          // the quad that straddles N
+                    for (int r = 0; r < p.N - n4[q]; ++r) c[r] = f32_to_bf16(v[q][r]);
+                } else {
+                    const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
+                    *reinterpret_cast<u32x2*>(c) = pk;
+                }
             }
     }
 }
@@ -864,12 +870,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 }
 
 int g256_epilogue_class(const GemmParams& p) {
-    const bool fast = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
-                      (!p.aux_out || (p.ld_aux_out & 3) == 0);
-    if (!fast) return 0;
+    const bool fast4 = (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
+                       (!p.aux_out || (p.ld_aux_out & 3) == 0);
     const bool none = p.act == I2T_ACT_NONE && !p.aux_out;
+    // bias-free only: a straddling quad would read bias[N .. N+2]
+    if (fast4 && (p.N & 3) != 0 && !p.c_is_f32 && none && !p.bias && !p.residual && !p.accumulate && !p.drop_mode) return 7;
+    if (!fast4 || (p.N & 3) != 0) return 0;
     if (!p.c_is_f32 && none && !p.residual && !p.accumulate && p.drop_mode != 1) return 1;
-    if (!p.c_is_f32 && p.bias && p.act == I2T_ACT_GELU && p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 2;
+    if (!p.c_is_f32 && p.bias && p.act == I2T_ACT_GELU && !p.drop_mode && !p.residual && !p.accumulate) return 2;
     if (p.c_is_f32 && none && p.residual && !p.accumulate && p.drop_mode != 2) return 3;
     if (!p.c_is_f32 && p.act == I2T_ACT_DGELU && !p.bias && !p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 4;
     if (p.c_is_f32 && none && p.accumulate && !p.bias && !p.residual && !p.drop_mode) return 5;
@@ -896,6 +904,7 @@ void launch_g256(hipStream_t s, GemmParams p) {
     // forward GEMMs (B^T form) meet classes 1-3, the dX GEMMs (B form) classes 1, 4, 5; anything else runs the generic one
     switch (g256_epilogue_class(p)) {
         case 1: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 1>), grid, block, 0, s, p); break;
+        case 7: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 7>), grid, block, 0, s, p); break; }
         case 2: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, s, p); break; }
         case 3: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 3>), grid, block, 0, s, p); break; }
         case 4: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p); break; }
@@ -1114,7 +1123,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
                          (!b_kmajor || (size_t)(K + 512) * ldb * 2 < (1ull << 32));
     // I2T_G256_MIN_TILES (read per call so that a test can flip it): tile count from which the large-tile kernel takes over
     const char* mt_env = getenv("I2T_G256_MIN_TILES");
-    const long min_tiles = mt_env ? atol(mt_env) : 96;
+    const long min_tiles = mt_env ? atol(mt_env) : 40;
     if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
         if (b_kmajor) launch_g256<true>(s, p);
         else launch_g256<false>(s, p);
