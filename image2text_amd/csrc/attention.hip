@@ -53,6 +53,28 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* bas
     }
 }
 
+// The same staging split in two (issue the global loads of tile t+1 before computing on tile t, write them to LDS after
+// the barrier that ends tile t): the load latency, which the one-piece form exposed once per tile, hides behind the MFMAs.
+struct TileRegs {
+    u32x4 v[2];
+};
+__device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* base, int rs, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u, r = c >> 3, kc = c & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)(r0 + r) * rs + kc * 8);
+        t.v[u] = v;
+    }
+}
+__device__ __forceinline__ void tile_store(const TileRegs& t, unsigned char* lds, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u, r = c >> 3, kc = c & 7;
+        *reinterpret_cast<u32x4*>(lds + r * TS + kc * 16) = t.v[u];
+    }
+}
+
 // row fragment: lane (g, i) <- tile[r0 + i][32 ks + 8 g .. +7]
 __device__ __forceinline__ bf16x8 tile_row_frag(const unsigned char* lds, int r0, int ks, int lane) {
     const int g = lane >> 4, i = lane & 15;
@@ -139,24 +161,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
     const int qlim = causal ? (min(qrow, Tq - 1) + shift) : (Tk - 1);
     const unsigned drow = (((unsigned)b * H + h) * TqMax + min(qrow, Tq - 1)) * (unsigned)TkMax;   // dropout index of (b, h, q, key 0)
 
+    // A wave whose 16 query rows are all past Tq only helps staging; 16-key blocks past the last visible key of a tile are
+    // skipped (T = 260 runs 5 key tiles, the last with 4 keys: whole-tile work there was ~30 % of the encoder's attention).
+    const bool wave_on = q0 < Tq;
+    TileRegs kr, vr;
+    tile_load(kr, kb, K.rs, 0, Tk, tid);
+    tile_load(vr, vb, V.rs, 0, Tk, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_tile(kt_lds, kb, K.rs, kt * 64, Tk, tid);
-        stage_tile(vt_lds, vb, V.rs, kt * 64, Tk, tid);
+        tile_store(kr, kt_lds, tid);
+        tile_store(vr, vt_lds, tid);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load(kr, kb, K.rs, (kt + 1) * 64, Tk, tid);
+            tile_load(vr, vb, V.rs, (kt + 1) * 64, Tk, tid);
+        }
+        if (!wave_on) continue;
+        const int nkj = min(4, (last_key - kt * 64) / 16 + 1);          // 16-key blocks of this tile that hold a visible key
         f32x4 s[4];
         float mx = -INFINITY;
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
+            f32x4 a = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kj < nkj) {
+                a = f32x4{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int key = kt * 64 + kj * 16 + 4 * g + r;
-                float v = (key <= qlim && key < Tk) ? a[r] * (SCALE * LOG2E) : -INFINITY;
-                a[r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) {
+                    int key = kt * 64 + kj * 16 + 4 * g + r;
+                    float v = (key <= qlim && key < Tk) ? a[r] * (SCALE * LOG2E) : -INFINITY;
+                    a[r] = v;
+                    mx = fmaxf(mx, v);
+                }
             }
             s[kj] = a;
         }
@@ -167,6 +204,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
         float rs = 0.f;
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
+            if (kj >= nkj) {
+                s[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             bool keep[4] = {true, true, true, true};
             if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
 #pragma unroll
@@ -186,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(vt_lds, 0, dt * 16, lane), p0, o[dt], 0, 0, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(vt_lds, 1, dt * 16, lane), p1, o[dt], 0, 0, 0);
+            if (nkj > 2) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(vt_lds, 1, dt * 16, lane), p1, o[dt], 0, 0, 0);
         }
     }
     l = quad_sum(l);
@@ -281,14 +322,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool wave_on = q0 < Tq;
+    TileRegs kr, vr;
+    tile_load(kr, kb, K.rs, 0, Tk, tid);
+    tile_load(vr, vb, V.rs, 0, Tk, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_tile(kt_lds, kb, K.rs, kt * 64, Tk, tid);
-        stage_tile(vt_lds, vb, V.rs, kt * 64, Tk, tid);
+        tile_store(kr, kt_lds, tid);
+        tile_store(vr, vt_lds, tid);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load(kr, kb, K.rs, (kt + 1) * 64, Tk, tid);
+            tile_load(vr, vb, V.rs, (kt + 1) * 64, Tk, tid);
+        }
+        if (!wave_on) continue;
+        const int nkj = min(4, (last_key - kt * 64) / 16 + 1);
         f32x4 ds[4];
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
+            if (kj >= nkj) {
+                ds[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
@@ -310,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {   // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
             acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(kt_lds, 0, dt * 16, lane), s0, acc[dt], 0, 0, 0);
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(kt_lds, 1, dt * 16, lane), s1, acc[dt], 0, 0, 0);
+            if (nkj > 2) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(kt_lds, 1, dt * 16, lane), s1, acc[dt], 0, 0, 0);
         }
     }
     if (qrow < Tq) {
@@ -375,19 +430,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) adk[dt] = adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool wave_on = k0 < Tk;
+    TileRegs qr, dr;
+    float lse_r = 0.f, dl_r = 0.f;
+    if (qt0 < nqt) {
+        tile_load(qr, qb, Q.rs, qt0 * 64, Tq, tid);
+        tile_load(dr, dob, dO.rs, qt0 * 64, Tq, tid);
+        if (tid < 64) {
+            const int q = min(qt0 * 64 + tid, Tq - 1);
+            lse_r = lse[stat_base + q] * LOG2E;
+            dl_r = delta[stat_base + q];
+        }
+    }
     for (int qt = qt0; qt < nqt; ++qt) {
         __syncthreads();
-        stage_tile(q_lds, qb, Q.rs, qt * 64, Tq, tid);
-        stage_tile(do_lds, dob, dO.rs, qt * 64, Tq, tid);
+        tile_store(qr, q_lds, tid);
+        tile_store(dr, do_lds, tid);
         if (tid < 64) {
-            int q = min(qt * 64 + tid, Tq - 1);
-            lse_lds[tid] = lse[stat_base + q] * LOG2E;
-            dl_lds[tid] = delta[stat_base + q];
+            lse_lds[tid] = lse_r;
+            dl_lds[tid] = dl_r;
         }
         __syncthreads();
+        if (qt + 1 < nqt) {
+            tile_load(qr, qb, Q.rs, (qt + 1) * 64, Tq, tid);
+            tile_load(dr, dob, dO.rs, (qt + 1) * 64, Tq, tid);
+            if (tid < 64) {
+                const int q = min((qt + 1) * 64 + tid, Tq - 1);
+                lse_r = lse[stat_base + q] * LOG2E;
+                dl_r = delta[stat_base + q];
+            }
+        }
+        if (!wave_on) continue;
+        const int nqj = min(4, (Tq - 1 - qt * 64) / 16 + 1);          // 16-row query blocks of this tile that exist
         f32x4 p[4], ds[4];
 #pragma unroll
         for (int qj = 0; qj < 4; ++qj) {
+            if (qj >= nqj) {
+                p[qj] = ds[qj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             // swapped issue: D[q][key] with rows = q (from the LDS tile), cols = key (this lane's register fragment)
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(q_lds, qj * 16, 0, lane), kf0, a, 0, 0, 0);
@@ -416,9 +497,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 0, dt * 16, lane), p0, adv[dt], 0, 0, 0);
-            adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 1, dt * 16, lane), p1, adv[dt], 0, 0, 0);
             adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 0, dt * 16, lane), s0, adk[dt], 0, 0, 0);
-            adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 1, dt * 16, lane), s1, adk[dt], 0, 0, 0);
+            if (nqj > 2) {
+                adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 1, dt * 16, lane), p1, adv[dt], 0, 0, 0);
+                adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 1, dt * 16, lane), s1, adk[dt], 0, 0, 0);
+            }
         }
     }
     if (key < Tk) {
