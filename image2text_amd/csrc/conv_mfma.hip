@@ -83,6 +83,44 @@ __device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void*
     }
 }
 
+// NHWC source: the same staging in two halves, so that the next tile's patch is in flight (registers) while the current
+// tile is being computed -- a tile is only ~1 us of MFMA work, less than the latency of its own halo gather.
+template <int CP>
+struct PatchRegs {
+    static constexpr int N = (PW * PW * (CP / 8) + 255) / 256;
+    u32x4 v[N];
+};
+template <int CP, bool IN_GELU>
+__device__ __forceinline__ void patch_load(PatchRegs<CP>& pr, const void* __restrict__ src, int b, int H, int W, int y0, int x0,
+                                           int pad_before, int tid) {
+    constexpr int CH = CP / 8;
+    const bf16_t* s = reinterpret_cast<const bf16_t*>(src) + (size_t)b * H * W * CP;
+#pragma unroll
+    for (int u = 0; u < PatchRegs<CP>::N; ++u) {
+        const int i = tid + 256 * u;
+        const int ch = i % CH, px = (i / CH) % PW, py = i / (CH * PW);
+        const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (i < PW * PW * CH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = *reinterpret_cast<const u32x4*>(s + ((size_t)gy * W + gx) * CP + ch * 8);
+        pr.v[u] = v;
+    }
+}
+template <int CP, bool IN_GELU>
+__device__ __forceinline__ void patch_store(const PatchRegs<CP>& pr, bf16_t* __restrict__ pl, int tid) {
+#pragma unroll
+    for (int u = 0; u < PatchRegs<CP>::N; ++u) {
+        const int i = tid + 256 * u;
+        if (i >= PW * PW * (CP / 8)) continue;
+        u32x4 v = pr.v[u];
+        if (IN_GELU) {        // gelu(0) = 0: the zero halo stays zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(gelu_tanh(bf16lo(v[e])), gelu_tanh(bf16hi(v[e])));
+        }
+        *reinterpret_cast<u32x4*>(pl + (size_t)i * 8) = v;          // [py][px][ch] is exactly chunk order i
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fwd / bwd-data
 template <int CP, int NT, int SRC, bool IN_GELU, bool DGELU, bool DST_NCHW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__ src, const bf16_t* __restrict__ wr,
@@ -96,13 +134,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.y;
-    const int y0 = (blockIdx.x / tiles_x) * TS, x0 = (blockIdx.x % tiles_x) * TS;
+    const int y0 = blockIdx.x * TS;
+    // A workgroup sweeps one row of tiles: the weights (up to 36 KiB) are staged ONCE per 14 tiles -- per tile they cost
+    // about as much LDS-fill time as the tile's MFMA work -- and the NCHW rows of neighbouring tiles are written by the
+    // same workgroup back to back (32-byte pieces that the L2 merges into full lines).
     for (int i = tid; i < COP * NTAP * CP / 8; i += 256) {    // weights: contiguous [co][tap][ci] -> padded rows
         const int co = i / (NTAP * CP / 8), rest = i % (NTAP * CP / 8);
         *reinterpret_cast<u32x4*>(wl + co * WROW + rest * 8) = *reinterpret_cast<const u32x4*>(wr + (size_t)i * 8);
     }
-    stage_patch<CP, SRC, IN_GELU>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
+    PatchRegs<CP> pr;
+    if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, 0, pad_before, tid);
+    for (int tx = 0; tx < tiles_x; ++tx) {
+    const int x0 = tx * TS;
+    __syncthreads();                                          // the previous tile's patch reads are done
+    if (SRC == SRC_NHWC_BF16) patch_store<CP, IN_GELU>(pr, pl, tid);
+    else stage_patch<CP, SRC, IN_GELU>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
     __syncthreads();
+    if (SRC == SRC_NHWC_BF16 && tx + 1 < tiles_x) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, x0 + TS, pad_before, tid);
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -158,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
             }
         }
     }
+    }   // tile sweep
 }
 
 // ------------------------------------------------------------------------------------------------ bwd-weight
@@ -308,7 +357,7 @@ static int conv_mfma_dispatch(hipStream_t s, const void* src, int src_layout, in
                               void* dst, int dst_nchw, const void* pre, int B, int Cin, int Cout, int H, int W,
                               int pad_before) {
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
-    dim3 grid(tiles_x * tiles_y, B);
+    dim3 grid(tiles_y, B);
     const int cp = pad8(Cin), nt = Cout <= 16 ? 1 : 2;
     const bool dg = pre != nullptr;
     // the combinations the feature extractor uses (forward: f32 NCHW image | NHWC+GELU; backward-data: NCHW | NHWC dY)
