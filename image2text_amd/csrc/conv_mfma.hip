@@ -330,6 +330,33 @@ int pad8(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : 32); }
 // dst[b][y][x][c] = src[b][c][y][x] (bf16): one workgroup per (64-pixel run of a row, b); coalesced both ways through LDS.
 // The projector's dX GEMM produces the last conv layer's gradient as flat NCHW patches; both backward kernels of that layer
 // are ~3x faster on channels-last input (16-byte staging instead of 2-byte scatter), so it is transposed once.
+// C = 32, 16-byte accesses on both sides: thread (c, 8-pixel group) loads 16 B of one channel row, the LDS image is
+// [c][64 px] with a 33-dword row stride (written as 4 dwords, read back as 8 conflict-free 16-bit reads per thread), thread
+// (px, 8-channel group) stores 16 B -- a wave writes 1 KiB of consecutive NHWC bytes.
+__global__ __launch_bounds__(256) void nchw_to_nhwc32_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int H, int W) {
+    __shared__ unsigned tile[32 * 33];
+    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64, t = threadIdx.x;
+    const size_t plane = (size_t)H * W;
+    {
+        const int c = t >> 3, pg = t & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (x0 + pg * 8 < W) v = *reinterpret_cast<const u32x4*>(src + ((size_t)b * 32 + c) * plane + (size_t)y * W + x0 + pg * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[c * 33 + pg * 4 + e] = v[e];
+    }
+    __syncthreads();
+    const int px = t >> 2, cg = t & 3;
+    if (x0 + px >= W) return;
+    const bf16_t* th = reinterpret_cast<const bf16_t*>(tile);
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned lo = th[((cg * 8 + 2 * j) * 33) * 2 + px], hi = th[((cg * 8 + 2 * j + 1) * 33) * 2 + px];
+        o[j] = lo | (hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(dst + (((size_t)b * H + y) * W + x0 + px) * 32 + cg * 8) = u32x4{o[0], o[1], o[2], o[3]};
+}
+
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int C, int H,
                                                            int W) {
     __shared__ bf16_t tile[64][33];
@@ -397,6 +424,12 @@ static int conv_mfma_dispatch(hipStream_t s, const void* src, int src_layout, in
 
 extern "C" int i2t_nchw_to_nhwc_bf16(void* stream, const void* src, void* dst, int B, int C, int H, int W) {
     I2T_REQUIRE(src && dst && B > 0 && C > 0 && C <= 32 && H > 0 && W > 0, "i2t_nchw_to_nhwc_bf16: bad args (C <= 32)");
+    if (C == 32 && W % 8 == 0 && ALIGNED16(src) && ALIGNED16(dst)) {
+        hipLaunchKernelGGL(nchw_to_nhwc32_kernel, dim3((W + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                           (bf16_t*)dst, H, W);
+        I2T_CHECK_LAUNCH("i2t_nchw_to_nhwc_bf16");
+        return I2T_OK;
+    }
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((W + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
                        (bf16_t*)dst, C, H, W);
     I2T_CHECK_LAUNCH("i2t_nchw_to_nhwc_bf16");

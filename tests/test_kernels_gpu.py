@@ -690,8 +690,10 @@ def test_embed_packed_positions(ops):
     check('packed dwpe', dwpe, torch.zeros(48, d, device=dev()).index_add_(0, pos.long() + off, dx), 1e-5, 1e-5)
 
 
-def test_nchw_to_nhwc(ops):
-    x = rnd(2, 32, 20, 70, dtype=BF16, seed=200)
-    y = torch.empty(2, 20, 70, 32, dtype=BF16, device=dev())
-    ops.nchw_to_nhwc(x, y, 2, 32, 20, 70)
+@pytest.mark.parametrize('C,H,W', [(32, 20, 70), (32, 9, 224), (32, 5, 72), (16, 7, 64)])
+def test_nchw_to_nhwc(ops, C, H, W):
+    """W % 8 == 0 with C = 32 takes the 16-byte-vector kernel (full and ragged 64-pixel tiles), the rest the scalar one."""
+    x = rnd(2, C, H, W, dtype=BF16, seed=200)
+    y = torch.empty(2, H, W, C, dtype=BF16, device=dev())
+    ops.nchw_to_nhwc(x, y, 2, C, H, W)
     assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
