@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int TqMax,
                                                           int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
-                                                          float drop_scale, VarLen vl) {
+                                                          float drop_scale, VarLen vl, unsigned od_key, unsigned od_thr,
+                                                          float od_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* kt_lds = smem;
     unsigned char* vt_lds = smem + TILE_BYTES;
@@ -370,8 +371,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     }
     if (qrow < Tq) {
         bf16_t* op = dQ + dqoff + (size_t)qrow * dq_rs + h * 64;
+        // od_*: the per-token multiplier that scaled q in the forward (GEMM drop_mode 2, third 0), row = token index
+        const unsigned grow = (unsigned)((vl.cu_q ? vl.cu_q[b] : b * TqMax) + qrow);
+        const float f = od_thr ? (dropout_keep(od_key, grow, od_thr) ? od_scale : 0.f) : 1.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
+            acc[dt] *= f;
             u32x2 pk = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
             *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = pk;
         }
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                                                            bf16_t* __restrict__ dK, long dk_bs, int dk_rs,
                                                            bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int TqMax,
                                                            int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
-                                                           float drop_scale, VarLen vl) {
+                                                           float drop_scale, VarLen vl, unsigned od_key, unsigned od_thr,
+                                                           float od_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * 64 * 4];
     unsigned char* q_lds = smem;
     unsigned char* do_lds = smem + TILE_BYTES;
@@ -507,8 +513,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     if (key < Tk) {
         bf16_t* pk_ = dK + dkoff + (size_t)key * dk_rs + h * 64;
         bf16_t* pv_ = dV + dvoff + (size_t)key * dv_rs + h * 64;
+        const unsigned grow = (unsigned)((vl.cu_k ? vl.cu_k[b] : b * TkMax) + key);     // thirds 1 (k) and 2 (v) of the fused c_attn
+        const float fk = od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f;
+        const float fv = od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
+            adk[dt] *= fk;
+            adv[dt] *= fv;
             u32x2 a = {pack_bf16x2(adk[dt][0], adk[dt][1]), pack_bf16x2(adk[dt][2], adk[dt][3])};
             u32x2 c = {pack_bf16x2(adv[dt][0], adv[dt][1]), pack_bf16x2(adv[dt][2], adv[dt][3])};
             *reinterpret_cast<u32x2*>(pk_ + dt * 16 + 4 * g) = a;
@@ -546,7 +557,8 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                                  const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws, void* dq,
                                  long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs, void* dv, long dv_bs, int dv_rs,
                                  int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                                 const int* cu_q, const int* cu_k, int total_q) {
+                                 const int* cu_q, const int* cu_k, int total_q, unsigned out_drop_key, unsigned out_drop_thr,
+                                 float out_drop_scale) {
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && lse && delta_ws, "i2t_attention_bwd: bad args");
     I2T_REQUIRE(!cu_q || total_q > 0, "i2t_attention_bwd: packed queries need total_q");
     I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_bwd: dropout index overflows 32 bits");
@@ -563,9 +575,11 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)o, o_bs, o_rs,
                        (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total, cu_q ? total_q : 0);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl);
+                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
+                       out_drop_scale);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl);
+                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl,
+                       out_drop_key, out_drop_thr, out_drop_scale);
     I2T_CHECK_LAUNCH("i2t_attention_bwd");
     return I2T_OK;
 }

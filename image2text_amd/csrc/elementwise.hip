@@ -184,20 +184,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 __global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ g, long n4, long n, const float* __restrict__ ws,
-                                                            bf16_t* __restrict__ gb) {
+                                                            bf16_t* __restrict__ gb, unsigned drop_key, unsigned drop_thr,
+                                                            float drop_scale) {
     const float inv = 1.0f / (sqrtf(*ws) + 1e-6f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = reinterpret_cast<f32x4*>(g)[i] * inv;
         reinterpret_cast<f32x4*>(g)[i] = v;
         if (gb) {
+            if (drop_thr) {        // the bf16 copy feeds a dropped-out branch: same elementwise mask as its forward
+                bool keep[4];
+                dropout_keep4(drop_key, (unsigned)(i * 4), drop_thr, keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * drop_scale : 0.f;
+            }
             u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             reinterpret_cast<u32x2*>(gb)[i] = pk;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        float v = g[n4 * 4 + threadIdx.x] * inv;
-        g[n4 * 4 + threadIdx.x] = v;
-        if (gb) gb[n4 * 4 + threadIdx.x] = f32_to_bf16(v);
+        const long e = n4 * 4 + threadIdx.x;
+        float v = g[e] * inv;
+        g[e] = v;
+        if (gb) gb[e] = f32_to_bf16((drop_thr && !dropout_keep(drop_key, (unsigned)e, drop_thr)) ? 0.f : (drop_thr ? v * drop_scale : v));
     }
 }
 
@@ -389,14 +397,17 @@ extern "C" int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* lab
     return I2T_OK;
 }
 
-extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16) {
+extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16, unsigned drop_key, unsigned drop_thr,
+                                  float drop_scale) {
     I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_grad_normalize: bad args");
+    I2T_REQUIRE(drop_thr == 0 || (g_bf16 && n < (1L << 32)), "i2t_grad_normalize: dropout needs the bf16 copy and n < 2^32");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
     if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
     const int grid = grid_for(n >> 2, 1024);
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
-    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16);
+    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16, drop_key,
+                       drop_thr, drop_scale);
     I2T_CHECK_LAUNCH("i2t_grad_normalize");
     return I2T_OK;
 }

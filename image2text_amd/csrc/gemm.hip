@@ -1119,7 +1119,9 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     }
     // large-tile kernel for the non-split problems with enough 256^2 tiles to occupy the chip (I2T_GEMM=v1 keeps the 128^2 one)
     // K % 128 == 0: K-tiles run in pairs and the DMA stream chains output tiles; k-major panels must fit a 32-bit byte offset
-    const bool g256_ok = K % 128 == 0 && (!a_kmajor || (size_t)(K + 512) * lda * 2 < (1ull << 32)) &&
+    // K % 128 == 0 (K-tiles run in pairs), or any K when B is k-major: the range check then returns B rows >= K as zeros, so
+    // whatever finite values a row-major A delivers past K (its zero pads, then the head of the next row) contribute nothing
+    const bool g256_ok = (K % 128 == 0 || b_kmajor) && (!a_kmajor || (size_t)(K + 512) * lda * 2 < (1ull << 32)) &&
                          (!b_kmajor || (size_t)(K + 512) * ldb * 2 < (1ull << 32));
     // I2T_G256_MIN_TILES (read per call so that a test can flip it): tile count from which the large-tile kernel takes over
     const char* mt_env = getenv("I2T_G256_MIN_TILES");

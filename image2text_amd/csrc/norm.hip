@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      int dx_accumulate, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                     int d) {
+                                                     int d, unsigned drop_key, unsigned drop_thr, float drop_scale) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = d >> 2;
@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 if (dx_accumulate) o += *dxp;
                 *dxp = o;
                 if (dx_bf16) {
+                    if (drop_thr) {    // the bf16 copy feeds a dropped-out branch: its forward mask, idx = row * d + column
+                        bool keep[4];
+                        dropout_keep4(drop_key, (unsigned)row * (unsigned)d + 4u * (unsigned)c, drop_thr, keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * drop_scale : 0.f;
+                    }
                     u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                     reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * d)[c] = pk;
                 }
@@ -329,17 +335,19 @@ extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamm
 
 extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
-                                 float* dgamma, float* dbeta, int M, int d) {
+                                 float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
+                                 float drop_scale) {
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
+    I2T_REQUIRE(drop_thr == 0 || (dx_bf16 && (long)M * d < (1L << 32)), "i2t_layernorm_bwd: dropout needs dx_bf16 and M*d < 2^32");
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
     int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
     hipStream_t s = (hipStream_t)stream;
     if (dy_is_f32)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale);
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
 }

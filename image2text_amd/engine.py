@@ -266,9 +266,8 @@ class HotPath:
         v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
         ws = self._empty(H * M)
         dr = sv.dr
-        # ---- MLP: x3 = x2 + drop(c_proj(gelu(c_fc(ln_2 x2))))
-        if dr['mlp'] is not None:
-            ops.dropout_apply(dxb, M, d, dr['mlp'])            # the branch sees the masked gradient; dx (residual) does not
+        # ---- MLP: x3 = x2 + drop(c_proj(gelu(c_fc(ln_2 x2)))).  dxb arrives already masked with the MLP dropout (the
+        # producer of the bf16 copy applies it: the branch sees the masked gradient, dx -- the residual path -- does not)
         dpre = self._empty(M, ff, dtype=BF16)
         self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
                          dx_out=dpre, act=2, aux_in=sv.pre)
@@ -276,7 +275,8 @@ class HotPath:
         self._linear_bwd(dpre, M, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', f'{pfx}.mlp.c_fc.bias' if a.G(f'{pfx}.mlp.c_fc.bias') is not None else None,
                          dx_out=dln)
         ops.layernorm_bwd(dln, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.G(f'{pfx}.ln_2.weight'),
-                          a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb)
+                          a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb,
+                          bf16_drop=None if sv.cross else dr['resid'])      # next consumer of dxb: attn.c_proj backward
         # ---- cross attention: x2 = x1 + out_proj(attn(q(ln_3 x1), kv(mem)))
         if sv.cross:
             win = a.W(f'{pfx}.cross_attn.in_proj_weight')
@@ -295,19 +295,16 @@ class HotPath:
             ops.gemm(dkvf, sv.mem, gin[d:], 2 * d, d, B * S, a_kmajor=True, b_kmajor=True, accumulate=True)
             ops.gemm(dkvf, win[d:], dmem, B * S, d, 2 * d, b_kmajor=True, accumulate=True)
             ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_3.weight'), sv.m3, sv.r3, dx, a.G(f'{pfx}.ln_3.weight'),
-                              a.G(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb)
-        # ---- self attention: x1 = x + drop(c_proj(attn(mult * c_attn(ln_1 x))))
-        if dr['resid'] is not None:
-            ops.dropout_apply(dxb, M, d, dr['resid'])
+                              a.G(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb, bf16_drop=dr['resid'])
+        # ---- self attention: x1 = x + drop(c_proj(attn(mult * c_attn(ln_1 x)))); dxb carries the resid-dropout mask
         dao = self._empty(M, d, dtype=BF16)
         self._linear_bwd(dxb, M, d, d, sv.ao, f'{pfx}.attn.c_proj.weight',
                          f'{pfx}.attn.c_proj.bias' if a.G(f'{pfx}.attn.c_proj.bias') is not None else None, dx_out=dao)
         dqkv = self._empty(M, 3 * d, dtype=BF16)
         q3, g3 = v3(sv.qkv, 3 * d), v3(dqkv, 3 * d)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], v3(sv.ao, d), v3(dao, d), sv.lse, ws, g3[..., :d],
-                          g3[..., d:2 * d], g3[..., 2 * d:], B, H, T, T, causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M)
-        if dr['qkv'] is not None:
-            ops.dropout_apply(dqkv, M, 3 * d, dr['qkv'])       # gradient w.r.t. the un-multiplied q/k/v
+                          g3[..., d:2 * d], g3[..., 2 * d:], B, H, T, T, causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M,
+                          out_drop=dr['qkv'])                  # gradient w.r.t. the un-multiplied q/k/v
         self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
                          f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
         ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
@@ -316,7 +313,8 @@ class HotPath:
     def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None):
         dxb = self._empty(dx.shape[0], d, dtype=BF16)
         for l in reversed(range(len(saves))):
-            ops.grad_normalize(dx, self._ws[:1], dxb)          # normalize_gradients at the block output
+            # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
+            ops.grad_normalize(dx, self._ws[:1], dxb, bf16_drop=saves[l].dr['mlp'])
             self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
                            vl=vl)
 

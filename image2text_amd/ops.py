@@ -68,10 +68,13 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d):
     return y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None, bf16_drop=None):
+    """bf16_drop = (1, key, thr, scale): elementwise dropout mask applied to the bf16 copy only (see include/i2t.h)."""
     _need_cuda(dy, x, dx)
+    assert bf16_drop is None or int(bf16_drop[0]) == 1
     _l.check(_lib().i2t_layernorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
-                                      int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d), 'i2t_layernorm_bwd')
+                                      int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d, *_drop(bf16_drop)[1:]),
+             'i2t_layernorm_bwd')
     return dx
 
 
@@ -109,13 +112,16 @@ def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=None, cu_q=None, c
     return o
 
 
-def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0):
+def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0,
+                  out_drop=None):
+    """out_drop = (2, key, thr, scale): the forward's per-token q/k/v multipliers applied to dq/dk/dv on the way out."""
     _need_cuda(q, k, v, o, do, dq, dk, dv)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
     dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
     _l.check(_lib().i2t_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
                                       _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
-                                      int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q)), 'i2t_attention_bwd')
+                                      int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q), *_drop(out_drop)[1:]),
+             'i2t_attention_bwd')
 
 
 def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab, pos=None):
@@ -141,9 +147,10 @@ def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
                                _p(gscale), M, V), 'i2t_ce_bwd')
 
 
-def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None):
+def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=None):
     _need_cuda(g, ws)
-    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws), _p(g_bf16)), 'i2t_grad_normalize')
+    assert bf16_drop is None or int(bf16_drop[0]) == 1
+    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws), _p(g_bf16), *_drop(bf16_drop)[1:]), 'i2t_grad_normalize')
     return g
 
 

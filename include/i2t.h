@@ -77,7 +77,10 @@ int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const fl
                       void* y, int y_is_f32, float* mean, float* rstd, int M, int d);
 int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                       const float* mean, const float* rstd,
-                      float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d);
+                      float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
+                      unsigned drop_key, unsigned drop_thr, float drop_scale);
+/* drop_* (bwd): optional elementwise dropout (rule of i2t_gemm_bf16, idx = row*d + col, drop_thr 0 = off) applied to the
+ * bf16 copy dx_bf16 only -- the copy feeds the backward of a dropped-out branch, the f32 dx is the residual gradient. */
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNormND (layers.py:361-370 via encoder.py:150,166,170): one normalisation per image over the joint
@@ -117,7 +120,11 @@ int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const vo
                       void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
                       void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal,
                       unsigned drop_key, unsigned drop_thr, float drop_scale,
-                      const int* cu_q, const int* cu_k, int total_q);
+                      const int* cu_q, const int* cu_k, int total_q,
+                      unsigned out_drop_key, unsigned out_drop_thr, float out_drop_scale);
+/* out_drop_* (bwd): the per-token q/k/v multipliers of the fused c_attn output (i2t_gemm_bf16 drop_mode 2) applied to
+ * dq / dk / dv on the way out: row r of dq is scaled by keep(key, r), of dk by keep(key + 1, r), of dv by keep(key + 2, r);
+ * r = token index (b*T + t, or the packed row).  out_drop_thr 0 = off. */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token + position embedding (decoder.py:231-243): x[b][t] = wte[ids[b][t]] + wpe[t + pos_offset]  (f32)
@@ -146,7 +153,8 @@ int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const 
  * Gradient normaliser (functions.py:19-24): g <- g / (||g||_2 + 1e-6) over the whole f32 tensor, in place.
  *   ws = 1 float of zero-initialised-by-the-call scratch; g_bf16 (nullable) receives a bf16 copy of the result.
  * --------------------------------------------------------------------------------------------------------- */
-int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16);
+int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16,
+                       unsigned drop_key, unsigned drop_thr, float drop_scale);     /* dropout on the bf16 copy, as i2t_layernorm_bwd */
 
 /* ---------------------------------------------------------------------------------------------------------
  * ConvMLP feature extractor (layers.py:258-282): Conv2d(k x k, padding='same', k even => pad (k-1)/2 before,

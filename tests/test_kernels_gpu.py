@@ -135,6 +135,21 @@ def test_gemm_large_tile_layouts(ops, M, N, K, a_km, b_km):
         assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize('K', [1000, 1050, 50257])
+def test_gemm_large_tile_ragged_k_with_kmajor_b(ops, K, monkeypatch):
+    """dX = dY . W with a reduction length that is no multiple of 64 (the lm_head's 50257): the large-tile kernel relies
+    on the k-major B panel reading as zeros past K; A's pad columns are zero, A's next row is not."""
+    monkeypatch.setenv('I2T_G256_MIN_TILES', '1')
+    M, N = 600, 768
+    ld = (K + 7) // 8 * 8
+    a = torch.zeros(M, ld, dtype=BF16, device=dev())
+    a[:, :K] = rnd(M, K, dtype=BF16, seed=31, scale=0.1)
+    w = rnd(K, N, dtype=BF16, seed=32, scale=0.1)
+    out = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a, w, out, M, N, K, b_kmajor=True)
+    check(f'ragged-K dX K={K}', out, a[:, :K].float() @ w.float(), 2e-3 * math.sqrt(K) / 8, 3e-3)
+
+
 def test_gemm_large_tile_epilogues(ops):
     from image2text_amd import rng
     M, N, K = 2900, 2304, 512
@@ -629,6 +644,42 @@ def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
     sc_ = float(do.float().abs().max())
     for name, got, ref in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
         check(f'attn dropout {name}', got.reshape(B, -1, H, 64), ref.permute(0, 2, 1, 3), 3e-2 * sc_, 1 / 32)
+
+
+def test_fused_backward_dropout_outputs(ops):
+    """The dropout re-application fused into the producers of a gradient copy: grad_normalize / layernorm_bwd (elementwise
+    mask on the bf16 copy only) and attention_bwd (per-token q/k/v multipliers on dq / dk / dv)."""
+    from image2text_amd import rng
+    key, thr = rng.site_key(4242, 77), rng.threshold(0.1)
+    sc = rng.scale(thr)
+    M, d = 300, 768
+    g = rnd(M * d, seed=301) * 2
+    ws, gb = torch.empty(1, device=dev()), torch.empty(M * d, dtype=BF16, device=dev())
+    ops.grad_normalize(g, ws, gb, bf16_drop=(1, key, thr, sc))
+    m = rng.keep_mask(key, M * d, thr).to(dev())
+    check('grad_normalize masked copy', gb, g * m * sc, 1e-7, 1 / 128)
+    x, gam, dy = rnd(M, d, seed=302), rnd(d, seed=303), rnd(M, d, seed=304)
+    mean, rstd = x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    dx0, dx1 = torch.zeros(M, d, device=dev()), torch.zeros(M, d, device=dev())
+    b0, b1 = torch.empty(M, d, dtype=BF16, device=dev()), torch.empty(M, d, dtype=BF16, device=dev())
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, dx0, None, None, M, d, dx_bf16=b0)
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, dx1, None, None, M, d, dx_bf16=b1, bf16_drop=(1, key, thr, sc))
+    assert torch.equal(dx0, dx1), 'the f32 gradient must not see the mask'
+    check('ln_bwd masked copy', b1, dx0 * m.view(M, d) * sc, 1e-7, 1 / 128)
+    B, H, T = 3, 2, 40
+    dd = 64 * H
+    qkv = rnd(B, T, 3 * dd, dtype=BF16, seed=305)
+    do = rnd(B, T, dd, dtype=BF16, seed=306)
+    o, lse = torch.empty(B, T, dd, dtype=BF16, device=dev()), torch.empty(B, H, T, device=dev())
+    q, k, v = qkv[..., :dd], qkv[..., dd:2 * dd], qkv[..., 2 * dd:]
+    ops.attention_fwd(q, k, v, o, lse, B, H, T, T, True)
+    g0, g1 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    for gq, od in ((g0, None), (g1, (2, key, thr, sc))):
+        ops.attention_bwd(q, k, v, o, do, lse, torch.empty(B, H, T, device=dev()), gq[..., :dd], gq[..., dd:2 * dd], gq[..., 2 * dd:],
+                          B, H, T, T, True, out_drop=od)
+    mult = torch.stack([rng.keep_mask((key + t) & 0xFFFFFFFF, B * T, thr) for t in range(3)], 1).float().to(dev()) * sc      # (B*T, 3)
+    ref = g0.float().view(B * T, 3, dd) * mult[:, :, None]
+    check('attention_bwd token multipliers', g1.view(B * T, 3, dd), ref, 1e-6, 1 / 128)
 
 
 def test_attention_packed_varlen(ops):
