@@ -143,6 +143,11 @@ def cpu_baseline(batch=8, steps=6, dropout=0.1):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: libraries that write to fd 1 (RCCL prints a version banner when the first
+    # communicator is created) are sent to stderr, the JSON goes to a private duplicate of the original stdout
+    json_out = os.fdopen(os.dup(1), 'w')
+    sys.stdout.flush()
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -165,7 +170,12 @@ def main():
     torch.manual_seed(0)
     wrapper = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
     opt = FusedAdamW(wrapper.model.parameters(), wrapper.model, lr=6e-4, betas=(0.9, 0.95), weight_decay=0.0)
-    dp = DataParallelGrads(wrapper.model) if world > 1 else None
+    # I2T_FORCE_DP=1: run the gradient exchange even at world size 1 (a 1-rank RCCL group) -- rehearsal of the N > 1 code path on one GPU
+    force_dp = world == 1 and os.environ.get('I2T_FORCE_DP') == '1' and 'RANK' in os.environ
+    if force_dp:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    dp = DataParallelGrads(wrapper.model) if (world > 1 or force_dp) else None
     images, labels = synthetic_batch(args.batch, 224, 64, V, seed=1 + rank)      # each rank draws its own shard
     images, labels = images.to(dev), labels.to(dev)
 
@@ -290,8 +300,8 @@ def main():
                                'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dropout=args.dropout)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 
