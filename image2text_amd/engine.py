@@ -26,6 +26,7 @@ Reference quirks reproduced on purpose (each pinned by a golden fixture):
   * ``normalize_gradients`` (models/functions.py:19-24) rescales the residual-stream gradient to unit L2 norm at
     every block output, per replica.
 """
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -50,15 +51,23 @@ class DropPlan:
     mlp.c_proj (layers.py:485).  The same plan object is kept in the saved context and re-evaluated in backward."""
     KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5}
 
-    def __init__(self, seed: int, tower: int, p: float, p_attn: float):
+    def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0):
+        """compact_layer / live_rows: in that layer only the first ``live_rows`` rows of every sequence are computed after
+        the K/V projections (the encoder's last block: only its CLS rows are ever read), so its sdpa / resid / mlp masks are
+        indexed over those rows alone; ``get`` then appends live_rows to the tuple so that a full-row consumer (the oracle)
+        can place the mask (rows past live_rows are dead, any mask does)."""
         self.seed, self.tower, self.p, self.p_attn = seed, tower, p, p_attn
+        self.compact_layer, self.live_rows = compact_layer, live_rows
 
     def get(self, layer: int, kind: str):
         p = self.p_attn if kind == 'qkv' else self.p
         if p <= 0.0:
             return None
         site = self.tower * 4096 + layer * 16 + self.KINDS[kind]
-        return (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), rng.scale(rng.threshold(p)))
+        e = (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), rng.scale(rng.threshold(p)))
+        if layer == self.compact_layer and kind in ('sdpa', 'resid', 'mlp'):
+            e = e + (self.live_rows,)
+        return e
 
 
 class ParamArena:
@@ -156,6 +165,9 @@ class HotPath:
         # MFMA (channels-last) convolutions when the kernel is 6x6 and every intermediate width is 8/16/32 channels
         self.conv_mfma = (ecfg.feature_extractor_kernel_size[0] == 6 and all(c in (8, 16, 32) for c in chans[1:-1])
                           and chans[0] <= 8 and chans[-1] <= 32 and all(c <= 16 for c in chans[:-1]))
+        # non-causal encoder: its output reads only the CLS rows, so the last block runs on those rows (block_fwd_cls);
+        # I2T_FULL_LAST_BLOCK=1 keeps the full-row form (A/B runs)
+        self.cls_only_last = (not self.enc.causal) and self.enc.L >= 1 and os.environ.get('I2T_FULL_LAST_BLOCK') != '1'
         self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
         self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
         self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
@@ -186,7 +198,8 @@ class HotPath:
             # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run)
             self._seed_state = (getattr(self, '_seed_state', torch.initial_seed()) * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
             if self.enc.dropout > 0 or self.enc.attn_dropout > 0:
-                self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout)
+                self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout,
+                                         compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
             if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
                 self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout)
         return self.arena
@@ -310,6 +323,67 @@ class HotPath:
         ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
                           a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None)
 
+    # ---- the encoder's LAST block, CLS rows only.  The encoder output is ln_f of the first ncls rows (encoder.py:172-173); the
+    # patch rows of the last block feed nothing, forward or backward.  K and V still come from every row; the queries, the
+    # attention output projection and the whole MLP run on B*ncls rows instead of B*T (ncls = 64 of T = 260 in nano-224).
+    def block_fwd_cls(self, pfx: str, x, B, T, d, H, ff, ncls, save: bool, plan: Optional[DropPlan], layer: int):
+        a = self.arena
+        M, Mc = B * T, B * ncls
+        dr = {k: (plan.get(layer, k) if plan is not None else None) for k in ('qkv', 'sdpa', 'resid', 'mlp')}
+        ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
+        ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
+        qkv = self._empty(M, 3 * d, dtype=BF16)
+        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv, M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'), drop=dr['qkv'])
+        q3 = qkv.view(B, T, 3 * d)
+        ao, lse = self._empty(B, ncls, d, dtype=BF16), self._empty(H * Mc)
+        ops.attention_fwd(q3[:, :ncls, :d], q3[..., d:2 * d], q3[..., 2 * d:], ao, lse, B, H, ncls, T, False, drop=dr['sdpa'])
+        xc = self._empty(Mc, d)
+        ops.copy_rows(x, T * d, xc, ncls * d, B, ncls, d)
+        x1 = self._empty(Mc, d)
+        ops.gemm(ao.view(Mc, d), a.W(f'{pfx}.attn.c_proj.weight'), x1, Mc, d, d, bias=a.P(f'{pfx}.attn.c_proj.bias'), residual=xc,
+                 drop=dr['resid'])
+        ln2, m2, r2 = self._empty(Mc, d, dtype=BF16), self._empty(Mc), self._empty(Mc)
+        ops.layernorm_fwd(x1, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, Mc, d)
+        h = self._empty(Mc, ff, dtype=BF16)
+        pre = self._empty(Mc, ff, dtype=BF16) if save else None
+        ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, Mc, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+        x3 = self._empty(Mc, d)
+        ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, Mc, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x1, drop=dr['mlp'])
+        sv = SimpleNamespace(x=x, dr=dr, ln1=ln1, m1=m1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, ln2=ln2, m2=m2, r2=r2, h=h, pre=pre)
+        return x3, (sv if save else None)
+
+    def block_bwd_cls(self, pfx: str, sv, dcls, dx_full, B, T, d, H, ff, ncls):
+        """dcls fp32 [B*ncls, d]: gradient w.r.t. the block's CLS-row output.  dx_full fp32 [B, T, d], zero on entry: receives the
+        gradient w.r.t. the block input (every row: K and V saw them all)."""
+        a = self.arena
+        M, Mc = B * T, B * ncls
+        dr = sv.dr
+        bias = lambda n: n if a.G(n) is not None else None
+        dxb = self._empty(Mc, d, dtype=BF16)
+        ops.grad_normalize(dcls, self._ws[:1], dxb, bf16_drop=dr['mlp'])      # the patch rows' gradient is zero: same norm
+        dpre = self._empty(Mc, ff, dtype=BF16)
+        self._linear_bwd(dxb, Mc, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', bias(f'{pfx}.mlp.c_proj.bias'), dx_out=dpre, act=2,
+                         aux_in=sv.pre)
+        dln = self._empty(Mc, d, dtype=BF16)
+        self._linear_bwd(dpre, Mc, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', bias(f'{pfx}.mlp.c_fc.bias'), dx_out=dln)
+        ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dcls, a.G(f'{pfx}.ln_2.weight'),
+                          a.G(f'{pfx}.ln_2.bias'), Mc, d, dx_accumulate=True, dx_bf16=dxb, bf16_drop=dr['resid'])
+        dao = self._empty(B, ncls, d, dtype=BF16)
+        self._linear_bwd(dxb, Mc, d, d, sv.ao.view(Mc, d), f'{pfx}.attn.c_proj.weight', bias(f'{pfx}.attn.c_proj.bias'),
+                         dx_out=dao.view(Mc, d))
+        dqkv = torch.zeros(B, T, 3 * d, dtype=BF16, device=a.device)            # dq of the patch rows stays zero
+        q3 = sv.qkv.view(B, T, 3 * d)
+        ops.attention_bwd(q3[:, :ncls, :d], q3[..., d:2 * d], q3[..., 2 * d:], sv.ao, dao, sv.lse, self._empty(H * Mc),
+                          dqkv[:, :ncls, :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, ncls, T, False, drop=dr['sdpa'])
+        if dr['qkv'] is not None:
+            ops.dropout_apply(dqkv, M, 3 * d, dr['qkv'])                         # full-row index space, as in the forward GEMM
+        dln1 = self._empty(M, d, dtype=BF16)
+        self._linear_bwd(dqkv.view(M, 3 * d), M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight', bias(f'{pfx}.attn.c_attn.bias'),
+                         dx_out=dln1)
+        ops.copy_rows(dcls, ncls * d, dx_full, T * d, B, ncls, d)               # residual path of the CLS rows
+        ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx_full.view(M, d), a.G(f'{pfx}.ln_1.weight'),
+                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True)
+
     def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None):
         dxb = self._empty(dx.shape[0], d, dtype=BF16)
         for l in reversed(range(len(saves))):
@@ -351,12 +425,16 @@ class HotPath:
         if emb_drop is not None:
             ops.dropout_apply(x, B * T, d, emb_drop)
         saves, cur_x = [], x.view(B * T, d)
-        for l in range(e.L):
+        for l in range(e.L - 1 if self.cls_only_last else e.L):
             cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save, plan, l)
             saves.append(sv)
         Mc = B * e.ncls
-        cls = self._empty(Mc, d)
-        ops.copy_rows(cur_x, T * d, cls, e.ncls * d, B, e.ncls, d)
+        if self.cls_only_last:      # the last block's patch rows are never read: compute its CLS rows only
+            cls, sv = self.block_fwd_cls(f'{self.ep}transformer.h.{e.L - 1}', cur_x, B, T, d, e.H, e.ff, e.ncls, save, plan, e.L - 1)
+            saves.append(sv)
+        else:
+            cls = self._empty(Mc, d)
+            ops.copy_rows(cur_x, T * d, cls, e.ncls * d, B, e.ncls, d)
         mf, rf = self._empty(Mc), self._empty(Mc)
         gf, bf = a.P(f'{self.ep}transformer.ln_f.weight'), a.P(f'{self.ep}transformer.ln_f.bias')
         if self.has_bridge:
@@ -391,8 +469,12 @@ class HotPath:
             ops.layernorm_bwd(denc, ctx.cls, gf, ctx.mf, ctx.rf, dcls, a.G(f'{self.ep}transformer.ln_f.weight'),
                               a.G(f'{self.ep}transformer.ln_f.bias'), Mc, d)
         dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
-        ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
-        self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
+        if self.cls_only_last:
+            self.block_bwd_cls(f'{self.ep}transformer.h.{e.L - 1}', ctx.saves[-1], dcls, dx, B, T, d, e.H, e.ff, e.ncls)
+            self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
+        else:
+            ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
+            self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
         if ctx.emb_drop is not None:
             ops.dropout_apply(dx, B * T, d, ctx.emb_drop)
         ops.sum_over_batch(dx, T * d, a.G(f'{self.ep}cls_token'), B, e.ncls, d, accumulate=True)

@@ -49,6 +49,14 @@ def _planned(entry, x, per_row_third=None):
     if entry is None:
         return x
     from image2text_amd import rng
+    if len(entry) == 5:     # the HIP path computes (and indexes) this site on the first `live` rows of every sequence only: the
+        live = entry[4]     # rows past them are dead in the reference too (nothing reads them), so they keep an all-ones mask
+        out = x.clone()
+        if x.dim() == 4:    # attention probabilities [B, H, Tq, Tk]: live query rows
+            out[:, :, :live] = _planned(entry[:4], x[:, :, :live].contiguous())
+        else:               # [B, T, C]
+            out[:, :live] = _planned(entry[:4], x[:, :live].contiguous())
+        return out
     mode, key, thr, scale = entry
     if mode == 2:       # per (row, third): x is (B, 1, T, 1) ones for third `per_row_third`
         B, _, T, _ = x.shape
