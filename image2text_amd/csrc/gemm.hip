@@ -275,20 +275,20 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 // EPI selects a compile-time epilogue class (the generic form keeps ~30 uniform values and every path alive: in the
 // 256^2 kernel that cost SGPR and VGPR spills whose serialized scratch reloads were ~10 us per tile):
 //   0 generic (all flags at run time)          1 bf16 C, optional bias, optional per-row/third dropout (mode 2)
-//   2 bf16 C, bias + GELU (+ pre-activation out) 3 f32 C, optional bias, optional dropout (mode 1), + residual
-//   4 bf16 C, GELU' of aux_in                   5 f32 C accumulate
+//   2 bf16 C, GELU, optional bias / pre-act out 3 f32 C, optional bias / dropout (mode 1) / residual
+//   4 bf16 C, GELU' of aux_in                   5 f32 C, optional accumulate
 //   7 = 1 with N % 4 != 0 (the lm_head's 50257 columns): the quad that straddles N is stored element-wise, [N, ldc) untouched
 template <int EPI>
 __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
     constexpr bool GEN = EPI == 0;
-    const bool f_bias = (GEN || EPI == 1 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : (EPI == 2);
+    const bool f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : false;
     const bool f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
     const bool f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
     const bool f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
     const bool f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
     const bool f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
-    const bool f_res = GEN ? (p.residual != nullptr) : (EPI == 3);
-    const bool f_acc = GEN ? (p.accumulate != 0) : (EPI == 5);
+    const bool f_res = (GEN || EPI == 3) ? (p.residual != nullptr) : false;
+    const bool f_acc = (GEN || EPI == 5) ? (p.accumulate != 0) : false;
     const bool f_f32 = GEN ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
     bool ok[4];
     int mc[4], nc[4];
@@ -877,10 +877,10 @@ int g256_epilogue_class(const GemmParams& p) {
     if (fast4 && (p.N & 3) != 0 && !p.c_is_f32 && none && !p.bias && !p.residual && !p.accumulate && !p.drop_mode) return 7;
     if (!fast4 || (p.N & 3) != 0) return 0;
     if (!p.c_is_f32 && none && !p.residual && !p.accumulate && p.drop_mode != 1) return 1;
-    if (!p.c_is_f32 && p.bias && p.act == I2T_ACT_GELU && !p.drop_mode && !p.residual && !p.accumulate) return 2;
-    if (p.c_is_f32 && none && p.residual && !p.accumulate && p.drop_mode != 2) return 3;
+    if (!p.c_is_f32 && p.act == I2T_ACT_GELU && !p.drop_mode && !p.residual && !p.accumulate) return 2;
+    if (p.c_is_f32 && none && !p.accumulate && p.drop_mode != 2 && (p.residual || p.bias || p.drop_mode)) return 3;
     if (!p.c_is_f32 && p.act == I2T_ACT_DGELU && !p.bias && !p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 4;
-    if (p.c_is_f32 && none && p.accumulate && !p.bias && !p.residual && !p.drop_mode) return 5;
+    if (p.c_is_f32 && none && !p.bias && !p.residual && !p.drop_mode) return 5;
     return 0;
 }
 
@@ -902,15 +902,22 @@ void launch_g256(hipStream_t s, GemmParams p) {
     const int tiles = p.tiles_m * p.tiles_n;
     const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
     // forward GEMMs (B^T form) meet classes 1-3, the dX GEMMs (B form) classes 1, 4, 5; anything else runs the generic one
-    switch (g256_epilogue_class(p)) {
-        case 1: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 1>), grid, block, 0, s, p); break;
-        case 7: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 7>), grid, block, 0, s, p); break; }
-        case 2: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, s, p); break; }
-        case 3: if (!B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, false, 3>), grid, block, 0, s, p); break; }
-        case 4: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p); break; }
-        case 5: if (B_KMAJOR) { hipLaunchKernelGGL((gemm256_kernel<false, true, 5>), grid, block, 0, s, p); break; }
-        default: hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
-    }
+    static const bool log_cls = getenv("I2T_GEMM_LOG") != nullptr;
+    if (log_cls)
+        fprintf(stderr, "[g256] class %d bk=%d M=%d N=%d K=%d f32=%d bias=%d act=%d auxo=%d auxi=%d res=%d acc=%d drop=%d ldc=%d\n",
+                g256_epilogue_class(p), (int)B_KMAJOR, p.M, p.N, p.K, p.c_is_f32, p.bias != nullptr, p.act, p.aux_out != nullptr,
+                p.aux_in != nullptr, p.residual != nullptr, p.accumulate, p.drop_mode, p.ldc);
+    // forward GEMMs (B^T form) meet classes 1, 2, 3, 5, 7, the dX GEMMs (B form) classes 1, 4, 5; a class that is not built for
+    // the layout runs the generic kernel (NO fall-through between cases: a wrong class dereferences a null epilogue operand)
+    int cls = g256_epilogue_class(p);
+    if (B_KMAJOR ? (cls == 2 || cls == 3 || cls == 7) : (cls == 4)) cls = 0;
+    if (cls == 1) hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 1>), grid, block, 0, s, p);
+    else if (cls == 5) hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 5>), grid, block, 0, s, p);
+    else if (cls == 2) hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, s, p);
+    else if (cls == 3) hipLaunchKernelGGL((gemm256_kernel<false, false, 3>), grid, block, 0, s, p);
+    else if (cls == 7) hipLaunchKernelGGL((gemm256_kernel<false, false, 7>), grid, block, 0, s, p);
+    else if (cls == 4) hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
 }
 
 // dW = A^T . B accumulated into an fp32 C (both operands k-major): K slices spread over the CUs when the output has too

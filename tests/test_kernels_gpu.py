@@ -174,6 +174,23 @@ def test_gemm_large_tile_epilogues(ops):
     od = torch.empty(M, N, dtype=BF16, device=dev())
     ops.gemm(a, b, od, M, N, K, act=2, aux_in=aux)
     check('dgelu', od, base * gelu_grad(aux.float()), 2e-2, 1 / 128)
+    # classes that exist only for the B^T (forward) form must fall back to the generic epilogue with a k-major B
+    bt = b.t().contiguous()
+    o32k = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a, bt, o32k, M, N, K, b_kmajor=True, bias=bias, residual=res)
+    check('k-major B: bias/residual (generic class)', o32k, base + bias + res, 2e-3, 2e-3)
+    ogk = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, bt, ogk, M, N, K, b_kmajor=True, bias=bias, act=1)
+    check('k-major B: gelu (generic class)', ogk, F.gelu(base + bias, approximate='tanh'), 1e-2, 1 / 128)
+    # forward form without bias / pre-activation output / residual (run-time options of classes 2, 3, 5)
+    og = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, og, M, N, K, act=1)
+    check('gelu without bias or aux', og, F.gelu(base, approximate='tanh'), 1e-2, 1 / 128)
+    o32p = torch.empty(M, N, dtype=F32, device=dev())
+    ops.gemm(a, b, o32p, M, N, K, bias=bias)
+    check('f32 + bias, no residual', o32p, base + bias, 2e-3, 2e-3)
+    ops.gemm(a, b, o32p, M, N, K)
+    check('f32 plain', o32p, base, 2e-3, 2e-3)
     outq = torch.empty(M, N, dtype=BF16, device=dev())
     ops.gemm(a, b, outq, M, N, K, bias=bias, drop=(2, key, thr, sc))
     mult = torch.stack([rng.keep_mask((key + t) & 0xFFFFFFFF, M, thr) for t in range(3)], 1).float().to(dev()) * sc
