@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
         mx = quad_max(mx);
         const float m_new = fmaxf(m, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m - m_safe);      // m = -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m - m_safe);      // m = -inf -> 0
         float rs = 0.f;
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
             if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = exp2f(s[kj][r] - m_safe);
+                float p = __builtin_amdgcn_exp2f(s[kj][r] - m_safe);      // raw v_exp_f32: exp2f() adds a denormal-range fix-up per call
                 rs += p;                               // the softmax denominator is dropout-free
                 if (drop_thr) p = keep[r] ? p * drop_scale : 0.f;
                 s[kj][r] = p;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 64 + kj * 16 + 4 * g + r;
-                float p = (key <= qlim && key < Tk) ? exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
+                float p = (key <= qlim && key < Tk) ? __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
                 float dpr = dp[r];                     // gradient w.r.t. the dropped probabilities -> undo the mask
                 if (drop_thr) dpr = keep[r] ? dpr * drop_scale : 0.f;
                 ds[kj][r] = p * (dpr - dl) * SCALE;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
             for (int r = 0; r < 4; ++r) {
                 int q = qt * 64 + qj * 16 + 4 * g + r;
                 bool vis = (q < Tq) && (key < Tk) && (!causal || key <= q + shift);
-                float pv = vis ? exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
+                float pv = vis ? __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
                 float pd = pv, dpr = dp[r];
                 if (drop_thr) {
                     const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * TqMax + min(q, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
