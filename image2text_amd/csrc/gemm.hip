@@ -277,7 +277,8 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 //   0 generic (all flags at run time)          1 bf16 C, optional bias, optional per-row/third dropout (mode 2)
 //   2 bf16 C, GELU, optional bias / pre-act out 3 f32 C, optional bias / dropout (mode 1) / residual
 //   4 bf16 C, GELU' of aux_in                   5 f32 C, optional accumulate
-//   7 = 1 with N % 4 != 0 (the lm_head's 50257 columns): the quad that straddles N is stored element-wise, [N, ldc) untouched
+//   7 plain bf16 or f32 C with N % 4 != 0 (the lm_head's 50257 columns): the quad that straddles N is stored element-wise,
+//     [N, ldc) untouched
 template <int EPI>
 __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
     constexpr bool GEN = EPI == 0;
@@ -289,7 +290,7 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
     const bool f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
     const bool f_res = (GEN || EPI == 3) ? (p.residual != nullptr) : false;
     const bool f_acc = (GEN || EPI == 5) ? (p.accumulate != 0) : false;
-    const bool f_f32 = GEN ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
+    const bool f_f32 = (GEN || EPI == 7) ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
     bool ok[4];
     int mc[4], nc[4];
 #pragma unroll
@@ -368,7 +369,13 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
     if (f_f32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (ok[q]) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m[q] * p.ldc + n4[q]) = v[q];
+            if (!ok[q]) continue;
+            float* c = reinterpret_cast<float*>(p.C) + (size_t)m[q] * p.ldc + n4[q];
+            if (EPI == 7 && n4[q] + 4 > p.N) {              // the quad that straddles N
+                for (int r = 0; r < p.N - n4[q]; ++r) c[r] = v[q][r];
+            } else {
+                *reinterpret_cast<f32x4*>(c) = v[q];
+            }
         }
     } else {
 #pragma unroll
@@ -874,7 +881,7 @@ int g256_epilogue_class(const GemmParams& p) {
                        (!p.aux_out || (p.ld_aux_out & 3) == 0);
     const bool none = p.act == I2T_ACT_NONE && !p.aux_out;
     // bias-free only: a straddling quad would read bias[N .. N+2]
-    if (fast4 && (p.N & 3) != 0 && !p.c_is_f32 && none && !p.bias && !p.residual && !p.accumulate && !p.drop_mode) return 7;
+    if (fast4 && (p.N & 3) != 0 && none && !p.bias && !p.residual && !p.accumulate && !p.drop_mode) return 7;
     if (!fast4 || (p.N & 3) != 0) return 0;
     if (!p.c_is_f32 && none && !p.residual && !p.accumulate && p.drop_mode != 1) return 1;
     if (!p.c_is_f32 && p.act == I2T_ACT_GELU && !p.drop_mode && !p.residual && !p.accumulate) return 2;
@@ -934,6 +941,7 @@ bool launch_g256_dw(hipStream_t s, GemmParams p) {
         return true;
     }
     int splits = n_cu / tiles;
+    if (const char* e = getenv("I2T_DW_SPLITS")) splits = atoi(e);      // experiments
     int per = ((nk_all + splits - 1) / splits + 1) & ~1;          // even number of K-tiles per slice
     if (per < 8) per = 8;
     splits = (nk_all + per - 1) / per;

@@ -105,6 +105,10 @@ def test_gemm_vocab_shapes(ops):
     ref = h.float() @ wte.float().t()
     check('logits', logits[:, :V], ref, 2e-2, 1 / 128)
     assert float(logits[:, V:].abs().max()) == 0.0, 'pad columns must stay untouched'
+    logits32 = torch.zeros(M, Vp, dtype=F32, device=dev())          # the decode path keeps fp32 logits for the argmax
+    ops.gemm(h, wte, logits32, M, V, d)
+    check('logits f32', logits32[:, :V], ref, 2e-3, 2e-3)
+    assert float(logits32[:, V:].abs().max()) == 0.0, 'pad columns must stay untouched (f32)'
     dl = torch.zeros(M, Vp, dtype=BF16, device=dev())
     dl[:, :V] = rnd(M, V, dtype=BF16, seed=10, scale=0.01)
     dh = torch.empty(M, d, dtype=F32, device=dev())

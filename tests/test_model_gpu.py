@@ -401,7 +401,7 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
     # the dropout-free loss differs (masks really were applied) and a new step draws new masks
     with torch.no_grad():
         clean = orc.lm_step_text_segment(sd, cfg, images, labels, tok)
-    assert abs(float(clean) - float(oloss)) > 1e-4          # (how far apart depends on the step seed: 1e-3 .. 1e-2 observed)
+    assert abs(float(clean) - float(oloss)) > 1e-6          # not the same number (how far apart depends on the step seed: 3e-5 .. 1e-2 observed)
     w.zero_grad()
     loss2, _ = w.train_step(images.to(dev()), labels.to(dev()))
     assert abs(float(loss2.detach()) - float(loss.detach())) > 1e-4
