@@ -604,6 +604,11 @@ __device__ __forceinline__ bf16x8 dma_frag_read(const unsigned char* lds, int r0
 //   * operands go through buffer descriptors (buffer_load_dwordx4 ... lds): one loop-invariant 32-bit voffset per
 //     thread and chunk, the K advance in the scalar offset, out-of-range rows / K-tail served as zeros by the range
 //     check -- no 64-bit address math or predicates in the loop (the first version spilled 250+ VGPRs on them).
+// s_setprio(1) around the MFMA clusters (cdna_hip_programming.md T5): measured -3 % end to end on this schedule (two
+// builds, same box, 2 x 10 steps each), so it stays off.
+#ifndef G2_SETPRIO
+#define G2_SETPRIO 0
+#endif
 constexpr int G2_UNIT = 128 * 128;                     // 16 KiB
 constexpr int G2_SMEM = 8 * G2_UNIT + 8 * 4096;        // 128 KiB of staging slots + a 4 KiB epilogue transpose pad per wave
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -771,6 +776,7 @@ struct G2 {
     }
     template <int SUBA, int SUBB, int KS>
     __device__ __forceinline__ void mma(f32x4 (&acc)[8][4], const bf16x8 (&ra)[8], const bf16x8 (&rb)[4]) {
+        if (G2_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -778,6 +784,7 @@ struct G2 {
                 acc[SUBA * 4 + i][SUBB * 2 + j] =     // UNSWAP (atomic epilogue): lane holds C[4 (lane>>4) + r][lane&15] of each 16 x 16 block
                     UNSWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[KS * 4 + i], rb[KS * 2 + j], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
+        if (G2_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
     template <int LG>
     __device__ __forceinline__ void fence() {     // my part of unit P+2 landed, my reads of phase P-2 retired; then everyone's

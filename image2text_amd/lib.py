@@ -5,7 +5,7 @@ import os
 import torch  # noqa: F401  -- must come first: libi2t_hip.so has to bind to the HIP runtime torch has already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libi2t_hip.so')
+LIB_PATH = os.environ.get('I2T_LIB') or os.path.join(_HERE, 'csrc', 'libi2t_hip.so')      # I2T_LIB: A/B builds of the same ABI
 
 P, I, L, F, I64, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64, C.c_uint
 
