@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=512, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=1024, help='images per GPU per step')
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=4096, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
@@ -245,6 +245,8 @@ def main():
     cap_s = None
     if not args.no_decode:
         wrapper.eval()
+        opt.zero_grad()
+        torch.cuda.empty_cache()              # hand the training step's cached blocks back before the decode leg allocates its own
         from image2text_amd.decoding import ConcurrentGreedyDecoder
         Bd, S = args.decode_batch, args.decode_streams
         dimgs = [synthetic_batch(Bd, 224, 64, V, seed=100 + rank * S + i)[0].to(dev) for i in range(S)]
