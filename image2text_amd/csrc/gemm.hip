@@ -934,244 +934,6 @@ void launch_g256(hipStream_t s, GemmParams p) {
     else hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// 128 x 256 x 64 tile, 4 waves (1 x 4, 128 x 64 outputs each -- the same wave tile as above), TWO workgroups per CU.
-// Why: at one workgroup per CU the epilogue of a tile runs with the MFMA pipes idle (every wave of the CU is in it);
-// with two independent 4-wave workgroups per CU (one wave of each per SIMD, 256 VGPRs each) one workgroup's K loop
-// fills the pipes while the other writes its tile out.  LDS budget 72 KiB per workgroup:
-//   A units (sub s = rows s*64 .. +63, 64 x 64 k = 8 KiB): ring of 3 slots, index (2T + s) mod 3 kept in a scalar;
-//   B units (as above, 128 columns x 64 k = 16 KiB): B-first always in slot 0, B-second in slot 1;
-//   4 x 4 KiB epilogue transpose pads.
-// Schedule (same phases / register roles / read placement as the 8-wave kernel; only staging differs -- a unit is staged
-// as late as its landing deadline allows, because a slot is free two phases after its last read and B is read in ONE phase):
-//   phase f = 0 stages A0(T+1) (read from f = 3), f = 1 B-first(T+1), f = 2 B-second(T+1) then A1(T+1), f = 3 nothing;
-//   per thread 2 DMA loads per A unit, 4 per B unit; the fences wait vmcnt 2, 2, 6, 6 (f = 0..3): exactly the loads
-//   issued after the unit that phase reads first.  Row-major A only (forward and dX GEMMs).
-constexpr int G3_A_SLOT = 64 * 128;                     // 8 KiB
-constexpr int G3_B_BASE = 3 * G3_A_SLOT;                // 24 KiB
-constexpr int G3_PAD_BASE = G3_B_BASE + 2 * G2_UNIT;    // 56 KiB
-constexpr int G3_SMEM = G3_PAD_BASE + 4 * 4096;         // 72 KiB
-
-template <bool B_KMAJOR>
-struct G3 {
-    static constexpr int FB = B_KMAJOR ? 2 : 1;
-    static constexpr int LG0 = 4 + 4 * FB, LG1 = 4, LG2 = 4, LG3 = 4 + 4 * FB;       // LGKM ops issued in the previous phase
-
-    unsigned char* smem;
-    unsigned lds0;
-    int lane, wc, wave_off, nk, tb, ia;          // ia = (2 T) mod 3: ring slot of the current K-tile's A-sub0
-    int va[2][2], vb[2][4];
-    unsigned step_a, step_b;
-    G2Tile cur, nxt;
-
-    __device__ __forceinline__ static G2Tile tile_desc(const GemmParams& p, int idx, int ntiles) {
-        G2Tile d;
-        d.t0 = 0;
-        if (idx >= ntiles) {
-            d.a = p.A; d.b = p.B; d.a_bytes = 0; d.b_bytes = 0; d.m0 = 0; d.n0 = 0;
-            return d;
-        }
-        int tile_m, tile_n;
-        tile_coords(p, idx, tile_m, tile_n, 8);
-        d.m0 = tile_m * 128; d.n0 = tile_n * 256;
-        d.a = p.A + (size_t)d.m0 * p.lda;
-        d.a_bytes = (unsigned)(min(p.M - d.m0, 128) * p.lda * 2);
-        if (!B_KMAJOR) {
-            d.b = p.B + (size_t)d.n0 * p.ldb;
-            d.b_bytes = (unsigned)(min(p.N - d.n0, 256) * p.ldb * 2);
-        } else {
-            d.b = p.B + d.n0;
-            d.b_bytes = (unsigned)(((size_t)(p.K - 1) * p.ldb + min(((p.N + 7) & ~7) - d.n0, 256)) * 2);
-        }
-        return d;
-    }
-    __device__ __forceinline__ void init(const GemmParams& p, unsigned char* smem_, int tid) {
-        smem = smem_;
-        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        wc = wave; wave_off = wave * 1024;
-        nk = p.g2_nk;
-        step_a = 128u;
-        step_b = B_KMAJOR ? 128u * (unsigned)p.ldb : 128u;
-        ia = 0;
-        init_lane(p, tid);
-    }
-    __device__ __forceinline__ void init_lane(const GemmParams& p, int tid) {
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63;
-        {
-            const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-            const int kr = 8 * g4 + q;
-            tb = kr * 256 + ((((wc * 4) + (pp >> 1)) ^ (cf_swz<false>(kr) << 1)) << 4) + (pp & 1) * 8;
-        }
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int c = u * 256 + tid, r = c >> 3, kc = (c & 7) ^ (r & 7);
-                va[sub][u] = (sub * 64 + r) * p.lda * 2 + kc * 16;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = u * 256 + tid;
-                if (!B_KMAJOR) {
-                    const int r = c >> 3, kc = (c & 7) ^ (r & 7);
-                    vb[sub][u] = ((r >> 5) * 64 + sub * 32 + (r & 31)) * p.ldb * 2 + kc * 16;
-                } else {
-                    const int kr = c >> 4, ul = ((c & 15) ^ (cf_swz<false>(kr) << 1)) * 8;
-                    vb[sub][u] = (kr * p.ldb + (ul >> 5) * 64 + sub * 32 + (ul & 31)) * 2;
-                }
-            }
-        }
-    }
-    __device__ __forceinline__ static int mod3(int x) { return x >= 3 ? x - 3 : x; }
-
-    __device__ __forceinline__ void dma(const bf16_t* base, unsigned bytes, unsigned lds_addr, int voff, unsigned so) {
-        const unsigned long long b = (unsigned long long)base;
-        const u32x4 rs = {(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(so) : "memory");
-    }
-    // A-sub SUB of K-tile T into ring slot `slot` (run-time); T >= nk continues into the next output tile
-    template <int SUB>
-    __device__ __forceinline__ void stage_a(int T, int slot) {
-        const bool nx = T >= nk;
-        const unsigned so = (unsigned)(nx ? T - nk : T) * step_a;
-        const unsigned dst = lds0 + slot * G3_A_SLOT + wave_off;
-        dma(nx ? nxt.a : cur.a, nx ? nxt.a_bytes : cur.a_bytes, dst, va[SUB][0], so);
-        dma(nx ? nxt.a : cur.a, nx ? nxt.a_bytes : cur.a_bytes, dst + 4096, va[SUB][1], so);
-    }
-    template <int SLOT, int SUB>
-    __device__ __forceinline__ void stage_b(int T) {
-        const bool nx = T >= nk;
-        const unsigned so = (unsigned)(nx ? T - nk : T) * step_b;
-        const unsigned dst = lds0 + G3_B_BASE + SLOT * G2_UNIT + wave_off;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dma(nx ? nxt.b : cur.b, nx ? nxt.b_bytes : cur.b_bytes, dst + u * 4096, vb[SUB][u], so);
-    }
-    template <int KS>
-    __device__ __forceinline__ void read_a(bf16x8 (&ra)[8], int slot) {
-        const unsigned char* base = smem + slot * G3_A_SLOT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[KS * 4 + i] = dma_frag_read<false, false>(base, i * 16, KS, lane);
-    }
-    template <int SLOT>
-    __device__ __forceinline__ void read_b(bf16x8 (&rb)[4]) {
-        if constexpr (B_KMAJOR) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned char* a = smem + G3_B_BASE + SLOT * G2_UNIT + ks * 8192 + (tb ^ (j << 5));
-                    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 1024);
-                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    rb[ks * 2 + j] = __builtin_bit_cast(bf16x8, v);
-                }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    rb[ks * 2 + j] = dma_frag_read<false, false>(smem + G3_B_BASE + SLOT * G2_UNIT, wc * 32 + j * 16, ks, lane);
-        }
-    }
-    template <int SUBA, int SUBB, int KS>
-    __device__ __forceinline__ void mma(f32x4 (&acc)[8][4], const bf16x8 (&ra)[8], const bf16x8 (&rb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[SUBA * 4 + i][SUBB * 2 + j] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
-    }
-    template <int VM, int LG>
-    __device__ __forceinline__ void fence() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(VM), "n"(LG) : "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    // one K-tile (4 phases).  FIRST = the sub of B that is "B-first" for this tile (0 on even tiles, 1 on odd ones):
-    // rbf / rbs are the register sets of B-first / B-second.
-    template <int FIRST, bool LAST>
-    __device__ __forceinline__ void one_tile(int T, f32x4 (&acc)[8][4], bf16x8 (&ra)[8], bf16x8 (&rbf)[4], bf16x8 (&rbs)[4]) {
-        constexpr int SECOND = FIRST ^ 1;
-        const int s0 = ia, s1 = mod3(ia + 1), s2 = mod3(ia + 2);
-        fence<2, LG3>();  read_a<1>(ra, s0);  read_b<1>(rbs);  stage_a<0>(T + 1, s2);
-        mma<0, FIRST, 0>(acc, ra, rbf);  mma<0, FIRST, 1>(acc, ra, rbf);
-        fence<2, LG0>();  stage_b<0, SECOND>(T + 1);              // next tile's B-first is this tile's "second" sub
-        mma<0, SECOND, 0>(acc, ra, rbs);  read_a<0>(ra, s1);  mma<0, SECOND, 1>(acc, ra, rbs);
-        fence<6, LG1>();  read_a<1>(ra, s1);  stage_b<1, FIRST>(T + 1);  stage_a<1>(T + 1, s0);
-        mma<1, SECOND, 0>(acc, ra, rbs);  mma<1, SECOND, 1>(acc, ra, rbs);
-        fence<6, LG2>();  if (!LAST) read_b<0>(rbs);              // B-first(T+1) = sub SECOND: its register set is rbs
-        mma<1, FIRST, 0>(acc, ra, rbf);  if (!LAST) read_a<0>(ra, s2);  mma<1, FIRST, 1>(acc, ra, rbf);
-        ia = s2;
-    }
-};
-
-template <bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm128_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G3_SMEM];
-    const int tid = threadIdx.x;
-    const int G = gridDim.x, bid = blockIdx.x, ntiles = p.tiles_m * p.tiles_n;
-    const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
-    const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-
-    G3<B_KMAJOR> g;
-    g.init(p, smem, tid);
-    g.cur = g.tile_desc(p, first, ntiles);
-    g.nxt = g.tile_desc(p, first + G, ntiles);
-    f32x4 acc[8][4];
-    bf16x8 ra[8], rb0[4], rb1[4];
-
-    // prologue: K-tile 0 complete (A0 -> ring 0, B-first = sub 0 -> slot 0, B-second = sub 1 -> slot 1, A1 -> ring 1)
-    g.template stage_a<0>(0, 0);  g.template stage_b<0, 0>(0);  g.template stage_b<1, 1>(0);  g.template stage_a<1>(0, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // A0 and B-first landed (B-second 4 + A1 2 loads may fly)
-    __builtin_amdgcn_s_barrier();
-    g.template read_b<0>(rb0);
-    g.template read_a<0>(ra, 0);
-
-    for (int idx = first; idx < ntiles; idx += G) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < g.nk - 2; t += 2) {
-            g.template one_tile<0, false>(t, acc, ra, rb0, rb1);
-            g.template one_tile<1, false>(t + 1, acc, ra, rb1, rb0);
-        }
-        g.template one_tile<0, false>(g.nk - 2, acc, ra, rb0, rb1);
-        g.template one_tile<1, true>(g.nk - 1, acc, ra, rb1, rb0);
-        const int m0 = g.cur.m0, n0 = g.cur.n0;
-        g.cur = g.nxt;
-        g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
-        {
-            int lane_e = tid & 63;
-            asm volatile("" : "+v"(lane_e));
-            epilogue_tile_tr<8, EPI>(p, acc, m0, n0 + g.wc * 64, lane_e, smem + G3_PAD_BASE + (g.wave_off << 2));
-        }
-        g.init_lane(p, tid);
-        g.template read_b<0>(rb0);          // the reads the LAST tile left out: B-first (sub 0, nk is even) and A0.ks0 of the next tile
-        g.template read_a<0>(ra, g.ia);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <bool B_KMAJOR>
-void launch_g128(hipStream_t s, GemmParams p) {
-    const int n_cu = g256_cus();
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = (p.N + 255) / 256;
-    p.g2_splits = 1; p.g2_nk = (((p.K + 63) >> 6) + 1) & ~1;
-    const int tiles = p.tiles_m * p.tiles_n;
-    const dim3 grid(tiles < 2 * n_cu ? tiles : 2 * n_cu), block(256);
-    int cls = g256_epilogue_class(p);
-    if (B_KMAJOR ? (cls == 2 || cls == 3 || cls == 7) : (cls == 4)) cls = 0;
-    if (cls == 1) hipLaunchKernelGGL((gemm128_kernel<B_KMAJOR, 1>), grid, block, 0, s, p);
-    else if (cls == 5) hipLaunchKernelGGL((gemm128_kernel<B_KMAJOR, 5>), grid, block, 0, s, p);
-    else if (cls == 2) hipLaunchKernelGGL((gemm128_kernel<false, 2>), grid, block, 0, s, p);
-    else if (cls == 3) hipLaunchKernelGGL((gemm128_kernel<false, 3>), grid, block, 0, s, p);
-    else if (cls == 7) hipLaunchKernelGGL((gemm128_kernel<false, 7>), grid, block, 0, s, p);
-    else if (cls == 4) hipLaunchKernelGGL((gemm128_kernel<true, 4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm128_kernel<B_KMAJOR, 0>), grid, block, 0, s, p);
-}
-
 // dW = A^T . B accumulated into an fp32 C (both operands k-major): K slices spread over the CUs when the output has too
 // few 256^2 tiles, partial tiles combined with float atomics (C already holds the value to accumulate onto); with enough
 // tiles (the tied lm_head / embedding gradient) one slice and a plain read-add-write epilogue.
@@ -1387,9 +1149,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     const char* mt_env = getenv("I2T_G256_MIN_TILES");
     const long min_tiles = mt_env ? atol(mt_env) : 40;
     if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
-        static const bool use_g128 = sel && !strcmp(sel, "g128");
-        if (use_g128) { if (b_kmajor) launch_g128<true>(s, p); else launch_g128<false>(s, p); }
-        else if (b_kmajor) launch_g256<true>(s, p);
+        if (b_kmajor) launch_g256<true>(s, p);
         else launch_g256<false>(s, p);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(256)");
         return I2T_OK;
