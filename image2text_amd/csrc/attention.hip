@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
         }
         if (!wave_on) continue;
         const int nkj = min(4, (last_key - kt * 64) / 16 + 1);          // 16-key blocks of this tile that hold a visible key
-        f32x4 s[4];
+        // every key of the tile visible to every row of this wave (wave-uniform): no per-element compare / select
+        const bool full = kt * 64 + 63 < Tk && (!causal || kt * 64 + 63 <= q0 + shift);
+        f32x4 s[4];                                                      // RAW scores; the 1/sqrt(d) log2(e) factor rides in the exp's fma
         float mx = -INFINITY;
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
@@ -187,17 +189,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
                 a = f32x4{0.f, 0.f, 0.f, 0.f};
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 0, lane), qf0, a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(kt_lds, kj * 16, 1, lane), qf1, a, 0, 0, 0);
+                if (!full) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int key = kt * 64 + kj * 16 + 4 * g + r;
-                    float v = (key <= qlim && key < Tk) ? a[r] * (SCALE * LOG2E) : -INFINITY;
-                    a[r] = v;
-                    mx = fmaxf(mx, v);
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + kj * 16 + 4 * g + r;
+                        if (!(key <= qlim && key < Tk)) a[r] = -INFINITY;
+                    }
                 }
+                mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
             }
             s[kj] = a;
         }
-        mx = quad_max(mx);
+        mx = quad_max(mx) * (SCALE * LOG2E);                             // (-inf stays -inf; the factor is positive)
         const float m_new = fmaxf(m, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_safe);      // m = -inf -> 0
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
             if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kj][r] - m_safe);      // raw v_exp_f32: exp2f() adds a denormal-range fix-up per call
+                float p = __builtin_amdgcn_exp2f(s[kj][r] * (SCALE * LOG2E) - m_safe);      // one fma + raw v_exp_f32
                 rs += p;                               // the softmax denominator is dropout-free
                 if (drop_thr) p = keep[r] ? p * drop_scale : 0.f;
                 s[kj][r] = p;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
         }
         if (!wave_on) continue;
         const int nkj = min(4, (last_key - kt * 64) / 16 + 1);
+        const bool full = kt * 64 + 63 < Tk && (!causal || kt * 64 + 63 <= q0 + shift);
         f32x4 ds[4];
 #pragma unroll
         for (int kj = 0; kj < 4; ++kj) {
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 64 + kj * 16 + 4 * g + r;
-                float p = (key <= qlim && key < Tk) ? __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - lse2) : 0.f;
+                float p = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - lse2);
+                if (!full && !(key <= qlim && key < Tk)) p = 0.f;
                 float dpr = dp[r];                     // gradient w.r.t. the dropped probabilities -> undo the mask
                 if (drop_thr) dpr = keep[r] ? dpr * drop_scale : 0.f;
                 ds[kj][r] = p * (dpr - dl) * SCALE;
@@ -468,6 +473,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
         }
         if (!wave_on) continue;
         const int nqj = min(4, (Tq - 1 - qt * 64) / 16 + 1);          // 16-row query blocks of this tile that exist
+        // every (query, key) pair of this wave's 64 x 16 block valid and visible (wave-uniform)
+        const bool full = qt * 64 + 63 < Tq && k0 + 15 < Tk && (!causal || k0 + 15 <= qt * 64 + shift);
         f32x4 p[4], ds[4];
 #pragma unroll
         for (int qj = 0; qj < 4; ++qj) {
@@ -486,8 +493,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int q = qt * 64 + qj * 16 + 4 * g + r;
-                bool vis = (q < Tq) && (key < Tk) && (!causal || key <= q + shift);
-                float pv = vis ? __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]) : 0.f;
+                float pv = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]);
+                if (!full && !((q < Tq) && (key < Tk) && (!causal || key <= q + shift))) pv = 0.f;
                 float pd = pv, dpr = dp[r];
                 if (drop_thr) {
                     const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * TqMax + min(q, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
