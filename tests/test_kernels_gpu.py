@@ -154,6 +154,56 @@ def test_gemm_large_tile_ragged_k_with_kmajor_b(ops, K, monkeypatch):
     check(f'ragged-K dX K={K}', out, a[:, :K].float() @ w.float(), 2e-3 * math.sqrt(K) / 8, 3e-3)
 
 
+def test_gemm_large_tile_random_shapes(ops, monkeypatch):
+    """Seeded random problems forced through the persistent large-tile kernels (every size, not only the ones the
+    heuristic would send there): ragged M / N down to a single partial tile, K from 2 K-tiles up, forward (B^T), dX (B) and
+    dW (A^T.B, K slices + atomics) forms, with the epilogue options each form meets in the model."""
+    monkeypatch.setenv('I2T_G256_MIN_TILES', '1')
+    rs = np.random.RandomState(1234)
+    for case in range(36):
+        form = ('fwd', 'dx', 'dw')[case % 3]
+        M = int(rs.choice([8, 100, 256, 257, 700, 1500]))
+        N = int(rs.choice([8, 64, 256, 264, 520, 1000]))
+        if form == 'dw':
+            M, N = max(256, M // 8 * 8), max(256, N // 8 * 8)          # dW route: M, N >= 256, multiples of 8 (k-major leading dims)
+            K = int(rs.choice([1024, 1111 * 8, 4096 + 8, 20000]))
+        elif form == 'dx':
+            N = N // 8 * 8 if N >= 8 else 8
+            K = int(rs.choice([128, 256, 1000, 3072]))
+        else:
+            K = int(rs.choice([128, 256, 768, 2048]))
+        a = rnd(M, K, dtype=BF16, seed=1000 + case, scale=0.5)
+        b = rnd(N, K, dtype=BF16, seed=2000 + case, scale=0.5)
+        ref = a.float() @ b.float().t()
+        tag = f'case {case} {form} M={M} N={N} K={K}'
+        tol = 2e-3 * math.sqrt(K) / 8
+        if form == 'fwd':
+            bias = rnd(N, seed=3000 + case)
+            if N % 4 == 0:
+                res = rnd(M, N, seed=4000 + case)
+                out = torch.empty(M, N, dtype=F32, device=dev())
+                ops.gemm(a, b, out, M, N, K, bias=bias, residual=res)
+                check(tag + ' f32+bias+res', out, ref + bias + res, tol, 2e-3)
+            outb = torch.empty(M, (N + 7) // 8 * 8, dtype=BF16, device=dev())
+            ops.gemm(a, b, outb, M, N, K, bias=bias, act=1)
+            check(tag + ' gelu', outb[:, :N], F.gelu(ref + bias, approximate='tanh'), 10 * tol + 1e-2, 1 / 128)
+        elif form == 'dx':
+            bt = b.t().contiguous()                                   # [K][N], N contiguous
+            out = rnd(M, N, seed=5000 + case)
+            base = out.clone()
+            ops.gemm(a, bt, out, M, N, K, b_kmajor=True, accumulate=True)
+            check(tag + ' f32 accumulate', out, base + ref, tol, 2e-3)
+            outb = torch.empty(M, N, dtype=BF16, device=dev())
+            ops.gemm(a, bt, outb, M, N, K, b_kmajor=True)
+            check(tag + ' bf16', outb, ref, 10 * tol + 1e-2, 1 / 128)
+        else:
+            at, bt = a.t().contiguous(), b.t().contiguous()           # [K][M], [K][N]
+            out = rnd(M, N, seed=6000 + case)
+            base = out.clone()
+            ops.gemm(at, bt, out, M, N, K, a_kmajor=True, b_kmajor=True, accumulate=True)
+            check(tag + ' dW accumulate', out, base + ref, 2 * tol, 3e-3)
+
+
 def test_gemm_large_tile_epilogues(ops):
     from image2text_amd import rng
     M, N, K = 2900, 2304, 512
