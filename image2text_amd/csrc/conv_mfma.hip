@@ -159,6 +159,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
         for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int CH = CP / 8;
     constexpr int NSTEP = NTAP * CH / 4;                      // k-steps of 4 (tap, chunk) groups
+    if constexpr (CP >= 16) {
+        // 16 / 32 input channels: one MFMA k-step covers 2 / 1 horizontal taps of ONE kernel row, so for a fixed
+        // horizontal tap (pair) the 4 output rows x 6 vertical taps of a wave read only 9 distinct patch-row fragments:
+        // keep them in registers and walk the vertical taps -- (9 + 6 NT) LDS reads per 24 NT MFMAs instead of 30 NT
+        // (the k-step-major loop re-read every patch fragment once per vertical tap; the kernel is LDS-read bound).
+        constexpr int TPM = 32 / CP;                          // horizontal taps per MFMA k-step
+        const int kxo = TPM == 2 ? (g >> 1) : 0, ch = TPM == 2 ? (g & 1) : g;
+#pragma unroll 1
+        for (int m = 0; m < KS / TPM; ++m) {
+            const int kx = m * TPM + kxo;
+            bf16x8 pf[TS / 4 + KS - 1];                       // rows 4 w .. 4 w + 8 of the halo patch
+#pragma unroll
+            for (int y = 0; y < 4 + KS - 1; ++y)
+                pf[y] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((4 * w + y) * PW + li + kx) * CP + ch * 8));
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int kg = (ky * KS + kx) * CH + ch;
+                bf16x8 fw[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (16 * t + li) * WROW + kg * 8));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], pf[r + ky], acc[r][t], 0, 0, 0);
+            }
+        }
+    } else
 #pragma unroll 2
     for (int s = 0; s < NSTEP; ++s) {
         const int kg = 4 * s + g;
