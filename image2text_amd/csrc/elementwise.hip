@@ -171,7 +171,16 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(bf16_t* __restrict__
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ ws) {
     __shared__ float red[16];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {            // 4 independent 16-byte loads in flight per lane
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(g)[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+    }
+    for (; i < n4; i += stride) {
         f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
