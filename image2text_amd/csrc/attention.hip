@@ -490,6 +490,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(do_lds, qj * 16, 1, lane), vf1, dp, 0, 0, 0);
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_lds + qj * 16 + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_lds + qj * 16 + 4 * g);
+            bool keep4[4] = {true, true, true, true};
+            if (drop_thr) {
+                // This lane's 4 elements sit in 4 different query rows (one hash each).  With an even TkMax the lanes of
+                // keys (2c, 2c+1) read the two 16-bit fields of the SAME hash: the even lane hashes rows r = 0, 1, the
+                // odd lane rows 2, 3, and they swap (2 hashes + 2 lane exchanges instead of 4 hashes per lane).
+                const unsigned rb = ((unsigned)b * H + h) * TqMax;
+                if ((TkMax & 1) == 0) {
+                    const int odd = li & 1, ra_ = 2 * odd;
+                    unsigned mine[2], both[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int q = min(qt * 64 + qj * 16 + 4 * g + ra_ + e, Tq - 1);
+                        mine[e] = dropout_hash(drop_key, ((rb + q) * (unsigned)TkMax + (unsigned)key) >> 1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned other = (unsigned)__shfl_xor((int)mine[e], 1, 64);
+                        both[e] = odd ? other : mine[e];            // rows 0, 1 (hashed by the even lane)
+                        both[2 + e] = odd ? mine[e] : other;        // rows 2, 3 (hashed by the odd lane)
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) keep4[r] = (odd ? (both[r] >> 16) : (both[r] & 0xffffu)) >= drop_thr;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        keep4[r] = dropout_keep(drop_key, (rb + min(qt * 64 + qj * 16 + 4 * g + r, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int q = qt * 64 + qj * 16 + 4 * g + r;
@@ -497,7 +525,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                 if (!full && !((q < Tq) && (key < Tk) && (!causal || key <= q + shift))) pv = 0.f;
                 float pd = pv, dpr = dp[r];
                 if (drop_thr) {
-                    const bool keep = dropout_keep(drop_key, (((unsigned)b * H + h) * TqMax + min(q, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
+                    const bool keep = keep4[r];
                     pd = keep ? pv * drop_scale : 0.f;     // dV sees the dropped probabilities
                     dpr = keep ? dpr * drop_scale : 0.f;
                 }
