@@ -34,7 +34,11 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
     }
 }
 
-// one wave per (b, h): keys strided over lanes for the scores, head dims over lanes for the output
+// One wave per (b, h).  Both passes over the cache use 16-byte loads with 8 lanes per key (lane = 8 * key_in_group + c,
+// c = 16-byte chunk of the 64-wide head): one wave-instruction fetches 8 keys x 128 B = 8 full cache lines (the
+// lane-per-key form issued 8 loads that each touched 64 lines).  Scores: per-lane partial dot over its 8 dims, 3 xor
+// shuffles inside the 8-lane group.  Output: per-lane partial sum over its key stripe for its 8 dims, 3 xor shuffles
+// across the 8 stripes.  The step is HBM-bound on the K/V cache (B x H x t x 256 B per call).
 constexpr int DEC_MAX_KEYS = 1024;
 // append_dm > 0: q points at a packed [q | k | v] row of width 3*append_dm; the new token's k/v (this head's 64
 // columns) are written into the cache at *pos by this workgroup and attended to from LDS (fused kv_append).
@@ -60,28 +64,37 @@ __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __re
         vb[(size_t)(n - 1) * cache_rs + lane] = vv;
     }
     __syncthreads();
+    const int kg = lane >> 3, c = lane & 7;                  // key within a group of 8, 16-byte chunk of the head
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = qs[c * 8 + e];
     float mx = -INFINITY;
-    if (append_dm > 0 && lane == ((n - 1) & 63)) {
+    if (append_dm > 0 && lane == 0) {
         float s = 0.f;
-        for (int c = 0; c < 64; ++c) s += kn[c] * qs[c];
+        for (int e = 0; e < 64; ++e) s += kn[e] * qs[e];
         s *= 0.125f;
         ps[n - 1] = s;
         mx = s;
     }
-    for (int key = lane; key < n_cached; key += 64) {
-        const u32x4* kr = reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs);
+    for (int k0 = 0; k0 < n_cached; k0 += 8) {
+        const int key = k0 + kg;
         float s = 0.f;
+        if (key < n_cached) {
+            const u32x4 kk = *reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs + c * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            u32x4 kk = kr[c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s += bf16lo(kk[e]) * qs[c * 8 + 2 * e] + bf16hi(kk[e]) * qs[c * 8 + 2 * e + 1];
+            for (int e = 0; e < 4; ++e) s += bf16lo(kk[e]) * qv[2 * e] + bf16hi(kk[e]) * qv[2 * e + 1];
         }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
         s *= 0.125f;
-        ps[key] = s;
-        mx = fmaxf(mx, s);
+        if (key < n_cached) {
+            if (c == 0) ps[key] = s;
+            mx = fmaxf(mx, s);
+        }
     }
     mx = wave_max(mx);
+    __syncthreads();
     float sum = 0.f;
     for (int key = lane; key < n; key += 64) {
         float p = __expf(ps[key] - mx);
@@ -90,10 +103,38 @@ __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __re
     }
     sum = wave_sum(sum);
     __syncthreads();
-    float acc = 0.f;
-    for (int key = 0; key < n_cached; ++key) acc += ps[key] * bf16_to_f32(vb[(size_t)key * cache_rs + lane]);
-    if (append_dm > 0) acc += ps[n - 1] * vn[lane];
-    o[(size_t)b * o_rs + h * 64 + lane] = f32_to_bf16(acc / sum);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < n_cached; k0 += 8) {
+        const int key = k0 + kg;
+        if (key < n_cached) {
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)key * cache_rs + c * 8);
+            const float p = ps[key];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += p * bf16lo(vv[e]);
+                acc[2 * e + 1] += p * bf16hi(vv[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                            // sum the 8 key stripes (lanes with equal c)
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (kg == 0) {
+        const float inv = 1.0f / sum;
+        if (append_dm > 0) {
+            const float pn = ps[n - 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pn * vn[c * 8 + e];
+        }
+        const u32x4 pk = {pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv),
+                          pack_bf16x2(acc[4] * inv, acc[5] * inv), pack_bf16x2(acc[6] * inv, acc[7] * inv)};
+        *reinterpret_cast<u32x4*>(o + (size_t)b * o_rs + h * 64 + c * 8) = pk;
+    }
 }
 
 // HF NoRepeatNGramLogitsProcessor + argmax for one caption per workgroup
@@ -212,6 +253,7 @@ extern "C" int i2t_decode_attention(void* stream, const void* q, int q_rs, void*
     I2T_REQUIRE(q && kcache && vcache && o && B > 0 && H > 0, "i2t_decode_attention: bad args");
     I2T_REQUIRE(pos_ptr || (n_keys_fixed > 0 && n_keys_fixed <= DEC_MAX_KEYS), "i2t_decode_attention: key count out of range");
     I2T_REQUIRE(cache_rs % 8 == 0 && cache_bs % 8 == 0 && ALIGNED16(kcache) && ALIGNED16(vcache), "i2t_decode_attention: cache misaligned");
+    I2T_REQUIRE(o_rs % 8 == 0 && ALIGNED16(o), "i2t_decode_attention: output rows must be 16-byte aligned");
     hipLaunchKernelGGL(decode_attention_kernel, dim3(H, B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
                        (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed, append_dm);
     I2T_CHECK_LAUNCH("i2t_decode_attention");
