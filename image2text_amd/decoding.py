@@ -49,7 +49,7 @@ class GreedyDecoder:
         st.q = e(B, d)
         st.h = e(B, ff)
         st.hid = e(B, d)
-        st.logits = e(B, dc.V, dtype=F32)
+        st.logits = e(B, dc.Vp, dtype=F32)                      # rows padded to 8 columns: 16-byte aligned rows for the GEMM epilogue
         st.margin = e(B, dtype=F32)
         st.kc = [e(B, tmax, d) for _ in range(dc.L)]
         st.vc = [e(B, tmax, d) for _ in range(dc.L)]
@@ -93,7 +93,7 @@ class GreedyDecoder:
         if with_head:
             ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
             ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
-            ops.ngram_ban_argmax(st.logits, dc.V, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
+            ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
         ops.advance(st.counters, 1)                            # pos and len together
 
     def _capture(self, st, with_head: bool):
