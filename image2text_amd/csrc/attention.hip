@@ -247,36 +247,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
 }
 
 // ================================================================================================== backward
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, long o_bs, int o_rs,
-                                                         const bf16_t* __restrict__ dO, long do_bs, int do_rs,
-                                                         float* __restrict__ delta, int H, int Tq, int total, int total_q) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;   // (b, q, h) with h fastest -> adjacent 128-B segments
-    if (idx >= total) return;
-    const int h = idx % H;
-    size_t orow, drow_, slot;
-    if (total_q > 0) {                                 // packed rows: stats laid out [H][total_q]
-        const int row = idx / H;
-        orow = (size_t)row * o_rs; drow_ = (size_t)row * do_rs; slot = (size_t)h * total_q + row;
-    } else {
-        const int q = (idx / H) % Tq, b = idx / (H * Tq);
-        orow = (size_t)b * o_bs + (size_t)q * o_rs; drow_ = (size_t)b * do_bs + (size_t)q * do_rs; slot = ((size_t)b * H + h) * Tq + q;
-    }
-    const u32x4* po = reinterpret_cast<const u32x4*>(O + orow + h * 64);
-    const u32x4* pd = reinterpret_cast<const u32x4*>(dO + drow_ + h * 64);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        u32x4 a = po[c], d = pd[c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(d[e]) + bf16hi(a[e]) * bf16hi(d[e]);
-    }
-    delta[slot] = s;
-}
-
 // dQ: one workgroup per (q tile, h, b); loops over key tiles.  Scores transposed (lane owns a query column).
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O,
+                                                          const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int TqMax,
                                                           int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
                                                           float drop_scale, VarLen vl, unsigned od_key, unsigned od_thr,
@@ -315,7 +288,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     const bf16x8 df1 = global_row_frag(dob, dO.rs, q0, Tq, 1, lane);
     const int qc = min(qrow, Tq - 1);
     const float lse2 = lse[stat_base + qc] * LOG2E;
-    const float dl = delta[stat_base + qc];
+    // delta[q] = sum_d dO[q][d] O[q][d], computed here (the 4 lanes of a query column hold 16 dims each of dO already) and
+    // stored for the dK/dV kernel that runs next on the stream -- the separate pass over O and dO is gone
+    float dl;
+    {
+        const bf16_t* ob = O.p + (vl.cu_q ? (size_t)vl.cu_q[b] * O.rs : (size_t)b * O.bs) + h * 64;
+        const bf16x8 of0 = global_row_frag(ob, O.rs, q0, Tq, 0, lane), of1 = global_row_frag(ob, O.rs, q0, Tq, 1, lane);
+        float sdl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sdl += (float)df0[e] * (float)of0[e] + (float)df1[e] * (float)of1[e];
+        dl = quad_sum(sdl);
+        if (g == 0 && qrow < Tq) delta[stat_base + qrow] = dl;
+    }
     int last_key = Tk - 1;
     if (causal) last_key = min(last_key, qt * 64 + 63 + shift);
     const int nkt = last_key / 64 + 1;
@@ -605,11 +589,9 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     hipStream_t s = (hipStream_t)stream;
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
-    const int total = cu_q ? total_q * H : B * H * Tq;
     const VarLen vl{cu_q, cu_k, total_q};
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)o, o_bs, o_rs,
-                       (const bf16_t*)d_o, do_bs, do_rs, delta_ws, H, Tq, total, cu_q ? total_q : 0);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO,
+                       AttnPtr{(const bf16_t*)o, o_bs, o_rs}, lse, delta_ws,
                        (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
                        out_drop_scale);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image2text_amd import ops  # noqa: E402
 from tools.bench_gemm import timeit  # noqa: E402
 dev = torch.device('cuda:0')
-for (M, N, K) in [(512, 512, 133120), (1536, 512, 133120), (512, 2048, 133120), (768, 768, 18617), (2304, 768, 18617), (768, 3072, 18617)]:
+for (M, N, K) in [(512, 512, 266240), (1536, 512, 266240), (512, 2048, 266240), (768, 768, 37236), (2304, 768, 37236), (768, 3072, 37236)]:
     Kp = (K + 7) // 8 * 8
     dy = torch.randn(Kp, M, device=dev).to(torch.bfloat16)
     x = torch.randn(Kp, N, device=dev).to(torch.bfloat16)
