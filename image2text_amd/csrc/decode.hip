@@ -172,7 +172,28 @@ __global__ __launch_bounds__(BAN_THREADS) void ngram_ban_argmax_kernel(const voi
     const int nb = min(n_banned, MAX_BANNED);
     float best = -INFINITY, second = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = tid; c < V; c += BAN_THREADS) {
+    // fp32 rows with ld % 4 == 0 (the decode path pads to 8): 16-byte loads, 4 consecutive columns per lane per step
+    // (the scalar scan ran at ~2.3 TB/s).  Per lane the columns are still visited in ascending order: first index wins ties.
+    const bool vec4 = F32 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0;
+    const int vend = vec4 ? (V & ~3) : 0;
+    for (int c4 = tid * 4; c4 < vend; c4 += BAN_THREADS * 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(logits) + (size_t)b * ld + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = q[e];
+            const int c = c4 + e;
+            for (int k = 0; k < nb; ++k)
+                if (banned[k] == c) v = -INFINITY;
+            if (v > best) {
+                second = best;
+                best = v;
+                bi = c;
+            } else if (v > second) {
+                second = v;
+            }
+        }
+    }
+    for (int c = vend + tid; c < V; c += BAN_THREADS) {
         float v = F32 ? reinterpret_cast<const float*>(logits)[(size_t)b * ld + c]
                       : bf16_to_f32(reinterpret_cast<const bf16_t*>(logits)[(size_t)b * ld + c]);
         for (int k = 0; k < nb; ++k)
