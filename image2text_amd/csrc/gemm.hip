@@ -898,6 +898,8 @@ int g256_epilogue_class(const GemmParams& p) {
     return 0;
 }
 
+// CUs the persistent kernels may occupy: all of them, unless i2t_gemm_set_cu_limit reserved some (see include/i2t.h)
+int g_cu_reserve = 0;
 int g256_cus() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -905,7 +907,8 @@ int g256_cus() {
         hipDeviceProp_t prop;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    return n_cu;
+    const int r = __atomic_load_n(&g_cu_reserve, __ATOMIC_RELAXED);
+    return (r > 0 && r < n_cu - 8) ? n_cu - r : n_cu;
 }
 
 template <bool B_KMAJOR>
@@ -1180,6 +1183,12 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, block, 0, s, p);
     }
     I2T_CHECK_LAUNCH("i2t_gemm_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gemm_reserve_cus(int n_reserved) {
+    I2T_REQUIRE(n_reserved >= 0, "i2t_gemm_reserve_cus: negative count");
+    __atomic_store_n(&g_cu_reserve, n_reserved, __ATOMIC_RELAXED);
     return I2T_OK;
 }
 

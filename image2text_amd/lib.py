@@ -14,6 +14,7 @@ SIGNATURES = {
     'i2t_abi_version': [],
     'i2t_last_error': [C.c_char_p, C.c_size_t],
     'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I, I, U, U, F],
+    'i2t_gemm_reserve_cus': [I],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F],

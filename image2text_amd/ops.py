@@ -54,6 +54,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     return out
 
 
+def gemm_reserve_cus(n: int):
+    """Leave n CUs free in later persistent-GEMM launches (0 = use all); see include/i2t.h::i2t_gemm_reserve_cus."""
+    _l.check(_lib().i2t_gemm_reserve_cus(int(n)), 'i2t_gemm_reserve_cus')
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumulate=False):
     _need_cuda(x, out)
     _l.check(_lib().i2t_colsum_bf16(_stream(), _p(x), x.stride(0) if ld is None else ld, M, N, _p(out), int(accumulate)),

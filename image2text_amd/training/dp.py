@@ -11,10 +11,17 @@ has finished, overlapped with the whole encoder backward; the encoder slice foll
 messages keep every link busy; RCCL picks the rings/trees.  ``torch.distributed`` (backend "nccl" = RCCL) is the
 transport; on CPU the same code runs over gloo (tests).
 """
+import os
 from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+# CUs left free for RCCL while a collective overlaps the backward pass.  The persistent GEMM kernels occupy whole CUs with a
+# static share of the tiles each; a collective's workgroups (one per channel) need whole CUs too and keep them for its whole
+# duration, so without this every GEMM launched during the window would wait for a second round of workgroups (2x its
+# time).  NCCL_MAX_NCHANNELS caps RCCL at the same number (only set when the user has not chosen a value).
+RCCL_CUS = int(os.environ.get('I2T_RCCL_CUS', '16'))
 
 
 class DataParallelGrads:
@@ -25,6 +32,9 @@ class DataParallelGrads:
         self.overlap = overlap
         self._pending = []
         self._reduced_upto = None
+        self._reserved = False
+        if dist.get_backend(group) == 'nccl' and RCCL_CUS > 0:
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', str(RCCL_CUS))     # read when the communicator is created (first collective)
         eng = getattr(model, '_engine', None)
         if eng is not None and overlap:
             eng.grad_ready_hooks.append(self._on_grads_ready)
@@ -53,6 +63,10 @@ class DataParallelGrads:
         if which == 'decoder' and self._reduced_upto is None:
             arena = self._arena()
             cut = self._split(arena)
+            if arena.g32.is_cuda and dist.get_backend(self.group) == 'nccl' and RCCL_CUS > 0:
+                from .. import ops
+                ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
+                self._reserved = True
             work, need_div = self._reduce(arena.g32[cut:], async_op=True)
             self._pending.append((work, arena.g32[cut:], need_div))
             self._reduced_upto = cut
@@ -70,6 +84,10 @@ class DataParallelGrads:
                 t.div_(self.world)
         self._pending.clear()
         self._reduced_upto = None
+        if self._reserved:
+            from .. import ops
+            ops.gemm_reserve_cus(0)
+            self._reserved = False
 
     def broadcast_parameters(self, src: int = 0):
         """Initial parameter sync (what DDP does at wrap time)."""

@@ -65,6 +65,14 @@ int i2t_gemm_bf16(void* stream,
                   int drop_mode, unsigned drop_key, unsigned drop_thr, float drop_scale);
 
 /* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients; X bf16 [M][ld]) */
+/* The large-tile GEMM kernels are persistent: one 8-wave workgroup per CU holds the CU's whole LDS and register file and
+ * walks a static share of the output tiles.  A kernel from another stream that needs whole CUs for a long time (an RCCL
+ * collective overlapped with the backward pass) would leave that many GEMM workgroups waiting for a second round, i.e. double
+ * the GEMM's duration.  i2t_gemm_reserve_cus(n) makes later launches leave n CUs free (0 = use every CU again); the
+ * data-parallel gradient exchange brackets its overlap window with it (training/dp.py).  Process-wide, takes effect at the
+ * next launch. */
+int i2t_gemm_reserve_cus(int n_reserved);
+
 int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -204,6 +204,22 @@ def test_gemm_large_tile_random_shapes(ops, monkeypatch):
             check(tag + ' dW accumulate', out, base + ref, 2 * tol, 3e-3)
 
 
+def test_gemm_reserved_cus(ops):
+    """i2t_gemm_reserve_cus: the persistent kernels run on fewer workgroups (each walks more tiles) with the same result."""
+    M, N, K = 4000, 2304, 512
+    a, b = rnd(M, K, dtype=BF16, seed=41), rnd(N, K, dtype=BF16, seed=42, scale=0.1)
+    full = torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, full, M, N, K)
+    try:
+        for r in (16, 100, 1000):          # 1000 > #CUs: ignored
+            ops.gemm_reserve_cus(r)
+            out = torch.empty(M, N, dtype=BF16, device=dev())
+            ops.gemm(a, b, out, M, N, K)
+            assert torch.equal(out, full), r
+    finally:
+        ops.gemm_reserve_cus(0)
+
+
 def test_gemm_large_tile_epilogues(ops):
     from image2text_amd import rng
     M, N, K = 2900, 2304, 512
