@@ -1,21 +1,25 @@
-// bf16 MFMA GEMM for gfx950 with fused epilogues (bias, GELU / GELU', residual, accumulate, bf16|f32 store).
+// bf16 MFMA GEMM for gfx950 with fused epilogues (bias, GELU / GELU', dropout, residual, accumulate, bf16|f32 store).
 //
 //   C[M,N] = epilogue(alpha * op(A)[M,K] . op(B)[K,N])
 //
-// Tile 128 x 128 x 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x 64 = 4x4 MFMA 16x16x32 tiles
-// (64 accumulator VGPRs).  Operands are staged global -> VGPR -> LDS (issue-early / write-late, double-buffered
-// LDS, one barrier per K-step) in one of two LDS images:
+// Three kernels behind one entry point (i2t_gemm_bf16 picks by shape; routing at the bottom of the file):
+//   gemm256_kernel   persistent 256 x 256 x 64 tiles, 8 waves, LDS-DMA staging with counted waits -- every problem with
+//                    >= 40 such tiles and every dW = dY^T.X problem (K slices + atomics): the workhorse, see its header;
+//   gemm_bf16_kernel 128 x 128 x 64 tiles, 4 waves (2 x 2, 64 x 64 each), register-staged double buffer, one barrier per
+//                    K-step, optional split-K with atomics -- small problems;
+//   gemm_skinny_kernel  M <= 64 (decode steps at small batch): weights streamed straight to registers.
+// LDS images shared by the tiled kernels:
 //   R  image (reduction index contiguous in memory):  tile[r][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by
 //            (r & 7); fragments are one ds_read_b128 each (conflict-free: cdna_hip_programming.md T2).
-//   Cf image (reduction index is the row index):       tile[64 k][128 r] bf16, 288-B rows (32-B pad = 8 banks per
-//            k-row, so the 8 k-rows x 4 column quads a half-wave touches cover 64 distinct banks); fragments are
+//   Cf image (reduction index is the row index):       tile[64 k][128 r] bf16, 256-B rows whose 32-B windows are XOR-moved
+//            by the k-row, so the 8 k-rows x 4 column quads a half-wave touches cover 64 distinct banks; fragments are
 //            two ds_read_b64_tr_b16 each (T10) -- this is what lets dX = dY.W and dW = dY^T.X run without any
 //            transposed copy of weights or activations in HBM.
 // The MFMA is issued "swapped" (weight-side fragment as the A operand, activation-side as B) so that a lane ends
 // up holding 4 CONSECUTIVE output columns of one output row: the epilogue reads bias/residual and stores C as one
-// 8-/16-byte vector per lane.
-// Block -> tile map is XCD-aware (8 XCDs, private L2s): blocks that share an XCD walk consecutive M-tiles of the
-// same N panel, so a weight panel is fetched into one L2 instead of eight.
+// 8-/16-byte vector per lane (the split-K forms issue it un-swapped: 4 rows x 64 contiguous bytes per atomic instruction).
+// Block -> tile maps are XCD-aware (8 XCDs, private L2s) and N-fastest inside groups of column tiles, so an activation row
+// panel is fetched once per group and a weight group stays in one L2.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
