@@ -407,16 +407,22 @@ extern "C" int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* lab
 }
 
 extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16, unsigned drop_key, unsigned drop_thr,
-                                  float drop_scale) {
+                                  float drop_scale, int presummed, float* clear_after) {
     I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_grad_normalize: bad args");
     I2T_REQUIRE(drop_thr == 0 || (g_bf16 && n < (1L << 32)), "i2t_grad_normalize: dropout needs the bf16 copy and n < 2^32");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
-    if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
-    const int grid = grid_for(n >> 2, 1024);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
+    if (!presummed) {          // presummed: the producer of g (i2t_layernorm_bwd's sumsq_out) already accumulated sum(g^2) into ws
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
+        if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+        const int grid = grid_for(n >> 2, 1024);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
+    }
     hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16, drop_key,
                        drop_thr, drop_scale);
+    if (clear_after) {         // zero the accumulator the NEXT producer will add into (a different float than ws)
+        hipError_t e = hipMemsetAsync(clear_after, 0, sizeof(float), s);
+        if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+    }
     I2T_CHECK_LAUNCH("i2t_grad_normalize");
     return I2T_OK;
 }

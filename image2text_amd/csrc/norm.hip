@@ -74,10 +74,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      int dx_accumulate, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                     int d, unsigned drop_key, unsigned drop_thr, float drop_scale) {
+                                                     int d, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                                                     float* __restrict__ sumsq_out) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = d >> 2;
+    float ssq = 0.f;                          // sum of squares of the f32 dx this block writes (for the gradient normaliser)
     f32x4 pg[MAXC], pb[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) pg[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                 if (dx_accumulate) o += *dxp;
                 *dxp = o;
+                ssq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
                 if (dx_bf16) {
                     if (drop_thr) {    // the bf16 copy feeds a dropped-out branch: its forward mask, idx = row * d + column
                         bool keep[4];
@@ -134,6 +137,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 }
             }
         }
+    }
+    if (sumsq_out) {                          // one atomic per workgroup (block-uniform branch)
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[0][0][w] = ssq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq_out, red[0][0][0] + red[0][0][1] + red[0][0][2] + red[0][0][3]);
+        __syncthreads();
     }
     if (!dgamma && !dbeta) return;
 #pragma unroll
@@ -336,7 +346,7 @@ extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamm
 extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
                                  float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
-                                 float drop_scale) {
+                                 float drop_scale, float* sumsq_out) {
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
     I2T_REQUIRE(drop_thr == 0 || (dx_bf16 && (long)M * d < (1L << 32)), "i2t_layernorm_bwd: dropout needs dx_bf16 and M*d < 2^32");
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
@@ -344,10 +354,10 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
     hipStream_t s = (hipStream_t)stream;
     if (dy_is_f32)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out);
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
 }

@@ -270,7 +270,7 @@ class HotPath:
             ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
         return dx_out
 
-    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None):
+    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None, sumsq_out=None):
         """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output, already normalised.  On return dx (and
         dxb when emit_last_bf16) hold the gradient w.r.t. the block input."""
         a = self.arena
@@ -320,8 +320,10 @@ class HotPath:
                           out_drop=dr['qkv'])                  # gradient w.r.t. the un-multiplied q/k/v
         self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
                          f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
+        # last writer of dx in this block: it also leaves sum(dx^2) for the next block's gradient normaliser
         ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
-                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None)
+                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None,
+                          sumsq_out=sumsq_out)
 
     # ---- the encoder's LAST block, CLS rows only.  The encoder output is ln_f of the first ncls rows (encoder.py:172-173); the
     # patch rows of the last block feed nothing, forward or backward.  K and V still come from every row; the queries, the
@@ -360,7 +362,8 @@ class HotPath:
         dr = sv.dr
         bias = lambda n: n if a.G(n) is not None else None
         dxb = self._empty(Mc, d, dtype=BF16)
-        ops.grad_normalize(dcls, self._ws[:1], dxb, bf16_drop=dr['mlp'])      # the patch rows' gradient is zero: same norm
+        # (the patch rows' gradient is zero: same norm as over the full block output); ws[1] collects sum(dx_full^2) below
+        ops.grad_normalize(dcls, self._ws[0:1], dxb, bf16_drop=dr['mlp'], clear_after=self._ws[1:2])
         dpre = self._empty(Mc, ff, dtype=BF16)
         self._linear_bwd(dxb, Mc, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', bias(f'{pfx}.mlp.c_proj.bias'), dx_out=dpre, act=2,
                          aux_in=sv.pre)
@@ -382,15 +385,20 @@ class HotPath:
                          dx_out=dln1)
         ops.copy_rows(dcls, ncls * d, dx_full, T * d, B, ncls, d)               # residual path of the CLS rows
         ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx_full.view(M, d), a.G(f'{pfx}.ln_1.weight'),
-                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True)
+                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, sumsq_out=self._ws[1:2])
 
-    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None):
+    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None, presummed_slot=None):
+        """presummed_slot: index into self._ws that already holds sum(dx^2) of the incoming gradient (None: reduce it here).
+        Inside the loop every block's last LayerNorm backward leaves that sum for the block below (two alternating floats)."""
         dxb = self._empty(dx.shape[0], d, dtype=BF16)
+        slot, presummed = (presummed_slot, True) if presummed_slot is not None else (0, False)
         for l in reversed(range(len(saves))):
+            cur, nxt = self._ws[slot:slot + 1], self._ws[1 - slot:2 - slot]
             # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
-            ops.grad_normalize(dx, self._ws[:1], dxb, bf16_drop=saves[l].dr['mlp'])
+            ops.grad_normalize(dx, cur, dxb, bf16_drop=saves[l].dr['mlp'], presummed=presummed, clear_after=nxt)
             self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
-                           vl=vl)
+                           vl=vl, sumsq_out=nxt)
+            slot, presummed = 1 - slot, True
 
     # ------------------------------------------------------------------------------------------------ encoder
     def encode(self, images: torch.Tensor, save: bool):
@@ -471,7 +479,7 @@ class HotPath:
         dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
         if self.cls_only_last:
             self.block_bwd_cls(f'{self.ep}transformer.h.{e.L - 1}', ctx.saves[-1], dcls, dx, B, T, d, e.H, e.ff, e.ncls)
-            self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
+            self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, presummed_slot=1)
         else:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
             self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)

@@ -17,7 +17,7 @@ SIGNATURES = {
     'i2t_gemm_reserve_cus': [I],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
-    'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F],
+    'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
     'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, U, U, F, P, P, I],
@@ -26,7 +26,7 @@ SIGNATURES = {
     'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I, P],
     'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
     'i2t_ce_bwd': [P, P, I, P, P, F, I64, P, P, I, I],
-    'i2t_grad_normalize': [P, P, L, P, P, U, U, F],
+    'i2t_grad_normalize': [P, P, L, P, P, U, U, F, I, P],
     'i2t_conv_fwd': [P, P, I, I, P, P, P, P, I, I, I, I, I, I],
     'i2t_conv_bwd_data': [P, P, P, P, I, P, P, I, I, I, I, I, I],
     'i2t_conv_bwd_weight': [P, P, P, I, I, P, P, I, I, I, I, I, I],

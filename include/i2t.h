@@ -86,8 +86,10 @@ int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const fl
 int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                       const float* mean, const float* rstd,
                       float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
-                      unsigned drop_key, unsigned drop_thr, float drop_scale);
-/* drop_* (bwd): optional elementwise dropout (rule of i2t_gemm_bf16, idx = row*d + col, drop_thr 0 = off) applied to the
+                      unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out);
+/* sumsq_out (bwd, nullable): += sum of squares of the f32 dx written by this call (after accumulation) -- lets the
+ * gradient normaliser that consumes dx next skip its own reduction pass (i2t_grad_normalize presummed).
+ * drop_* (bwd): optional elementwise dropout (rule of i2t_gemm_bf16, idx = row*d + col, drop_thr 0 = off) applied to the
  * bf16 copy dx_bf16 only -- the copy feeds the backward of a dropped-out branch, the f32 dx is the residual gradient. */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -162,7 +164,10 @@ int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const 
  *   ws = 1 float of zero-initialised-by-the-call scratch; g_bf16 (nullable) receives a bf16 copy of the result.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16,
-                       unsigned drop_key, unsigned drop_thr, float drop_scale);     /* dropout on the bf16 copy, as i2t_layernorm_bwd */
+                       unsigned drop_key, unsigned drop_thr, float drop_scale,      /* dropout on the bf16 copy, as i2t_layernorm_bwd */
+                       int presummed, float* clear_after);
+/* presummed != 0: *ws already holds sum(g^2) (accumulated by the producer through i2t_layernorm_bwd's sumsq_out) and the
+ * reduction pass is skipped; clear_after (nullable): a float zeroed after the call, i.e. the accumulator of the next producer. */
 
 /* ---------------------------------------------------------------------------------------------------------
  * ConvMLP feature extractor (layers.py:258-282): Conv2d(k x k, padding='same', k even => pad (k-1)/2 before,

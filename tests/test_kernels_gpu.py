@@ -443,6 +443,19 @@ def test_grad_normalize(ops):
         ops.grad_normalize(g, ws, gb)
         check('grad_normalize', g, ref, 1e-7, 1e-4)
         check('grad_normalize bf16 copy', gb, g, 0, 1 / 128)
+    # sum of squares handed over by the producer (layernorm_bwd's sumsq_out) instead of a reduction pass
+    M, d = 500, 512
+    x, gam, dy = rnd(M, d, seed=30), rnd(d, seed=31), rnd(M, d, seed=32)
+    mean, rstd = x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    dx = rnd(M, d, seed=33)
+    ws2 = torch.zeros(2, device=dev())
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, dx, None, None, M, d, dx_accumulate=True, sumsq_out=ws2[0:1])
+    check('ln_bwd sumsq_out', ws2[0:1], (dx.double() ** 2).sum().float().view(1), 1e-3, 1e-5)
+    ws2[1] = 123.0
+    ref2 = dx / (torch.linalg.vector_norm(dx.double()).float() + 1e-6)
+    ops.grad_normalize(dx, ws2[0:1], None, presummed=True, clear_after=ws2[1:2])
+    check('grad_normalize presummed', dx, ref2, 1e-7, 1e-4)
+    assert float(ws2[1]) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------------ conv stack
