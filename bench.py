@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=4096, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
-    ap.add_argument('--decode-streams', type=int, default=2, help='independent caption batches decoded concurrently')
+    ap.add_argument('--decode-streams', type=int, default=3, help='independent caption batches decoded concurrently')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -249,11 +249,23 @@ def main():
         torch.cuda.empty_cache()              # hand the training step's cached blocks back before the decode leg allocates its own
         from image2text_amd.decoding import ConcurrentGreedyDecoder
         Bd, S = args.decode_batch, args.decode_streams
-        dimgs = [synthetic_batch(Bd, 224, 64, V, seed=100 + rank * S + i)[0].to(dev) for i in range(S)]
-        prompts = [torch.full((Bd, 1), V - 1, dtype=torch.long, device=dev) for _ in range(S)]
-        cdec = ConcurrentGreedyDecoder(wrapper.model, S)
-        log(f'decode: {S} concurrent batches x {Bd} captions, warm-up + graph capture')
-        cdec.generate(dimgs, prompts, 64)                                      # warm-up + graph capture
+        cdec = dimgs = prompts = None
+        while True:       # the decode leg is rank-local: a rank that runs out of memory retries with half the captions per batch
+            try:
+                dimgs = [synthetic_batch(Bd, 224, 64, V, seed=100 + rank * S + i)[0].to(dev) for i in range(S)]
+                prompts = [torch.full((Bd, 1), V - 1, dtype=torch.long, device=dev) for _ in range(S)]
+                cdec = ConcurrentGreedyDecoder(wrapper.model, S)
+                log(f'decode: {S} concurrent batches x {Bd} captions, warm-up + graph capture')
+                cdec.generate(dimgs, prompts, 64)                              # warm-up + graph capture
+                torch.cuda.synchronize()
+                break
+            except torch.OutOfMemoryError:
+                cdec = dimgs = prompts = None
+                torch.cuda.empty_cache()
+                if Bd <= 256:
+                    raise
+                Bd //= 2
+                log(f'decode: out of memory, retrying with {Bd} captions per batch')
         fence()
         log('decode: timed runs')
         t0 = time.perf_counter()
@@ -262,11 +274,15 @@ def main():
         fence()
         assert all(tuple(o.shape) == (Bd, 65) for o in outs)
         dt = time.perf_counter() - t0
+        n_caps = float(Bd * S * args.decode_reps)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
-        cap_s = world * Bd * S * args.decode_reps / dt
+            c = torch.tensor([n_caps], dtype=torch.float64, device=dev)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            n_caps = float(c)
+        cap_s = n_caps / dt
         wrapper.train()
 
     if rank == 0:
@@ -280,7 +296,7 @@ def main():
                        'parallelism': f'dp{world}', 'dropout': args.dropout, 'optimizer': 'AdamW lr 6e-4 betas (0.9,0.95)',
                        'weights': 'random init (reference distributions)'},
             'greedy_captions_per_sec': None if cap_s is None else round(cap_s, 2),
-            'greedy_config': {'captions_per_batch': args.decode_batch, 'concurrent_batches_per_gpu': args.decode_streams,
+            'greedy_config': {'captions_per_batch': (Bd if not args.no_decode else args.decode_batch), 'concurrent_batches_per_gpu': args.decode_streams,
                               'new_tokens': 64, 'ngrams': [2, 3, 4, 5], 'includes': 'encoder forward + KV-cache decode (hipGraph replay)'},
             'final_loss': round(final_loss, 4),
             'host_input_images_per_sec': None if pcie_img_s is None else round(pcie_img_s, 1),     # H2D copy of the batch inside the step
