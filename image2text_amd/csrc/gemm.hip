@@ -56,6 +56,7 @@ struct GemmParams {
     unsigned drop_key, drop_thr;
     float drop_scale;
     int g2_splits, g2_nk;     // 256^2 kernel: K slices per output tile and K-tiles per slice (even)
+    int g2_gn;                // 256^2 kernel: column tiles per group of the tile order
 };
 
 // Tile order inside an XCD's contiguous chunk of the grid.  PMC (round 1, B = 256): with M fastest the GEMM family moved
@@ -652,7 +653,7 @@ struct G2 {
         const int tiles = p.tiles_m * p.tiles_n, slice = idx / tiles;
         d.t0 = slice * p.g2_nk;
         int tile_m, tile_n;
-        tile_coords(p, idx - slice * tiles, tile_m, tile_n, 8);
+        tile_coords(p, idx - slice * tiles, tile_m, tile_n, p.g2_gn);
         d.m0 = tile_m * 256; d.n0 = tile_n * 256;
         if (!A_KMAJOR) {
             d.a = p.A + (size_t)d.m0 * p.lda;
@@ -1118,6 +1119,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
     p.g2_splits = 1; p.g2_nk = 0;
+    { static const char* e = getenv("I2T_G256_GN"); static const int gn = e ? atoi(e) : 8; p.g2_gn = gn > 0 ? gn : 8; }
     I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
