@@ -21,6 +21,16 @@ def _stale():
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
+    # one builder at a time (ranks of one job, pytest-xdist workers): the others wait, then find the library fresh
+    import fcntl
+    with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build(verbose)
+
+
+def _build(verbose: bool) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []

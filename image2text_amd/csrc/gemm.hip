@@ -284,55 +284,86 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 //   4 bf16 C, GELU' of aux_in                   5 f32 C, optional accumulate
 //   7 plain bf16 or f32 C with N % 4 != 0 (the lm_head's 50257 columns): the quad that straddles N is stored element-wise,
 //     [N, ldc) untouched
+// The loads of a batch (bias, GELU' input, residual / accumulate addend) are a separate step from the arithmetic and the
+// stores, so that the 256^2 kernel can issue the loads of the NEXT 16-row group before the stores of the current one
+// (epilogue_tile_tr): the compiler may not hoist them itself -- C may alias residual / aux_in -- and without that every
+// group paid a full load latency (8 per tile).
+#ifndef G2_EPI_DEPTH
+#define G2_EPI_DEPTH 1
+#endif
+struct EpiPre {
+    f32x4 bv[4], add[4];
+    u32x2 ax[4];
+};
 template <int EPI>
-__device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
-    constexpr bool GEN = EPI == 0;
-    const bool f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : false;
-    const bool f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
-    const bool f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
-    const bool f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
-    const bool f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
-    const bool f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
-    const bool f_res = (GEN || EPI == 3) ? (p.residual != nullptr) : false;
-    const bool f_acc = (GEN || EPI == 5) ? (p.accumulate != 0) : false;
-    const bool f_f32 = (GEN || EPI == 7) ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
-    bool ok[4];
+struct EpiFlags {
+    static constexpr bool GEN = EPI == 0;
+    bool f_bias, f_gelu, f_dgelu, f_auxout, f_drop1, f_drop2, f_res, f_acc, f_f32;
+    __device__ __forceinline__ explicit EpiFlags(const GemmParams& p) {
+        f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : false;
+        f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
+        f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
+        f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
+        f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
+        f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
+        f_res = (GEN || EPI == 3) ? (p.residual != nullptr) : false;
+        f_acc = (GEN || EPI == 5) ? (p.accumulate != 0) : false;
+        f_f32 = (GEN || EPI == 7) ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
+    }
+};
+// EPI 7: the straddling quad loads bias from [N-1 .. N+2]: inside the 16-B padded vector
+__device__ __forceinline__ int epi_clamp_n(const GemmParams& p, int n4) { return min(n4, ((p.N + 3) & ~3) - 4); }
+
+template <int EPI, bool WITH_BIAS = true>
+__device__ __forceinline__ void epilogue_loads4(const GemmParams& p, const int (&m)[4], const int (&n4)[4], EpiPre& L) {
+    const EpiFlags<EPI> F(p);
     int mc[4], nc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        ok[q] = m[q] < p.M && n4[q] < p.N;
         mc[q] = min(m[q], p.M - 1);
-        nc[q] = min(n4[q], ((p.N + 3) & ~3) - 4);        // EPI 7: the straddling quad loads bias from [N-1 .. N+2]: inside the 16-B padded vector
+        nc[q] = epi_clamp_n(p, n4[q]);
+    }
+    if (WITH_BIAS && F.f_bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nc[q]);
+    }
+    if (F.f_dgelu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
     }
     // one set of addend registers serves residual and accumulate (both at once is rare: the second then waits on the first)
-    f32x4 v[4], bv[4], add[4];
-    u32x2 ax[4];
-    if (f_bias) {
+    if (F.f_res) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nc[q]);
+        for (int q = 0; q < 4; ++q) L.add[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mc[q] * p.ldr + nc[q]);
     }
-    if (f_dgelu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
-    }
-    if (f_res) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) add[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mc[q] * p.ldr + nc[q]);
-    }
-    if (f_acc) {
+    if (F.f_acc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)mc[q] * p.ldc + nc[q]);
-            add[q] = f_res ? add[q] + c : c;
+            L.add[q] = F.f_res ? L.add[q] + c : c;
         }
     }
-    const bool has_add = f_res || f_acc;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4],
+                                                 const EpiPre& L) {
+    const EpiFlags<EPI> F(p);
+    bool ok[4];
+    int nc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ok[q] = m[q] < p.M && n4[q] < p.N;
+        nc[q] = epi_clamp_n(p, n4[q]);
+    }
+    f32x4 v[4];
+    const bool has_add = F.f_res || F.f_acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         v[q] = a[q] * p.alpha;
-        if (f_bias) v[q] += bv[q];
+        if (F.f_bias) v[q] += L.bv[q];
     }
-    if (f_auxout) {
+    if (F.f_auxout) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (ok[q]) {
@@ -340,19 +371,19 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
                 *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]) = pk;
             }
     }
-    if (f_gelu) {
+    if (F.f_gelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = gelu_tanh(v[q][r]);
-    } else if (f_dgelu) {
+    } else if (F.f_dgelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            v[q][0] *= gelu_tanh_grad(bf16lo(ax[q][0])); v[q][1] *= gelu_tanh_grad(bf16hi(ax[q][0]));
-            v[q][2] *= gelu_tanh_grad(bf16lo(ax[q][1])); v[q][3] *= gelu_tanh_grad(bf16hi(ax[q][1]));
+            v[q][0] *= gelu_tanh_grad(bf16lo(L.ax[q][0])); v[q][1] *= gelu_tanh_grad(bf16hi(L.ax[q][0]));
+            v[q][2] *= gelu_tanh_grad(bf16lo(L.ax[q][1])); v[q][3] *= gelu_tanh_grad(bf16hi(L.ax[q][1]));
         }
     }
-    if (f_drop1) {
+    if (F.f_drop1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bool keep[4];
@@ -360,7 +391,7 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = keep[r] ? v[q][r] * p.drop_scale : 0.f;
         }
-    } else if (f_drop2) {
+    } else if (F.f_drop2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned third = (unsigned)nc[q] / (unsigned)(p.N / 3);
@@ -369,9 +400,9 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
     }
     if (has_add) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += add[q];
+        for (int q = 0; q < 4; ++q) v[q] += L.add[q];
     }
-    if (f_f32) {
+    if (F.f_f32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (!ok[q]) continue;
@@ -395,6 +426,13 @@ __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4
                 }
             }
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
+    EpiPre L;
+    epilogue_loads4<EPI>(p, m, n4, L);
+    epilogue_finish4<EPI>(p, a, m, n4, L);
 }
 
 // Fused epilogue of an (MI x 16) x (NJ x 16) wave tile held in swapped-issue accumulators: lane holds
@@ -440,23 +478,56 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     const int g = lane >> 4, li = lane & 15;
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
     const bool fast = EPI != 0 || epilogue_fast_ok(p);        // the launcher picks a specialised class only when fast_ok holds
+    // classes that LOAD per element (residual, accumulate, GELU' input) run the loads G2_EPI_DEPTH row groups ahead
+    constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5;
+    constexpr int DEPTH = PIPE ? G2_EPI_DEPTH : 0, NB = DEPTH + 1;
+    EpiPre L[NB];
+    const int n4c = nbase + 4 * li;                           // after the transpose a lane's 4 quads share their columns
+    auto rows_of = [&](int i, int (&m)[4], int (&n4)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = mbase + i * 16 + 4 * k + g;
+            n4[k] = n4c;
+        }
+    };
+    if constexpr (EPI != 0) {
+        const EpiFlags<EPI> F(p);
+        if (F.f_bias) {                                       // one bias vector per lane and tile
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + epi_clamp_n(p, n4c));
+#pragma unroll
+            for (int s = 0; s < NB; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) L[s].bv[q] = b;
+        }
+        static_for<DEPTH>([&](auto D_) {
+            constexpr int d = decltype(D_)::value;
+            int m[4], n4[4];
+            rows_of(d, m, n4);
+            epilogue_loads4<EPI, false>(p, m, n4, L[d % NB]);
+        });
+    }
     static_for<MI>([&](auto I_) {
         constexpr int i = decltype(I_)::value;
+        int m[4], n4[4];
+        if constexpr (EPI != 0 && i + DEPTH < MI) {
+            rows_of(i + DEPTH, m, n4);
+            epilogue_loads4<EPI, false>(p, m, n4, L[(i + DEPTH) % NB]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<f32x4*>(wave_lds + li * 256 + (((4 * j + g) ^ (li & 7)) << 4)) = acc[i][j];
         f32x4 a[4];
-        int m[4], n4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = 4 * k + g;
             a[k] = *reinterpret_cast<const f32x4*>(wave_lds + row * 256 + ((li ^ (row & 7)) << 4));
-            m[k] = mbase + i * 16 + row;
-            n4[k] = nbase + 4 * li;
         }
-        if (fast) {
-            epilogue_batch4<EPI>(p, a, m, n4);
-        } else if constexpr (EPI == 0) {
+        rows_of(i, m, n4);
+        if constexpr (EPI != 0) {
+            epilogue_finish4<EPI>(p, a, m, n4, L[i % NB]);
+        } else if (fast) {
+            epilogue_batch4<0>(p, a, m, n4);
+        } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (m[k] < p.M && n4[k] < p.N) epilogue_quad(p, a[k], m[k], n4[k], vec_ok);
