@@ -7,6 +7,9 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libi2t_hip.so')
 SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
+# per-file additions.  attention: keep MFMA accumulators in VGPRs -- the softmax rescales them every key tile, and the
+# AGPR form cost ~110 v_accvgpr_read/write per tile in kernels that are VALU-bound
+EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _stale():
@@ -37,7 +40,7 @@ def _build(verbose: bool) -> str:
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')
-        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

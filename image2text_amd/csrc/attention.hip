@@ -116,6 +116,11 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // ================================================================================================== forward
+// All three kernels are VALU-bound (softmax + the dropout hash; ~4 VALU issue slots per MFMA slot), so the variants are
+// compile-time: DROP (probability dropout on) and EVEN (TkMax even: a lane's 4 consecutive keys are the fields of exactly
+// two hashes, no per-lane alignment case).  The dropout scale 1/(1-p) and the 1/sqrt(d) factor of dS are applied once to
+// the accumulators at the end instead of per probability.
+template <bool DROP, bool EVEN>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O,
                                                        long o_bs, int o_rs, float* __restrict__ lse, int H, int TqMax,
                                                        int TkMax, int causal, unsigned drop_key, unsigned drop_thr,
@@ -212,12 +217,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
                 continue;
             }
             bool keep[4] = {true, true, true, true};
-            if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+            if constexpr (DROP) {
+                if constexpr (EVEN) dropout_keep4_even(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+                else dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(s[kj][r] * (SCALE * LOG2E) - m_safe);      // one fma + raw v_exp_f32
                 rs += p;                               // the softmax denominator is dropout-free
-                if (drop_thr) p = keep[r] ? p * drop_scale : 0.f;
+                if constexpr (DROP) p = keep[r] ? p : 0.f;                                   // x drop_scale: once, on O
                 s[kj][r] = p;
             }
         }
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
         }
     }
     l = quad_sum(l);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const float inv = l > 0.f ? (DROP ? drop_scale : 1.0f) / l : 0.f;
     if (qrow < Tq) {
         bf16_t* op = O + ooff + (size_t)qrow * o_rs + h * 64;
 #pragma unroll
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
 
 // ================================================================================================== backward
 // dQ: one workgroup per (q tile, h, b); loops over key tiles.  Scores transposed (lane owns a query column).
+template <bool DROP, bool EVEN>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, int H, int TqMax,
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dscale = DROP ? drop_scale : 1.f;
 
     const bool wave_on = q0 < Tq;
     TileRegs kr, vr;
@@ -339,15 +349,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 0, lane), df0, dp, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(vt_lds, kj * 16, 1, lane), df1, dp, 0, 0, 0);
             bool keep[4] = {true, true, true, true};
-            if (drop_thr) dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+            if constexpr (DROP) {
+                if constexpr (EVEN) dropout_keep4_even(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+                else dropout_keep4(drop_key, drow + kt * 64 + kj * 16 + 4 * g, drop_thr, keep);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 64 + kj * 16 + 4 * g + r;
                 float p = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - lse2);
                 if (!full && !(key <= qlim && key < Tk)) p = 0.f;
                 float dpr = dp[r];                     // gradient w.r.t. the dropped probabilities -> undo the mask
-                if (drop_thr) dpr = keep[r] ? dpr * drop_scale : 0.f;
-                ds[kj][r] = p * (dpr - dl) * SCALE;
+                if constexpr (DROP) dpr = keep[r] ? dpr : 0.f;
+                ds[kj][r] = p * fmaf(dpr, dscale, -dl);              // x 1/sqrt(d): once, on dQ (a power of two: exact)
             }
         }
         const bf16x8 s0 = pack_frag(ds[0], ds[1]);
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
         bf16_t* op = dQ + dqoff + (size_t)qrow * dq_rs + h * 64;
         // od_*: the per-token multiplier that scaled q in the forward (GEMM drop_mode 2, third 0), row = token index
         const unsigned grow = (unsigned)((vl.cu_q ? vl.cu_q[b] : b * TqMax) + qrow);
-        const float f = od_thr ? (dropout_keep(od_key, grow, od_thr) ? od_scale : 0.f) : 1.f;
+        const float f = (od_thr ? (dropout_keep(od_key, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             acc[dt] *= f;
@@ -375,6 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
 // dK, dV: one workgroup per (key tile, h, b); each wave owns 16 keys and loops over 64-row query tiles.
 // Scores NOT transposed here (D[q][key]: lane owns a key column), so P / dS are the B operands of
 // dV^T[d][key] = dO^T[d][q] . P[q][key] and dK^T[d][key] = Q^T[d][q] . dS[q][key].
+template <bool DROP, bool EVEN>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dK, long dk_bs, int dk_rs,
@@ -426,6 +440,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     for (int dt = 0; dt < 4; ++dt) adk[dt] = adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool wave_on = k0 < Tk;
+    const float dscale = DROP ? drop_scale : 1.f;
     TileRegs qr, dr;
     float lse_r = 0.f, dl_r = 0.f;
     if (qt0 < nqt) {
@@ -475,12 +490,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_lds + qj * 16 + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_lds + qj * 16 + 4 * g);
             bool keep4[4] = {true, true, true, true};
-            if (drop_thr) {
+            if constexpr (DROP) {
                 // This lane's 4 elements sit in 4 different query rows (one hash each).  With an even TkMax the lanes of
                 // keys (2c, 2c+1) read the two 16-bit fields of the SAME hash: the even lane hashes rows r = 0, 1, the
                 // odd lane rows 2, 3, and they swap (2 hashes + 2 lane exchanges instead of 4 hashes per lane).
                 const unsigned rb = ((unsigned)b * H + h) * TqMax;
-                if ((TkMax & 1) == 0) {
+                if constexpr (EVEN) {
                     const int odd = li & 1, ra_ = 2 * odd;
                     unsigned mine[2], both[4];
 #pragma unroll
@@ -508,13 +523,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
                 float pv = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]);
                 if (!full && !((q < Tq) && (key < Tk) && (!causal || key <= q + shift))) pv = 0.f;
                 float pd = pv, dpr = dp[r];
-                if (drop_thr) {
+                if constexpr (DROP) {
                     const bool keep = keep4[r];
-                    pd = keep ? pv * drop_scale : 0.f;     // dV sees the dropped probabilities
-                    dpr = keep ? dpr * drop_scale : 0.f;
+                    pd = keep ? pv : 0.f;                  // dV sees the dropped probabilities (x drop_scale: once, on dV)
+                    dpr = keep ? dpr : 0.f;
                 }
                 p[qj][r] = pd;
-                ds[qj][r] = pv * (dpr - d4[r]) * SCALE;
+                ds[qj][r] = pv * fmaf(dpr, dscale, -d4[r]);          // x 1/sqrt(d): once, on dK
             }
         }
         const bf16x8 p0 = pack_frag(p[0], p[1]), p1 = pack_frag(p[2], p[3]);
@@ -533,8 +548,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
         bf16_t* pk_ = dK + dkoff + (size_t)key * dk_rs + h * 64;
         bf16_t* pv_ = dV + dvoff + (size_t)key * dv_rs + h * 64;
         const unsigned grow = (unsigned)((vl.cu_k ? vl.cu_k[b] : b * TkMax) + key);     // thirds 1 (k) and 2 (v) of the fused c_attn
-        const float fk = od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f;
-        const float fv = od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f;
+        const float fk = (od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+        const float fv = (od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f) * dscale;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             adk[dt] *= fk;
@@ -546,6 +561,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
         }
     }
 }
+
+// variant of a kernel template <bool DROP, bool EVEN> for this call (EVEN only matters with dropout)
+#define ATTN_DISPATCH(KERNEL, drop_thr, Tk, ...)                                   \
+    do {                                                                           \
+        if (!(drop_thr)) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);   \
+        else if (((Tk) & 1) == 0) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__);               \
+    } while (0)
 
 bool strides_ok(const void* p, long bs, int rs) { return p && ALIGNED16(p) && (bs % 8 == 0) && (rs % 8 == 0) && rs >= 64; }
 
@@ -565,8 +588,8 @@ extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_r
     I2T_REQUIRE(H <= 65535 && B <= 65535, "i2t_attention_fwd: grid too large");
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     dim3 grid((Tq + 63) / 64, H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
-                       Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q});
+    ATTN_DISPATCH(attn_fwd_kernel, drop_thr, Tk, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
+                  Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q});
     I2T_CHECK_LAUNCH("i2t_attention_fwd");
     return I2T_OK;
 }
@@ -590,13 +613,13 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
     const VarLen vl{cu_q, cu_k, total_q};
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO,
-                       AttnPtr{(const bf16_t*)o, o_bs, o_rs}, lse, delta_ws,
-                       (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
-                       out_drop_scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
-                       (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl,
-                       out_drop_key, out_drop_thr, out_drop_scale);
+    const AttnPtr Ow{(const bf16_t*)o, o_bs, o_rs};
+    ATTN_DISPATCH(attn_bwd_dq_kernel, drop_thr, Tk, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
+                  (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
+                  out_drop_scale);
+    ATTN_DISPATCH(attn_bwd_dkv_kernel, drop_thr, Tk, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
+                  (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl,
+                  out_drop_key, out_drop_thr, out_drop_scale);
     I2T_CHECK_LAUNCH("i2t_attention_bwd");
     return I2T_OK;
 }

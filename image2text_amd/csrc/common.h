@@ -94,6 +94,14 @@ __device__ __forceinline__ void dropout_keep4(unsigned key, unsigned idx0, unsig
     }
 }
 
+// idx0 even: the 4 elements are the two fields of two consecutive hashes (no per-lane alignment case)
+__device__ __forceinline__ void dropout_keep4_even(unsigned key, unsigned idx0, unsigned thr16, bool (&keep)[4]) {
+    const unsigned p0 = idx0 >> 1;
+    const unsigned h0 = dropout_hash(key, p0), h1 = dropout_hash(key, p0 + 1);
+    keep[0] = (h0 & 0xffffu) >= thr16; keep[1] = (h0 >> 16) >= thr16;
+    keep[2] = (h1 & 0xffffu) >= thr16; keep[3] = (h1 >> 16) >= thr16;
+}
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

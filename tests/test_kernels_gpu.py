@@ -720,7 +720,8 @@ def test_gemm_epilogue_dropout(ops):
     check('qkv multipliers', outb, base * mult.repeat_interleave(N // 3, dim=1), 2e-2, 1 / 128)
 
 
-@pytest.mark.parametrize('B,H,Tq,Tk,causal', [(2, 2, 64, 64, True), (2, 3, 100, 40, False)])
+@pytest.mark.parametrize('B,H,Tq,Tk,causal', [(2, 2, 64, 64, True), (2, 3, 100, 40, False), (1, 2, 70, 37, False),
+                                                (2, 1, 33, 131, True)])      # odd Tk: the per-lane alignment variant
 def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
     from image2text_amd import rng
     d = 64 * H
