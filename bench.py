@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=1024, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=2048, help='images per GPU per step')
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=4096, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
@@ -302,6 +302,7 @@ def main():
             'host_input_images_per_sec': None if pcie_img_s is None else round(pcie_img_s, 1),     # H2D copy of the batch inside the step
             # nominal = SURVEY 8(d) required-output count (98 GFLOP/image); the step executes less: padded caption rows are skipped
             'step_nominal_tflops': round(img_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
+            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }
         traffic = None
         try:      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same batch only

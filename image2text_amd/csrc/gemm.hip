@@ -387,7 +387,8 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bool keep[4];
-            dropout_keep4(p.drop_key, (unsigned)m[q] * (unsigned)p.N + (unsigned)n4[q], p.drop_thr, keep);
+            // N % 4 == 0 and n4 % 4 == 0 on this path (epilogue_fast_ok): the index is even -> two hashes, no alignment case
+            dropout_keep4_even(p.drop_key, (unsigned)m[q] * (unsigned)p.N + (unsigned)n4[q], p.drop_thr, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[q][r] = keep[r] ? v[q][r] * p.drop_scale : 0.f;
         }

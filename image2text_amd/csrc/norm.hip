@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 if (dx_bf16) {
                     if (drop_thr) {    // the bf16 copy feeds a dropped-out branch: its forward mask, idx = row * d + column
                         bool keep[4];
-                        dropout_keep4(drop_key, (unsigned)row * (unsigned)d + 4u * (unsigned)c, drop_thr, keep);
+                        dropout_keep4_even(drop_key, (unsigned)row * (unsigned)d + 4u * (unsigned)c, drop_thr, keep);      // d % 4 == 0: even index
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * drop_scale : 0.f;
                     }
