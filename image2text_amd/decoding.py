@@ -13,12 +13,16 @@ for the n-gram ban (``.tolist()``).  Here
 Because text rows never attend to the soft-prompt columns (see engine.py) the cache holds text positions only; the
 prompt shifts the position embedding by n_cls.
 """
+import os
 from types import SimpleNamespace
 
 import torch
 
 from . import ops
 from .engine import BF16, F32, HotPath
+
+
+ENC_CHUNK = int(os.environ.get('I2T_DECODE_ENC_CHUNK', '1024'))      # images per encoder pass inside generate()
 
 
 class GreedyDecoder:
@@ -121,7 +125,18 @@ class GreedyDecoder:
             st = self._state = self._build(B, max(total, dc.block))
         assert total <= st.tmax, f'prompt + new tokens ({total}) exceed the text window ({st.tmax})'
         # encoder + per-layer cross K/V (once per image)
-        enc_out, _ = eng.encode(images, False)
+        # (in slices of ENC_CHUNK images: every image is independent in the encoder, and its activations -- ~20 MB per
+        # image in eval mode -- would otherwise set the memory footprint of a large caption batch)
+        if B <= ENC_CHUNK:
+            enc_out, _ = eng.encode(images, False)
+        else:
+            enc_out = None
+            for i in range(0, B, ENC_CHUNK):
+                part, _ = eng.encode(images[i:i + ENC_CHUNK], False)
+                if enc_out is None:
+                    enc_out = torch.empty(B, *part.shape[1:], dtype=part.dtype, device=part.device)
+                enc_out[i:i + ENC_CHUNK].copy_(part)
+                del part
         S = enc_out.shape[1]
         if st.cross_kv:
             assert S == next(iter(st.cross_kv.values()))[1]
