@@ -338,11 +338,11 @@ def test_tiny_greedy_tokens(tiny_model, tiny_decode):
 def test_greedy_with_sliced_encoder_pass(tiny_model, tiny_decode, monkeypatch):
     """generate() runs the encoder in slices of ENC_CHUNK images (every image is independent there): same tokens and margins."""
     from image2text_amd import decoding
-    images = tiny_decode['images'].to(dev())
-    prompt = tiny_decode['prompt_ids'].to(dev())
-    assert images.shape[0] >= 3
+    images = torch.from_numpy(tiny_decode['images']).to(dev())
+    prompt = torch.from_numpy(tiny_decode['prompt']).to(dev())
+    assert images.shape[0] == 4
     whole, m0 = decoding.GreedyDecoder(tiny_model).generate(images, prompt, 24, return_margins=True, use_graph=False)
-    monkeypatch.setattr(decoding, 'ENC_CHUNK', 2)                      # ragged last slice when the batch is odd
+    monkeypatch.setattr(decoding, 'ENC_CHUNK', 3)                      # slices of 3 + 1 images
     sliced, m1 = decoding.GreedyDecoder(tiny_model).generate(images, prompt, 24, return_margins=True, use_graph=False)
     assert torch.equal(whole, sliced)
     assert torch.equal(m0, m1)
