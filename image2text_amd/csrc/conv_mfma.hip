@@ -121,6 +121,38 @@ __device__ __forceinline__ void patch_store(const PatchRegs<CP>& pr, bf16_t* __r
     }
 }
 
+// fp32 NCHW source with <= 4 channels and CP == 8 (the image under the first layer): one pixel per thread slot, its channels
+// gathered from the planes and written as ONE 16-byte [8 ch] chunk (the generic planar staging walks all CP channel slots
+// -- 5 of 8 are padding -- with 2-byte LDS stores, 14 rounds per tile); in two halves like the NHWC patch so that the next
+// tile's pixels are in flight while the current tile is computed.
+struct PatchRegsImg {
+    static constexpr int N = (PW * PW + 255) / 256;
+    float v[N][4];
+};
+__device__ __forceinline__ void img_patch_load(PatchRegsImg& pr, const void* __restrict__ src, int b, int C, int H, int W, int y0,
+                                               int x0, int pad_before, int tid) {
+    const size_t plane = (size_t)H * W;
+    const float* s = reinterpret_cast<const float*>(src) + (size_t)b * C * plane;
+#pragma unroll
+    for (int u = 0; u < PatchRegsImg::N; ++u) {
+        const int i = tid + 256 * u;
+        const int px = i % PW, py = i / PW;
+        const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
+        const bool ok = i < PW * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pr.v[u][c] = (ok && c < C) ? s[c * plane + (size_t)gy * W + gx] : 0.f;
+    }
+}
+__device__ __forceinline__ void img_patch_store(const PatchRegsImg& pr, bf16_t* __restrict__ pl, int tid) {
+#pragma unroll
+    for (int u = 0; u < PatchRegsImg::N; ++u) {
+        const int i = tid + 256 * u;
+        if (i >= PW * PW) continue;
+        const u32x4 v = {pack_bf16x2(pr.v[u][0], pr.v[u][1]), pack_bf16x2(pr.v[u][2], pr.v[u][3]), 0u, 0u};
+        *reinterpret_cast<u32x4*>(pl + (size_t)i * 8) = v;            // [py][px][8 ch]
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fwd / bwd-data
 template <int CP, int NT, int SRC, bool IN_GELU, bool DGELU, bool DST_NCHW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__ src, const bf16_t* __restrict__ wr,
@@ -143,14 +175,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
         *reinterpret_cast<u32x4*>(wl + co * WROW + rest * 8) = *reinterpret_cast<const u32x4*>(wr + (size_t)i * 8);
     }
     PatchRegs<CP> pr;
+    PatchRegsImg pi;
+    constexpr bool IMG_OK = SRC == SRC_NCHW_F32 && CP == 8 && !IN_GELU;
+    const bool img = IMG_OK && Cin <= 4;                      // workgroup-uniform
     if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, 0, pad_before, tid);
+    else if (img) img_patch_load(pi, src, b, Cin, H, W, y0, 0, pad_before, tid);
     for (int tx = 0; tx < tiles_x; ++tx) {
     const int x0 = tx * TS;
     __syncthreads();                                          // the previous tile's patch reads are done
     if (SRC == SRC_NHWC_BF16) patch_store<CP, IN_GELU>(pr, pl, tid);
+    else if (img) img_patch_store(pi, pl, tid);
     else stage_patch<CP, SRC, IN_GELU>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
     __syncthreads();
-    if (SRC == SRC_NHWC_BF16 && tx + 1 < tiles_x) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, x0 + TS, pad_before, tid);
+    if (tx + 1 < tiles_x) {
+        if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, x0 + TS, pad_before, tid);
+        else if (img) img_patch_load(pi, src, b, Cin, H, W, y0, x0 + TS, pad_before, tid);
+    }
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
 // ------------------------------------------------------------------------------------------------ bwd-weight
 // scratch layout: [COP][NTAP][CP] f32 (this launch's partial dW), db scratch [COP]
 template <int CP, int COP, int DY_SRC, int ACT_SRC, bool ACT_GELU>
-__global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* __restrict__ dy, const void* __restrict__ act,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_mfma_bwd_weight_kernel(const void* __restrict__ dy, const void* __restrict__ act,
                                                                    float* __restrict__ scratch, float* __restrict__ db,
                                                                    int Cin, int Cout, int H, int W, int pad_before,
                                                                    int tiles_x) {
@@ -261,6 +301,9 @@ __global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* _
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < COP) dbs[tid] = 0.f;
+    float dbp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dbp[t] = 0.f;
 
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int x0 = tx * TS;
@@ -288,11 +331,6 @@ __global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* _
         }
         stage_patch<CP, ACT_SRC, ACT_GELU>(pl, act, b, Cin, H, W, y0, x0, pad_before, tid);
         __syncthreads();
-        if (db && tid < COP) {
-            float s = 0.f;
-            for (int px = 0; px < TS * TS; ++px) s += bf16_to_f32(dl[px * COP + tid]);
-            dbs[tid] += s;
-        }
         // 8 k-steps of 32 pixels = 2 tile rows x 16 x; k-slot (g, j) <-> pixel (row 2 s + (j >> 2), x = 4 g + (j & 3))
 #pragma unroll 1
         for (int s = 0; s < 8; ++s) {
@@ -304,6 +342,15 @@ __global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* _
                 s16x4 hi = lds_read_tr16(a0 + TS * COP);
                 s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 fa[t] = __builtin_bit_cast(bf16x8, v);
+            }
+            // bias gradient = column sums of dY: lane (g, li) already holds dY[8 pixels of chunk g][co = 16 t + li] in fa[t]
+            // (every wave loads the same A fragments), so the waves take turns adding them up -- the separate pass over the
+            // LDS tile (COP threads x 256 serial reads per tile) cost 15-30 % of this kernel
+            if (db && w == (s & 3)) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dbp[t] += (float)fa[t][j];
             }
 #pragma unroll
             for (int n = 0; n < NPW; ++n) {
@@ -339,6 +386,15 @@ __global__ __launch_bounds__(256) void conv_mfma_bwd_weight_kernel(const void* _
                 const int co = 16 * t + 4 * g + e;
                 atomicAdd(scratch + ((size_t)co * NTAP + tap) * CP + ci, acc[n][t][e]);
             }
+    }
+    if (db) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v = dbp[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) atomicAdd(&dbs[16 * t + li], v);      // LDS: 4 waves x NT x 16 adds per workgroup
+        }
     }
     __syncthreads();
     if (db && tid < Cout) atomicAdd(db + tid, dbs[tid]);
