@@ -305,6 +305,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 #pragma unroll
     for (int t = 0; t < NT; ++t) dbp[t] = 0.f;
 
+    // the fp32 image under the first layer: pixel-chunk staging, next tile's pixels in flight during the MFMAs
+    constexpr bool IMG_OK = ACT_SRC == SRC_NCHW_F32 && CP == 8 && !ACT_GELU;
+    const bool img = IMG_OK && Cin <= 4;
+    PatchRegsImg pi;
+    if (img) img_patch_load(pi, act, b, Cin, H, W, y0, 0, pad_before, tid);
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int x0 = tx * TS;
         __syncthreads();
@@ -329,8 +334,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
                 dl[(py * TS + px) * COP + c] = v;
             }
         }
-        stage_patch<CP, ACT_SRC, ACT_GELU>(pl, act, b, Cin, H, W, y0, x0, pad_before, tid);
+        if (img) img_patch_store(pi, pl, tid);
+        else stage_patch<CP, ACT_SRC, ACT_GELU>(pl, act, b, Cin, H, W, y0, x0, pad_before, tid);
         __syncthreads();
+        if (img && tx + 1 < tiles_x) img_patch_load(pi, act, b, Cin, H, W, y0, x0 + TS, pad_before, tid);
         // 8 k-steps of 32 pixels = 2 tile rows x 16 x; k-slot (g, j) <-> pixel (row 2 s + (j >> 2), x = 4 g + (j & 3))
 #pragma unroll 1
         for (int s = 0; s < 8; ++s) {
