@@ -57,6 +57,8 @@ struct GemmParams {
     float drop_scale;
     int g2_splits, g2_nk;     // 256^2 kernel: K slices per output tile and K-tiles per slice (even)
     int g2_gn;                // 256^2 kernel: column tiles per group of the tile order
+    int g2_dbg;               // experiment (I2T_G256_DBG): 1 = epilogue without its global stores, 2 = no epilogue at all
+    int g2_stagger, g2_stagger_groups;   // experiment: start delay (units of s_sleep 127) x (workgroup index within its XCD mod groups)
 };
 
 // Tile order inside an XCD's contiguous chunk of the grid.  PMC (round 1, B = 256): with M fastest the GEMM family moved
@@ -291,6 +293,14 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 #ifndef G2_EPI_DEPTH
 #define G2_EPI_DEPTH 1
 #endif
+// Output tiles are written with non-temporal stores: a tile's 128-256 KB burst then does not have to find room in the
+// XCD's 4 MB L2 (32 CUs x 128 KB arrive together), and the next output tile's first DMA fence -- which, vmcnt being one
+// in-order counter, also waits for these stores -- comes 1-2 us sooner per tile (+1 % on the whole step).
+#ifndef G2_PLAIN_STORES
+#define G2_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define G2_STORE(ptr, val) (*(ptr) = (val))
+#endif
 struct EpiPre {
     f32x4 bv[4], add[4];
     u32x2 ax[4];
@@ -353,7 +363,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
     int nc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        ok[q] = m[q] < p.M && n4[q] < p.N;
+        ok[q] = m[q] < p.M && n4[q] < p.N && !(p.g2_dbg & 1);
         nc[q] = epi_clamp_n(p, n4[q]);
     }
     f32x4 v[4];
@@ -368,7 +378,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
         for (int q = 0; q < 4; ++q)
             if (ok[q]) {
                 const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
-                *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]) = pk;
+                G2_STORE(reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]), pk);
             }
     }
     if (F.f_gelu) {
@@ -411,7 +421,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
             if (EPI == 7 && n4[q] + 4 > p.N) {              // the quad that straddles N
                 for (int r = 0; r < p.N - n4[q]; ++r) c[r] = v[q][r];
             } else {
-                *reinterpret_cast<f32x4*>(c) = v[q];
+                G2_STORE(reinterpret_cast<f32x4*>(c), v[q]);
             }
         }
     } else {
@@ -423,7 +433,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
                     for (int r = 0; r < p.N - n4[q]; ++r) c[r] = f32_to_bf16(v[q][r]);
                 } else {
                     const u32x2 pk = {pack_bf16x2(v[q][0], v[q][1]), pack_bf16x2(v[q][2], v[q][3])};
-                    *reinterpret_cast<u32x2*>(c) = pk;
+                    G2_STORE(reinterpret_cast<u32x2*>(c), pk);
                 }
             }
     }
@@ -910,6 +920,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
     const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 
+    if (p.g2_stagger > 0) {             // de-phase the workgroups of an XCD: their epilogues (HBM bursts) then interleave
+        const int k = ((bid >> 3) % p.g2_stagger_groups) * p.g2_stagger;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     G2<A_KMAJOR, B_KMAJOR, EPI == 6> g;
     g.init(p, smem, tid);
     g.cur = g.tile_desc(p, first, ntiles);
@@ -952,7 +966,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         } else {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
-            epilogue_tile_tr<8, EPI>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            if (!(p.g2_dbg & 2))
+                epilogue_tile_tr<8, EPI>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            else if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[7][3][3];      // keep the accumulators alive
         }
         g.init_lane(p, tid);
         g.next_tile_reads(ra, rb0);      // units 0, 1 of the next tile landed before the last fence; same LGKM count as in-loop
@@ -1192,6 +1208,15 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
     p.g2_splits = 1; p.g2_nk = 0;
     { static const char* e = getenv("I2T_G256_GN"); static const int gn = e ? atoi(e) : 8; p.g2_gn = gn > 0 ? gn : 8; }
+    {
+        static const char* e = getenv("I2T_G256_STAGGER");                   // "units[,groups]"
+        static const int su = e ? atoi(e) : 0;
+        static const int sg = (e && strchr(e, ',')) ? atoi(strchr(e, ',') + 1) : 2;
+        p.g2_stagger = su; p.g2_stagger_groups = sg > 1 ? sg : 2;
+        static const char* d = getenv("I2T_G256_DBG");
+        static const int dbg = d ? atoi(d) : 0;
+        p.g2_dbg = dbg;
+    }
     I2T_REQUIRE(drop_mode == 0 || (drop_mode == 1 && (long)M * N < (1L << 32)) || (drop_mode == 2 && N % 12 == 0),
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
