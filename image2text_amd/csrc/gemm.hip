@@ -961,7 +961,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = mb + i * 16 + r, n = n_ + j * 16;
-                        if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                        if (m < p.M && n < p.N && !(p.g2_dbg & 2)) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
                     }
         } else {
             int lane_e = tid & 63;
