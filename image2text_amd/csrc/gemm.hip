@@ -324,14 +324,15 @@ struct EpiFlags {
 // EPI 7: the straddling quad loads bias from [N-1 .. N+2]: inside the 16-B padded vector
 __device__ __forceinline__ int epi_clamp_n(const GemmParams& p, int n4) { return min(n4, ((p.N + 3) & ~3) - 4); }
 
-template <int EPI, bool WITH_BIAS = true>
+// FULL: the caller guarantees that every quad lies inside C (no clamps, no store predicates)
+template <int EPI, bool WITH_BIAS = true, bool FULL = false>
 __device__ __forceinline__ void epilogue_loads4(const GemmParams& p, const int (&m)[4], const int (&n4)[4], EpiPre& L) {
     const EpiFlags<EPI> F(p);
     int mc[4], nc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        mc[q] = min(m[q], p.M - 1);
-        nc[q] = epi_clamp_n(p, n4[q]);
+        mc[q] = FULL ? m[q] : min(m[q], p.M - 1);
+        nc[q] = FULL ? n4[q] : epi_clamp_n(p, n4[q]);
     }
     if (WITH_BIAS && F.f_bias) {
 #pragma unroll
@@ -355,7 +356,7 @@ __device__ __forceinline__ void epilogue_loads4(const GemmParams& p, const int (
     }
 }
 
-template <int EPI>
+template <int EPI, bool FULL = false>
 __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4],
                                                  const EpiPre& L) {
     const EpiFlags<EPI> F(p);
@@ -363,8 +364,8 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
     int nc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        ok[q] = m[q] < p.M && n4[q] < p.N && !(p.g2_dbg & 1);
-        nc[q] = epi_clamp_n(p, n4[q]);
+        ok[q] = FULL ? true : (m[q] < p.M && n4[q] < p.N && !(p.g2_dbg & 1));
+        nc[q] = FULL ? n4[q] : epi_clamp_n(p, n4[q]);
     }
     f32x4 v[4];
     const bool has_add = F.f_res || F.f_acc;
@@ -483,7 +484,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 // c = lane&15, so one store instruction covers 4 rows x 128 B (bf16) / 256 B (f32) of FULL cache lines instead of 16 rows
 // x 32 / 64 B.  Measured need (round 1, K sweep): the direct form cost a fixed ~18 us per 256^2 tile -- 16 distinct lines
 // per store instruction, row strides of 1-4 KiB camping on a few L2 channels.
-template <int MI, int EPI>
+template <int MI, int EPI, bool FULL = false>
 __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int lane,
                                                  unsigned char* wave_lds) {
     const int g = lane >> 4, li = lane & 15;
@@ -504,7 +505,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     if constexpr (EPI != 0) {
         const EpiFlags<EPI> F(p);
         if (F.f_bias) {                                       // one bias vector per lane and tile
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + epi_clamp_n(p, n4c));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + (FULL ? n4c : epi_clamp_n(p, n4c)));
 #pragma unroll
             for (int s = 0; s < NB; ++s)
 #pragma unroll
@@ -514,7 +515,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
             constexpr int d = decltype(D_)::value;
             int m[4], n4[4];
             rows_of(d, m, n4);
-            epilogue_loads4<EPI, false>(p, m, n4, L[d % NB]);
+            epilogue_loads4<EPI, false, FULL>(p, m, n4, L[d % NB]);
         });
     }
     static_for<MI>([&](auto I_) {
@@ -522,7 +523,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
         int m[4], n4[4];
         if constexpr (EPI != 0 && i + DEPTH < MI) {
             rows_of(i + DEPTH, m, n4);
-            epilogue_loads4<EPI, false>(p, m, n4, L[(i + DEPTH) % NB]);
+            epilogue_loads4<EPI, false, FULL>(p, m, n4, L[(i + DEPTH) % NB]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -535,7 +536,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
         }
         rows_of(i, m, n4);
         if constexpr (EPI != 0) {
-            epilogue_finish4<EPI>(p, a, m, n4, L[i % NB]);
+            epilogue_finish4<EPI, FULL>(p, a, m, n4, L[i % NB]);
         } else if (fast) {
             epilogue_batch4<0>(p, a, m, n4);
         } else {
@@ -966,9 +967,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         } else {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
-            if (!(p.g2_dbg & 2))
-                epilogue_tile_tr<8, EPI>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
-            else if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[7][3][3];      // keep the accumulators alive
+            // most tiles lie inside C: that copy of the epilogue carries no clamps and no store predicates (wave-uniform choice)
+            const int inside = (EPI != 0 && p.g2_dbg == 0) ?
+                __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= p.M && n0 + g.wc * 64 + 64 <= p.N) ? 1 : 0) : 0;
+            if (p.g2_dbg & 2) {
+                if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[7][3][3];      // keep the accumulators alive
+            } else if (inside) {
+                epilogue_tile_tr<8, EPI, true>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            } else {
+                epilogue_tile_tr<8, EPI, false>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            }
         }
         g.init_lane(p, tid);
         g.next_tile_reads(ra, rb0);      // units 0, 1 of the next tile landed before the last fence; same LGKM count as in-loop
