@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int64_t* __res
     }
 }
 
-// dst[r][:] (+)= sum_b x[b][r][:]   (one thread per float4 column chunk of a row; loops over the batch)
+// dst[r][:] (+)= sum_b x[b][r][:]   (one thread per float4 column chunk of a row; loops over its slice of the batch --
+// blockIdx.y -- with 4 loads in flight; more than one slice: float atomics onto a dst that already holds its base value)
 __global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __restrict__ x, long x_bs,
                                                              float* __restrict__ dst, int B, int rows, int d,
                                                              int accumulate) {
@@ -41,11 +42,36 @@ __global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __rest
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)rows * d4) return;
     const int r = (int)(idx / d4), c = (int)(idx % d4);
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)r * d) + c;
+    const size_t bs4 = (size_t)x_bs >> 2;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) s += reinterpret_cast<const f32x4*>(x + (size_t)b * x_bs + (size_t)r * d)[c];
-    f32x4* o = reinterpret_cast<f32x4*>(dst + (size_t)r * d) + c;
-    if (accumulate) s += *o;
-    *o = s;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        const f32x4 v0 = xp[(size_t)b * bs4], v1 = xp[(size_t)(b + 1) * bs4], v2 = xp[(size_t)(b + 2) * bs4], v3 = xp[(size_t)(b + 3) * bs4];
+        s += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < b1; ++b) s += xp[(size_t)b * bs4];
+    float* o = dst + (size_t)r * d + 4 * c;
+    if (gridDim.y == 1) {
+        f32x4* o4 = reinterpret_cast<f32x4*>(o);
+        if (accumulate) s += *o4;
+        *o4 = s;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(o + e, s[e]);
+    }
+}
+
+// launch helper: batch slices when the column grid alone cannot fill the chip (>= 32 batch entries per slice)
+static void launch_sum_over_batch(hipStream_t s, const float* x, long x_bs, float* dst, int B, int rows, int d, int accumulate) {
+    const long items = (long)rows * (d >> 2);
+    const int col_blocks = (int)((items + 255) / 256);
+    int slices = 1;
+    while (slices < 32 && col_blocks * slices < 1024 && B / (slices * 2) >= 32) slices *= 2;
+    if (slices > 1 && !accumulate) (void)hipMemsetAsync(dst, 0, (size_t)rows * d * sizeof(float), s);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(col_blocks, slices), dim3(256), 0, s, x, x_bs, dst, B, rows, d, accumulate);
 }
 
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ src, float* __restrict__ y, long y_bs,
@@ -323,9 +349,7 @@ extern "C" int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, 
     if (dwpe && pos) {
         hipLaunchKernelGGL(embed_bwd_wpe_packed_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, pos, dx, dwpe, d, pos_offset, rows);
     } else if (dwpe) {
-        const long items = (long)T * (d >> 2);
-        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((items + 255) / 256), dim3(256), 0, s, dx, (long)T * d,
-                           dwpe + (size_t)pos_offset * d, B, T, d, 1);
+        launch_sum_over_batch(s, dx, (long)T * d, dwpe + (size_t)pos_offset * d, B, T, d, 1);
     }
     I2T_CHECK_LAUNCH("i2t_embed_bwd");
     return I2T_OK;
@@ -334,9 +358,7 @@ extern "C" int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, 
 extern "C" int i2t_sum_over_batch(void* stream, const float* x, long x_batch_stride, float* dst, int B, int rows, int d,
                                   int accumulate) {
     I2T_REQUIRE(x && dst && B > 0 && rows > 0 && d % 4 == 0 && x_batch_stride % 4 == 0, "i2t_sum_over_batch: bad args");
-    const long items = (long)rows * (d >> 2);
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride,
-                       dst, B, rows, d, accumulate);
+    launch_sum_over_batch((hipStream_t)stream, x, x_batch_stride, dst, B, rows, d, accumulate);
     I2T_CHECK_LAUNCH("i2t_sum_over_batch");
     return I2T_OK;
 }

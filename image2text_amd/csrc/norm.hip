@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256) void lnnd_bwd_partial_kernel(const float* __re
     }
 }
 
-// bwd pass 2: one thread per float4 of the slab, looping over the batch: dx written, dgamma/dbeta/dadd summed in
-// registers (no atomics, deterministic) and added once.
+// bwd pass 2: one thread per float4 of the slab, looping over ITS SLICE of the batch (blockIdx.y): dx written,
+// dgamma/dbeta/dadd summed in registers and added once per slice (float atomics when there is more than one slice).
+// One slice for the whole batch meant 98 workgroups for a 196 x 512 slab and two loads in flight per thread: 2.4 TB/s.
 __global__ __launch_bounds__(256) void lnnd_bwd_apply_kernel(const float* __restrict__ dy, long dy_bs,
                                                              const float* __restrict__ x, const float* __restrict__ add,
                                                              const float* __restrict__ gamma,
@@ -300,7 +301,10 @@ __global__ __launch_bounds__(256) void lnnd_bwd_apply_kernel(const float* __rest
     const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c];
     const f32x4 ad = add ? reinterpret_cast<const f32x4*>(add)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = ag, aa = ag;
-    for (int b = 0; b < B; ++b) {
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+#pragma unroll 2
+    for (int b = b0; b < b1; ++b) {
         const float* st = stats + (size_t)b * STATS_STRIDE;
         const float mean = st[0], rstd = st[1];
         float s1 = 0.f, s2 = 0.f;
@@ -323,9 +327,18 @@ __global__ __launch_bounds__(256) void lnnd_bwd_apply_kernel(const float* __rest
         }
         reinterpret_cast<f32x4*>(dx + (size_t)b * n)[c] = o;
     }
-    if (dgamma) reinterpret_cast<f32x4*>(dgamma)[c] += ag;
-    if (dbeta) reinterpret_cast<f32x4*>(dbeta)[c] += ab;
-    if (dadd) reinterpret_cast<f32x4*>(dadd)[c] += aa;
+    if (gridDim.y == 1) {
+        if (dgamma) reinterpret_cast<f32x4*>(dgamma)[c] += ag;
+        if (dbeta) reinterpret_cast<f32x4*>(dbeta)[c] += ab;
+        if (dadd) reinterpret_cast<f32x4*>(dadd)[c] += aa;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (dgamma) atomicAdd(dgamma + 4 * (size_t)c + e, ag[e]);
+            if (dbeta) atomicAdd(dbeta + 4 * (size_t)c + e, ab[e]);
+            if (dadd) atomicAdd(dadd + 4 * (size_t)c + e, aa[e]);
+        }
+    }
 }
 
 }  // namespace
@@ -385,7 +398,10 @@ extern "C" int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lnnd_bwd_partial_kernel, dim3(B, NSPLIT), dim3(256), 0, s, dy, dy_batch_stride, x, add, gamma, stats, (int)n);
     const int n4 = (int)(n >> 2);
-    hipLaunchKernelGGL(lnnd_bwd_apply_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, dy, dy_batch_stride, x, add, gamma,
+    const int col_blocks = (n4 + 255) / 256;
+    int slices = 1;                                            // >= 32 images per slice, ~1024 workgroups at most
+    while (slices < 16 && col_blocks * slices < 1024 && B / (slices * 2) >= 32) slices *= 2;
+    hipLaunchKernelGGL(lnnd_bwd_apply_kernel, dim3(col_blocks, slices), dim3(256), 0, s, dy, dy_batch_stride, x, add, gamma,
                        stats, dx, dgamma, dbeta, dadd, B, (int)n);
     I2T_CHECK_LAUNCH("i2t_layernorm_nd_bwd");
     return I2T_OK;

@@ -309,7 +309,8 @@ def test_layernorm(ops, M, d, bias):
             check('ln dbeta', db, br.grad, tol * math.sqrt(M), tol)
 
 
-@pytest.mark.parametrize('B,rows,d,bias', [(3, 16, 64, False), (2, 196, 512, False), (2, 16, 64, True)])
+@pytest.mark.parametrize('B,rows,d,bias', [(3, 16, 64, False), (2, 196, 512, False), (2, 16, 64, True),
+                                           (130, 16, 64, True)])       # 130 images: the backward runs in 4 ragged batch slices
 def test_layernorm_nd(ops, B, rows, d, bias):
     x = rnd(B, rows, d, seed=16) * 1.5 + 0.3
     add = rnd(rows, d, seed=17)
@@ -536,6 +537,14 @@ def test_small_helpers(ops):
     dst = torch.ones(rows, d, device=dev())
     ops.sum_over_batch(y[:, ncls:], (ncls + rows) * d, dst, B, rows, d, accumulate=True)
     check('sum_over_batch', dst, 1 + B * src, 1e-6, 1e-6)
+    # a batch large enough for the sliced form (131 entries -> 4 ragged slices, float atomics), with and without accumulate
+    Bb = 131
+    xb = rnd(Bb, ncls + rows, d, seed=73)
+    want = xb[:, ncls:].double().sum(0).float()
+    for acc in (True, False):
+        dst = torch.full((rows, d), 2.0, device=dev())
+        ops.sum_over_batch(xb[:, ncls:], (ncls + rows) * d, dst, Bb, rows, d, accumulate=acc)
+        check(f'sum_over_batch sliced acc={acc}', dst, want + (2.0 if acc else 0.0), 1e-4, 1e-5)
     out = torch.zeros(B, rows, d, dtype=BF16, device=dev())
     ops.copy_rows(y[:, ncls:], (ncls + rows) * d, out, rows * d, B, rows, d)
     check('copy_rows', out, src.expand(B, rows, d), 0, 1 / 128)

@@ -385,6 +385,8 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
     from the step's DropPlans), so loss and every gradient must agree as in the dropout-free case; a second step must draw
     different masks; eval mode must be dropout-free."""
     from oracle import reference_model as orc
+    torch.manual_seed(20240917)  # the step seed (hence every mask) derives from torch's seed: without this the masks -- and how
+    #                              close to its tolerances the test lands -- changed from process to process (1 failure in ~10 runs)
     cfg = tiny_config(dropout=0.1)
     tok = fake_tokenizer(cfg.decoder_config.vocab_size)
     w = _wrapper(cfg)
@@ -430,6 +432,7 @@ def test_training_memorises_a_small_caption_set():
     fused AdamW, bf16 shadow refresh): 8 fixed (image, caption) pairs must be memorised -- the loss has to fall far below
     both its initial value and the unigram entropy, which only happens if the image-conditioned gradients are right."""
     from image2text_amd.training.optim import FusedAdamW
+    torch.manual_seed(7)         # reproducible dropout masks (the step seeds derive from torch's seed)
     cfg = tiny_config(dropout=0.05)
     w = _wrapper(cfg).train()
     det_init_(w.model, seed=3, style='reference')
