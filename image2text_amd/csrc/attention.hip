@@ -39,6 +39,7 @@ struct VarLen {
     const int* cu_q;
     const int* cu_k;
     int total_q;
+    int nseq;                 // B: sequences in the batch (the 1-D grid decode needs it)
 };
 
 // stage rows [r0, r0+64) x 64 columns of one (b, h) slice into a P160 tile; rows >= nrows are zero-filled
@@ -115,6 +116,30 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Workgroup -> (tile, head, sequence) for a 1-D grid of ntile * H * B workgroups.  The tiles of one (head, sequence) pair
+// re-read that pair's K and V (forward, dQ) or Q and dO (dK/dV) -- 5 times at T = 260.  Workgroups are dealt round-robin
+// over the 8 XCDs by their linear id, so with the tile index fastest those 5 land on 5 different L2s and every re-read
+// crosses the fabric (PMC: 6.3 GB per encoder layer forward against 2.2 GB algorithmic at B = 2048).  Here ids l, l + 8,
+// l + 16, ... walk the tiles of ONE pair, i.e. one XCD serves all tiles of a pair back to back and its L2 absorbs the
+// re-reads: FETCH_SIZE of the three kernels fell from 1840 to 906 MB per launch.  Their time did not move (VALU-bound, see
+// below) -- kept for the fabric / HBM headroom it leaves to whatever runs beside them (the gradient exchange).  Placement
+// affects speed only: any mapping gives the same result.
+__device__ __forceinline__ void attn_block_coords(int ntile, int H, int B, int& tile, int& h, int& b) {
+    const int L = blockIdx.x, P = H * B, full = (P >> 3) * 8 * ntile;
+    int pair;
+    if (L < full) {
+        const int grp = L / (8 * ntile), r = L - grp * 8 * ntile;
+        pair = grp * 8 + (r & 7);
+        tile = r >> 3;
+    } else {
+        const int r = L - full;
+        pair = (P >> 3) * 8 + r / ntile;
+        tile = r % ntile;
+    }
+    h = pair % H;
+    b = pair / H;
+}
+
 // ================================================================================================== forward
 // All three kernels are VALU-bound (softmax + the dropout hash; ~4 VALU issue slots per MFMA slot), so the variants are
 // compile-time: DROP (probability dropout on) and EVEN (TkMax even: a lane's 4 consecutive keys are the fields of exactly
@@ -130,7 +155,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, Att
     unsigned char* vt_lds = smem + TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qt, h, b;
+    attn_block_coords((TqMax + 63) / 64, H, vl.nseq, qt, h, b);
     int Tq = TqMax, Tk = TkMax;
     size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, ooff = (size_t)b * o_bs;
     size_t stat_base = ((size_t)b * H + h) * TqMax;
@@ -268,7 +294,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnPtr Q, AttnPtr K, 
     unsigned char* vt_lds = smem + TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qt, h, b;
+    attn_block_coords((TqMax + 63) / 64, H, vl.nseq, qt, h, b);
     int Tq = TqMax, Tk = TkMax;
     size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, dooff = (size_t)b * dO.bs, dqoff = (size_t)b * dq_bs;
     size_t stat_base = ((size_t)b * H + h) * TqMax;
@@ -403,7 +430,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     float* dl_lds = lse_lds + 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kt, h, b;
+    attn_block_coords((TkMax + 63) / 64, H, vl.nseq, kt, h, b);
     int Tq = TqMax, Tk = TkMax;
     size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, dooff = (size_t)b * dO.bs;
     size_t dkoff = (size_t)b * dk_bs, dvoff = (size_t)b * dv_bs;
@@ -585,11 +613,11 @@ extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_r
                     strides_ok(o, o_bs, o_rs),
                 "i2t_attention_fwd: operands must be 16-byte aligned with strides that are multiples of 8");
     I2T_REQUIRE(!causal || Tk >= Tq, "i2t_attention_fwd: causal needs Tk >= Tq");
-    I2T_REQUIRE(H <= 65535 && B <= 65535, "i2t_attention_fwd: grid too large");
+    I2T_REQUIRE((double)((Tq + 63) / 64) * H * B < 2147483647.0, "i2t_attention_fwd: grid too large");
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
-    dim3 grid((Tq + 63) / 64, H, B);
+    dim3 grid(((Tq + 63) / 64) * H * B);
     ATTN_DISPATCH(attn_fwd_kernel, drop_thr, Tk, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
-                  Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q});
+                  Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q, B});
     I2T_CHECK_LAUNCH("i2t_attention_fwd");
     return I2T_OK;
 }
@@ -609,15 +637,16 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                     strides_ok(dk, dk_bs, dk_rs) && strides_ok(dv, dv_bs, dv_rs),
                 "i2t_attention_bwd: operands must be 16-byte aligned with strides that are multiples of 8");
     I2T_REQUIRE(!causal || Tk >= Tq, "i2t_attention_bwd: causal needs Tk >= Tq");
+    I2T_REQUIRE((double)((Tq + 63) / 64 + (Tk + 63) / 64) * H * B < 2147483647.0, "i2t_attention_bwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
-    const VarLen vl{cu_q, cu_k, total_q};
+    const VarLen vl{cu_q, cu_k, total_q, B};
     const AttnPtr Ow{(const bf16_t*)o, o_bs, o_rs};
-    ATTN_DISPATCH(attn_bwd_dq_kernel, drop_thr, Tk, dim3((Tq + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
+    ATTN_DISPATCH(attn_bwd_dq_kernel, drop_thr, Tk, dim3(((Tq + 63) / 64) * H * B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
                   (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
                   out_drop_scale);
-    ATTN_DISPATCH(attn_bwd_dkv_kernel, drop_thr, Tk, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
+    ATTN_DISPATCH(attn_bwd_dkv_kernel, drop_thr, Tk, dim3(((Tk + 63) / 64) * H * B), dim3(256), 0, s, Q, K, V, DO, lse, delta_ws,
                   (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl,
                   out_drop_key, out_drop_thr, out_drop_scale);
     I2T_CHECK_LAUNCH("i2t_attention_bwd");
