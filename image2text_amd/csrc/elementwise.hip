@@ -220,11 +220,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 __global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ g, long n4, long n, const float* __restrict__ ws,
                                                             bf16_t* __restrict__ gb, unsigned drop_key, unsigned drop_thr,
-                                                            float drop_scale) {
+                                                            float drop_scale, int keep_f32) {
+    // keep_f32: g itself is left un-normalised (its first consumer applies the factor, i2t_layernorm_bwd dx_pre_sumsq);
+    // only the bf16 copy is produced -- 6 bytes per element instead of 10
     const float inv = 1.0f / (sqrtf(*ws) + 1e-6f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = reinterpret_cast<f32x4*>(g)[i] * inv;
-        reinterpret_cast<f32x4*>(g)[i] = v;
+        if (!keep_f32) reinterpret_cast<f32x4*>(g)[i] = v;
         if (gb) {
             if (drop_thr) {        // the bf16 copy feeds a dropped-out branch: same elementwise mask as its forward
                 bool keep[4];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void scale_by_norm_kernel(float* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long e = n4 * 4 + threadIdx.x;
         float v = g[e] * inv;
-        g[e] = v;
+        if (!keep_f32) g[e] = v;
         if (gb) gb[e] = f32_to_bf16((drop_thr && !dropout_keep(drop_key, (unsigned)e, drop_thr)) ? 0.f : (drop_thr ? v * drop_scale : v));
     }
 }
@@ -433,14 +435,15 @@ extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, voi
     I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_grad_normalize: bad args");
     I2T_REQUIRE(drop_thr == 0 || (g_bf16 && n < (1L << 32)), "i2t_grad_normalize: dropout needs the bf16 copy and n < 2^32");
     hipStream_t s = (hipStream_t)stream;
-    if (!presummed) {          // presummed: the producer of g (i2t_layernorm_bwd's sumsq_out) already accumulated sum(g^2) into ws
+    I2T_REQUIRE(!(presummed & 2) || g_bf16, "i2t_grad_normalize: flag 2 (fp32 left as is) needs the bf16 copy");
+    if (!(presummed & 1)) {    // presummed (bit 0): the producer of g (i2t_layernorm_bwd's sumsq_out) already accumulated sum(g^2) into ws
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
         if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
         const int grid = grid_for(n >> 2, 1024);
         hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
     }
     hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16, drop_key,
-                       drop_thr, drop_scale);
+                       drop_thr, drop_scale, (presummed & 2) ? 1 : 0);
     if (clear_after) {         // zero the accumulator the NEXT producer will add into (a different float than ws)
         hipError_t e = hipMemsetAsync(clear_after, 0, sizeof(float), s);
         if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      int dx_accumulate, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int d, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                                                     float* __restrict__ sumsq_out) {
+                                                     float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
+    // dx_pre_sumsq: the dx this launch accumulates onto is still UN-normalised; its normaliser 1 / (||dx|| + 1e-6) -- the
+    // gradient normaliser of the block boundary above, whose fp32 rescale pass this replaces -- is applied while adding
+    const float pre = dx_pre_sumsq ? 1.0f / (sqrtf(*dx_pre_sumsq) + 1e-6f) : 1.0f;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = d >> 2;
     float ssq = 0.f;                          // sum of squares of the f32 dx this block writes (for the gradient normaliser)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-                if (dx_accumulate) o += *dxp;
+                if (dx_accumulate) o += *dxp * pre;
                 *dxp = o;
                 ssq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
                 if (dx_bf16) {
@@ -359,18 +362,19 @@ extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamm
 extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
                                  float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
-                                 float drop_scale, float* sumsq_out) {
+                                 float drop_scale, float* sumsq_out, const float* dx_pre_sumsq) {
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
+    I2T_REQUIRE(!dx_pre_sumsq || dx_accumulate, "i2t_layernorm_bwd: dx_pre_sumsq only applies when accumulating onto dx");
     I2T_REQUIRE(drop_thr == 0 || (dx_bf16 && (long)M * d < (1L << 32)), "i2t_layernorm_bwd: dropout needs dx_bf16 and M*d < 2^32");
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
     int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
     hipStream_t s = (hipStream_t)stream;
     if (dy_is_f32)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out);
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq);
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
 }

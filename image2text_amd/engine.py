@@ -270,9 +270,12 @@ class HotPath:
             ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
         return dx_out
 
-    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None, sumsq_out=None):
-        """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output, already normalised.  On return dx (and
-        dxb when emit_last_bf16) hold the gradient w.r.t. the block input."""
+    def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None, sumsq_out=None,
+                  dx_pre=None):
+        """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output; dxb already normalised, dx too unless dx_pre (1 float:
+        sum(dx^2)) is given -- then the first LayerNorm backward that accumulates onto dx applies 1 / (||dx|| + 1e-6) on the fly
+        (the normaliser's fp32 rescale pass is not run).  On return dx (and dxb when emit_last_bf16) hold the gradient w.r.t. the
+        block input."""
         a = self.arena
         M = vl.total if vl is not None else B * T
         cu = vl.cu if vl is not None else None
@@ -289,7 +292,8 @@ class HotPath:
                          dx_out=dln)
         ops.layernorm_bwd(dln, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.G(f'{pfx}.ln_2.weight'),
                           a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb,
-                          bf16_drop=None if sv.cross else dr['resid'])      # next consumer of dxb: attn.c_proj backward
+                          bf16_drop=None if sv.cross else dr['resid'],      # next consumer of dxb: attn.c_proj backward
+                          dx_pre_sumsq=dx_pre)                              # first fp32 use of dx in the block
         # ---- cross attention: x2 = x1 + out_proj(attn(q(ln_3 x1), kv(mem)))
         if sv.cross:
             win = a.W(f'{pfx}.cross_attn.in_proj_weight')
@@ -395,9 +399,10 @@ class HotPath:
         for l in reversed(range(len(saves))):
             cur, nxt = self._ws[slot:slot + 1], self._ws[1 - slot:2 - slot]
             # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
-            ops.grad_normalize(dx, cur, dxb, bf16_drop=saves[l].dr['mlp'], presummed=presummed, clear_after=nxt)
+            # (fp32 dx stays un-normalised here: the block's first LayerNorm backward rescales it while accumulating)
+            ops.grad_normalize(dx, cur, dxb, bf16_drop=saves[l].dr['mlp'], presummed=presummed, clear_after=nxt, keep_f32=True)
             self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
-                           vl=vl, sumsq_out=nxt)
+                           vl=vl, sumsq_out=nxt, dx_pre=cur)
             slot, presummed = 1 - slot, True
 
     # ------------------------------------------------------------------------------------------------ encoder

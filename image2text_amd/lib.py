@@ -17,7 +17,7 @@ SIGNATURES = {
     'i2t_gemm_reserve_cus': [I],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
-    'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P],
+    'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
     'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, U, U, F, P, P, I],
@@ -52,7 +52,7 @@ SIGNATURES = {
     'i2t_graph_destroy': [P],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -74,13 +74,13 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None, bf16_drop=None,
-                  sumsq_out=None):
+                  sumsq_out=None, dx_pre_sumsq=None):
     """bf16_drop = (1, key, thr, scale): elementwise dropout mask applied to the bf16 copy only (see include/i2t.h)."""
     _need_cuda(dy, x, dx)
     assert bf16_drop is None or int(bf16_drop[0]) == 1
     _l.check(_lib().i2t_layernorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
                                       int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d, *_drop(bf16_drop)[1:],
-                                      _p(sumsq_out)), 'i2t_layernorm_bwd')
+                                      _p(sumsq_out), _p(dx_pre_sumsq)), 'i2t_layernorm_bwd')
     return dx
 
 
@@ -153,12 +153,14 @@ def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
                                _p(gscale), M, V), 'i2t_ce_bwd')
 
 
-def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=None, presummed=False, clear_after=None):
-    """presummed: ws already holds sum(g^2) (layernorm_bwd's sumsq_out); clear_after: 1-float tensor zeroed afterwards."""
+def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=None, presummed=False, clear_after=None,
+                   keep_f32=False):
+    """presummed: ws already holds sum(g^2) (layernorm_bwd's sumsq_out); clear_after: 1-float tensor zeroed afterwards;
+    keep_f32: g stays un-normalised, only the bf16 copy is written (the first layernorm_bwd onto g passes dx_pre_sumsq=ws)."""
     _need_cuda(g, ws)
     assert bf16_drop is None or int(bf16_drop[0]) == 1
-    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws), _p(g_bf16), *_drop(bf16_drop)[1:], int(presummed),
-                                       _p(clear_after)), 'i2t_grad_normalize')
+    _l.check(_lib().i2t_grad_normalize(_stream(), _p(g), g.numel(), _p(ws), _p(g_bf16), *_drop(bf16_drop)[1:],
+                                       int(bool(presummed)) | (2 if keep_f32 else 0), _p(clear_after)), 'i2t_grad_normalize')
     return g
 
 

@@ -27,7 +27,7 @@ extern "C" {
 #define I2T_EINVAL (-1)   /* bad argument (shape/alignment/unsupported size) */
 #define I2T_EHIP (-2)     /* a HIP runtime call failed */
 
-#define I2T_ABI_VERSION 1
+#define I2T_ABI_VERSION 2
 
 int i2t_abi_version(void);
 /* copies the last error message of the calling thread into buf (NUL-terminated); returns its length */
@@ -86,8 +86,10 @@ int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const fl
 int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                       const float* mean, const float* rstd,
                       float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
-                      unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out);
-/* sumsq_out (bwd, nullable): += sum of squares of the f32 dx written by this call (after accumulation) -- lets the
+                      unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out, const float* dx_pre_sumsq);
+/* dx_pre_sumsq (bwd, nullable, needs dx_accumulate): the dx accumulated onto is still un-normalised -- its old value is
+ * multiplied by 1 / (sqrt(*dx_pre_sumsq) + 1e-6) while adding (the gradient normaliser of i2t_grad_normalize flag 2).
+ * sumsq_out (bwd, nullable): += sum of squares of the f32 dx written by this call (after accumulation) -- lets the
  * gradient normaliser that consumes dx next skip its own reduction pass (i2t_grad_normalize presummed).
  * drop_* (bwd): optional elementwise dropout (rule of i2t_gemm_bf16, idx = row*d + col, drop_thr 0 = off) applied to the
  * bf16 copy dx_bf16 only -- the copy feeds the backward of a dropped-out branch, the f32 dx is the residual gradient. */
@@ -166,8 +168,10 @@ int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const 
 int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16,
                        unsigned drop_key, unsigned drop_thr, float drop_scale,      /* dropout on the bf16 copy, as i2t_layernorm_bwd */
                        int presummed, float* clear_after);
-/* presummed != 0: *ws already holds sum(g^2) (accumulated by the producer through i2t_layernorm_bwd's sumsq_out) and the
- * reduction pass is skipped; clear_after (nullable): a float zeroed after the call, i.e. the accumulator of the next producer. */
+/* presummed bit 0: *ws already holds sum(g^2) (accumulated by the producer through i2t_layernorm_bwd's sumsq_out) and the
+ * reduction pass is skipped; bit 1 (2): g itself is left as it is and only the normalised bf16 copy is written -- the first
+ * i2t_layernorm_bwd that accumulates onto g applies the factor (its dx_pre_sumsq = ws), 6 instead of 10 bytes per element;
+ * clear_after (nullable): a float zeroed after the call, i.e. the accumulator of the next producer. */
 
 /* ---------------------------------------------------------------------------------------------------------
  * ConvMLP feature extractor (layers.py:258-282): Conv2d(k x k, padding='same', k even => pad (k-1)/2 before,

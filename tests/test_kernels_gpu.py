@@ -457,6 +457,20 @@ def test_grad_normalize(ops):
     ops.grad_normalize(dx, ws2[0:1], None, presummed=True, clear_after=ws2[1:2])
     check('grad_normalize presummed', dx, ref2, 1e-7, 1e-4)
     assert float(ws2[1]) == 0.0
+    # deferred form: the fp32 tensor is left as it is, only the normalised bf16 copy is written; the next LayerNorm backward
+    # that accumulates onto it applies the factor -> same result as normalise-then-accumulate
+    g = rnd(M, d, seed=34) * 2
+    g0 = g.clone()
+    ws3 = torch.zeros(1, device=dev())
+    gb = torch.empty(M, d, dtype=BF16, device=dev())
+    ops.grad_normalize(g, ws3, gb, keep_f32=True)
+    assert torch.equal(g, g0)
+    inv = 1.0 / (torch.linalg.vector_norm(g0.double()).float() + 1e-6)
+    check('grad_normalize keep_f32 bf16 copy', gb, g0 * inv, 1e-7, 1 / 128)
+    want = g0 * inv
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, want, None, None, M, d, dx_accumulate=True)          # reference: already scaled
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, g, None, None, M, d, dx_accumulate=True, dx_pre_sumsq=ws3)
+    check('ln_bwd dx_pre_sumsq', g, want, 1e-6, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------------------ conv stack
