@@ -378,7 +378,8 @@ class HotPath:
         dao = self._empty(B, ncls, d, dtype=BF16)
         self._linear_bwd(dxb, Mc, d, d, sv.ao.view(Mc, d), f'{pfx}.attn.c_proj.weight', bias(f'{pfx}.attn.c_proj.bias'),
                          dx_out=dao.view(Mc, d))
-        dqkv = torch.zeros(B, T, 3 * d, dtype=BF16, device=a.device)            # dq of the patch rows stays zero
+        dqkv = self._empty(B, T, 3 * d, dtype=BF16)
+        dqkv[:, ncls:, :d].zero_()                                              # dq of the patch rows: zero (no query ran there); the rest is written below
         q3 = sv.qkv.view(B, T, 3 * d)
         ops.attention_bwd(q3[:, :ncls, :d], q3[..., d:2 * d], q3[..., 2 * d:], sv.ao, dao, sv.lse, self._empty(H * Mc),
                           dqkv[:, :ncls, :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, ncls, T, False, drop=dr['sdpa'])
