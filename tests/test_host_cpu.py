@@ -134,3 +134,31 @@ def test_dropin_aliases():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_dropout_rule_statistics():
+    """The counter-based dropout rule (rng.py = csrc/common.h): drop rate = thr16 / 65536 within sampling error, the two
+    decisions drawn from one hash are uncorrelated, so are neighbouring hashes and the masks of different sites, and the
+    scale makes the mask mean-preserving."""
+    import math
+    from image2text_amd import rng
+    n = 1 << 20
+    for p in (0.1, 0.05, 0.5):
+        thr = rng.threshold(p)
+        p_eff = thr / 65536.0
+        assert abs(p_eff - p) < 1e-5
+        k0, k1 = rng.site_key(12345, 7), rng.site_key(12345, 8)
+        m0, m1 = rng.keep_mask(k0, n, thr).double(), rng.keep_mask(k1, n, thr).double()
+        sigma = math.sqrt(p_eff * (1 - p_eff) / n)
+        assert abs((1 - m0.mean().item()) - p_eff) < 5 * sigma
+        assert abs(m0.mean().item() * rng.scale(thr) - 1.0) < 5 * sigma * rng.scale(thr)
+        d0, d1 = 1 - m0, 1 - m1
+
+        def corr(a, b):
+            return ((a * b).mean().item() - a.mean().item() * b.mean().item()) / (p_eff * (1 - p_eff))
+        lim = 5 / math.sqrt(n / 2)
+        assert abs(corr(d0[0::2], d0[1::2])) < lim          # low / high field of the same hash
+        assert abs(corr(d0[1:-1:2], d0[2::2])) < lim        # last decision of one hash / first of the next
+        assert abs(corr(d0[:-4], d0[4:])) < lim             # a row apart in a 4-wide layout
+        assert abs(corr(d0, d1)) < lim                      # two sites of the same step
+    assert rng.site_key(1, 2) != rng.site_key(2, 1) and rng.site_key(1 << 40, 3) != rng.site_key(0, 3)
