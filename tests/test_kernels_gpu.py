@@ -139,6 +139,21 @@ def test_gemm_large_tile_layouts(ops, M, N, K, a_km, b_km):
         assert torch.equal(again, out)
 
 
+def test_gemm_dw_reduction_longer_than_a_32bit_panel(ops):
+    """dW = dY^T . X whose k-major panel exceeds the 4 GiB a buffer descriptor can address ((K + 512) rows x ld x 2 bytes:
+    the tied lm_head at B = 2048 reads 74 k rows of 50 264 logits): the call runs as K chunks accumulating into C."""
+    M, N, K, lda = 512, 768, 43037, 50264                     # (K + 512) * lda * 2 = 4.38 GB
+    assert (K + 512) * lda * 2 > 2 ** 32
+    dy = torch.empty(K, lda, dtype=BF16, device=dev())        # only the first M columns take part
+    dy[:, :M] = rnd(K, M, dtype=BF16, seed=41, scale=0.05)
+    x = rnd(K, N, dtype=BF16, seed=42, scale=0.05)
+    c0 = rnd(M, N, seed=43)
+    out = c0.clone()
+    ops.gemm(dy, x, out, M, N, K, a_kmajor=True, b_kmajor=True, accumulate=True)
+    ref = c0 + dy[:, :M].float().t() @ x.float()
+    check('chunked dW', out, ref, 2e-3 * math.sqrt(K) / 8, 3e-3)
+
+
 @pytest.mark.parametrize('K', [1000, 1050, 50257])
 def test_gemm_large_tile_ragged_k_with_kmajor_b(ops, K, monkeypatch):
     """dX = dY . W with a reduction length that is no multiple of 64 (the lm_head's 50257): the large-tile kernel relies
