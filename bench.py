@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=2048, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=3072, help='images per GPU per step')
     ap.add_argument('--dropout', type=float, default=0.1, help='dropout = attn_dropout of both towers (nano.yaml: 0.1)')
     ap.add_argument('--decode-batch', type=int, default=4096, help='captions per GPU per greedy run')
     ap.add_argument('--decode-reps', type=int, default=3)
