@@ -151,6 +151,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 or os.environ.get('I2T_FORCE_DP') == '1':
+        from image2text_amd.training.dp import configure_rccl_env
+        configure_rccl_env()          # NCCL_MAX_NCHANNELS must be in the environment BEFORE the communicator is created
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -195,7 +198,8 @@ def main():
             torch.cuda.synchronize()
 
     if dp is not None:
-        wrapper.train_step(images[:1], labels[:1])[0].backward()     # builds the arena
+        with dp.no_sync():                                           # priming backward: builds the arena, exchanges nothing
+            wrapper.train_step(images[:1], labels[:1])[0].backward()
         opt.zero_grad()
         dp.broadcast_parameters()
     log(f'train: batch {args.batch}/gpu, {args.warmup} warm-up + {args.steps} timed steps')

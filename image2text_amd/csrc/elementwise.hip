@@ -283,6 +283,47 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// SNRAdam (reference models/optimizer.py:56-113): Adam whose second moment tracks the VARIANCE of the gradient around the
+// bias-corrected running mean of the previous step instead of its energy: d = g - m_prev / (1 - beta1^(t-1)) (t = 1: d = g),
+// v = beta2 v + (1 - beta2) d^2, step = lr * (m / (1 - beta1^t)) / (sqrt(v / (1 - beta2^t)) + eps); decoupled weight decay
+// applied first.  Same arena / segment-table / bf16-shadow contract as adamw_kernel.
+__global__ __launch_bounds__(256) void snradam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      bf16_t* __restrict__ pb, long n, const long* __restrict__ seg_end,
+                                                      const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
+                                                      int nseg, float beta1, float beta2, float eps, float inv_bc1_prev,
+                                                      float inv_bc1, float inv_bc2, float grad_scale) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e0 = i * 4;
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (seg_end[mid] > e0) hi = mid; else lo = mid + 1;
+        }
+        const float lr = seg_lr[lo], wd = seg_wd[lo];
+        if (lr == 0.f && wd == 0.f) continue;            // parameters outside every group: no state, no update (as the reference)
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gv[e] * grad_scale;
+            pv[e] *= (1.f - lr * wd);
+            const float dev = gr - mv[e] * inv_bc1_prev;
+            mv[e] = beta1 * mv[e] + (1.f - beta1) * gr;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * dev * dev;
+            pv[e] -= lr * (mv[e] * inv_bc1) / (sqrtf(vv[e] * inv_bc2) + eps);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (pb) {
+            u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+            reinterpret_cast<u32x2*>(pb)[i] = pk;
+        }
+    }
+}
+
 // in-place dropout of a [rows][cols] tensor: mode 1 elementwise (idx = r*cols + c), mode 2 per (row, third of cols)
 template <bool F32>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(void* __restrict__ x, long n4, int cols, int mode, unsigned key,
@@ -462,5 +503,19 @@ extern "C" int i2t_adamw_step(void* stream, float* p, const float* g, float* m, 
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                        n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bc1, bc2s, grad_scale);
     I2T_CHECK_LAUNCH("i2t_adamw_step");
+    return I2T_OK;
+}
+
+extern "C" int i2t_snradam_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+                                const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
+                                float beta2, float eps, int step, float grad_scale) {
+    I2T_REQUIRE(p && g && m && v && seg_end && seg_lr && seg_wd && nseg > 0 && n > 0 && step > 0, "i2t_snradam_step: bad args");
+    I2T_REQUIRE(n % 4 == 0 && ALIGNED16(p) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v), "i2t_snradam_step: arena must be 16-byte aligned, n %% 4 == 0");
+    const float inv_bc1_prev = step == 1 ? 1.f : 1.f / (1.f - powf(beta1, (float)(step - 1)));
+    const float inv_bc1 = 1.f / (1.f - powf(beta1, (float)step));
+    const float inv_bc2 = 1.f / (1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(snradam_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                       n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, inv_bc1_prev, inv_bc1, inv_bc2, grad_scale);
+    I2T_CHECK_LAUNCH("i2t_snradam_step");
     return I2T_OK;
 }

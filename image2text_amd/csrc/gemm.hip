@@ -1320,6 +1320,8 @@ extern "C" int i2t_gemm_reserve_cus(int n_reserved) {
     return I2T_OK;
 }
 
+extern "C" int i2t_gemm_reserved_cus(void) { return __atomic_load_n(&g_cu_reserve, __ATOMIC_RELAXED); }
+
 extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate) {
     I2T_REQUIRE(X && out && M > 0 && N > 0, "i2t_colsum_bf16: bad args");
     I2T_REQUIRE((ld & 7) == 0 && ALIGNED16(X), "i2t_colsum_bf16: X must be 16-byte aligned with ld %% 8 == 0");

@@ -183,6 +183,11 @@ class ConcurrentGreedyDecoder:
     def generate(self, image_batches, prompt_batches, max_new_tokens: int):
         assert len(image_batches) == len(prompt_batches) <= len(self.lanes)
         cur = torch.cuda.current_stream()
+        # shared state is brought up to date on the parent stream BEFORE fanning out: the bf16 weight shadow's re-cast (if a
+        # torch-side optimizer touched the parameters) must not land on one lane's stream while the other lanes read it; the
+        # lanes' own prepare() calls then find nothing to do.  Per-lane state (KV caches, graphs, the encoder's conv weight
+        # workspace -- keyed by stream in the engine) is private.
+        self.model._engine.prepare(False)
         outs = []
         for (dec, stream), images, prompt in zip(self.lanes, image_batches, prompt_batches):
             stream.wait_stream(cur)

@@ -27,6 +27,7 @@ Reference quirks reproduced on purpose (each pinned by a golden fixture):
     every block output, per replica.
 """
 import os
+import weakref
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -40,6 +41,11 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+def _dp_rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 class DropPlan:
@@ -70,10 +76,24 @@ class DropPlan:
         return e
 
 
+_ARENAS = weakref.WeakSet()
+
+
+def arena_of(param: torch.Tensor):
+    """The live ParamArena whose fp32 buffer ``param`` is a view of, or None (optimizers find their arena through this)."""
+    ptr = param.data_ptr()
+    for a in _ARENAS:
+        base = a.p32.data_ptr()
+        if base <= ptr < base + 4 * a.total and a.p32.device == param.device:
+            return a
+    return None
+
+
 class ParamArena:
     """Flat fp32 parameters + fp32 gradients + bf16 shadow; parameters of ``module`` become views into it."""
 
     def __init__(self, module: torch.nn.Module, device: torch.device):
+        _ARENAS.add(self)
         self.device = device
         self.entries: Dict[str, Tuple[int, int, torch.Size]] = {}
         self.params: Dict[str, torch.nn.Parameter] = {}
@@ -174,7 +194,7 @@ class HotPath:
                           for l in range(dcfg.n_layer)]
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
-        self.grad_ready_hooks = []      # callables(which: 'decoder' | 'encoder'), e.g. the data-parallel exchange
+        self.grad_ready_hooks = []      # callables(which: 'begin' | 'decoder' | 'encoder'), e.g. the data-parallel exchange
 
     def notify_grads_ready(self, which: str):
         for hook in self.grad_ready_hooks:
@@ -188,21 +208,38 @@ class HotPath:
         if self.arena is None or self.arena.device != dev or not self.arena.valid():
             self.arena = ParamArena(self.model, dev)
             self._ws = torch.zeros(4, dtype=F32, device=dev)
-            self._conv_ws = torch.empty(max(32 * 36 * 32, max(self.arena.entries[f'{n}.weight'][1] for n, _, _ in self.conv)),
-                                        dtype=F32, device=dev)
+            self._conv_ws_pool = {}
             self._conv_scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev)
             self._logits_cache.clear()
         self.arena.refresh_shadow()
         self.enc_drop = self.dec_drop = None
         if training:
-            # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run)
-            self._seed_state = (getattr(self, '_seed_state', torch.initial_seed()) * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+            # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run, and
+            # a later torch.manual_seed restarts the sequence) and from the data-parallel rank: replicas seeded identically
+            # must still draw different dropout masks on their different shards
+            base = torch.initial_seed()
+            if getattr(self, '_seed_base', None) != base:
+                self._seed_base = base
+                self._seed_state = (base ^ (0x9E3779B97F4A7C15 * _dp_rank())) & (2 ** 64 - 1)      # rank 0: torch's seed itself
+            self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
             if self.enc.dropout > 0 or self.enc.attn_dropout > 0:
                 self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout,
                                          compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
             if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
                 self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout)
         return self.arena
+
+    @property
+    def _conv_ws(self):
+        """Workspace the convolution launchers repack a layer's weights into (bf16 MFMA operand image) before the conv kernel
+        reads it.  One per HIP stream: concurrent decode lanes run their encoders on separate streams, and nothing orders one
+        lane's repack against another lane's conv kernel, so a shared buffer would be a cross-stream write/read race."""
+        key = torch.cuda.current_stream(self.arena.device).cuda_stream
+        ws = self._conv_ws_pool.get(key)
+        if ws is None:
+            n = max(32 * 36 * 32, max(self.arena.entries[f'{n}.weight'][1] for n, _, _ in self.conv))
+            ws = self._conv_ws_pool[key] = torch.empty(n, dtype=F32, device=self.arena.device)
+        return ws
 
     def _empty(self, *shape, dtype=F32):
         return torch.empty(*shape, dtype=dtype, device=self.arena.device)

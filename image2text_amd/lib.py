@@ -15,6 +15,7 @@ SIGNATURES = {
     'i2t_last_error': [C.c_char_p, C.c_size_t],
     'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I, I, U, U, F],
     'i2t_gemm_reserve_cus': [I],
+    'i2t_gemm_reserved_cus': [],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],
@@ -37,6 +38,7 @@ SIGNATURES = {
     'i2t_cast_f32_bf16': [P, P, P, L],
     'i2t_dropout_apply': [P, P, I, L, I, I, U, U, F],
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
+    'i2t_snradam_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_bcast_rows': [P, P, P, L, I, I, I],
     'i2t_sum_over_batch': [P, P, L, P, I, I, I, I],
     'i2t_copy_rows': [P, P, L, P, L, I, I, I, I],

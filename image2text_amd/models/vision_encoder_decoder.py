@@ -62,6 +62,7 @@ class _HotPathFunction(torch.autograd.Function):
         eng: HotPath = model._engine
         a = eng.arena
         B, T, ncls = ctx.shapes
+        eng.notify_grads_ready('begin')          # e.g. the DP exchange drains whatever is still in flight on the arena
         a.begin_backward()
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
         dl = None

@@ -59,6 +59,10 @@ def gemm_reserve_cus(n: int):
     _l.check(_lib().i2t_gemm_reserve_cus(int(n)), 'i2t_gemm_reserve_cus')
 
 
+def gemm_reserved_cus() -> int:
+    return int(_lib().i2t_gemm_reserved_cus())
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumulate=False):
     _need_cuda(x, out)
     _l.check(_lib().i2t_colsum_bf16(_stream(), _p(x), x.stride(0) if ld is None else ld, M, N, _p(out), int(accumulate)),
@@ -231,6 +235,13 @@ def adamw_step(p, g, m, v, p_bf16, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta
     _l.check(_lib().i2t_adamw_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(seg_end), _p(seg_lr), _p(seg_wd),
                                    nseg, float(beta1), float(beta2), float(eps), int(step), float(grad_scale)),
              'i2t_adamw_step')
+
+
+def snradam_step(p, g, m, v, p_bf16, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale=1.0):
+    _need_cuda(p, g, m, v)
+    _l.check(_lib().i2t_snradam_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(seg_end), _p(seg_lr), _p(seg_wd),
+                                     nseg, float(beta1), float(beta2), float(eps), int(step), float(grad_scale)),
+             'i2t_snradam_step')
 
 
 def bcast_rows(src, y, y_batch_stride, B, rows, d):

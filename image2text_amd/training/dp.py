@@ -10,7 +10,20 @@ DDP's 25 MB buckets: the decoder slice (80 % of the bytes) is reduced on RCCL's 
 has finished, overlapped with the whole encoder backward; the encoder slice follows.  xGMI is point-to-point, large
 messages keep every link busy; RCCL picks the rings/trees.  ``torch.distributed`` (backend "nccl" = RCCL) is the
 transport; on CPU the same code runs over gloo (tests).
+
+Protocol (what a training loop does; ``training/utils.train_loop`` and ``bench.py`` follow it):
+
+    with dp.no_sync():                 # micro-batches 1 .. k-1 of an accumulation window: nothing is exchanged
+        loss.backward()
+    loss.backward()                    # last micro-batch: the decoder slice's all-reduce starts inside this backward
+    dp.all_reduce_mean()               # finishes the exchange (encoder slice + wait); then optimizer.step()
+
+A backward that is neither inside ``no_sync`` nor followed by ``all_reduce_mean`` (e.g. a priming backward that only
+builds the arena) is tolerated: the next backward's start (engine hook 'begin'), ``broadcast_parameters`` and
+``all_reduce_mean`` all drain whatever is still in flight and reset the window, so an early reduce is never skipped
+because of stale state and never races the next backward's accumulation into the arena.
 """
+import contextlib
 import os
 from typing import Optional
 
@@ -24,20 +37,37 @@ import torch.distributed as dist
 RCCL_CUS = int(os.environ.get('I2T_RCCL_CUS', '16'))
 
 
+def configure_rccl_env():
+    """Call BEFORE ``dist.init_process_group``: RCCL reads NCCL_MAX_NCHANNELS when a communicator is created, and
+    ``init_process_group(device_id=...)`` creates it eagerly.  A value the user exported wins."""
+    if RCCL_CUS > 0:
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', str(RCCL_CUS))
+
+
 class DataParallelGrads:
     def __init__(self, model, group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group)
         self.overlap = overlap
-        self._pending = []
-        self._reduced_upto = None
+        self._pending = []              # (work, tensor view, needs division by world)
+        self._reduced_upto = None       # arena offset from which the current window's gradients are already in flight/reduced
         self._reserved = False
-        if dist.get_backend(group) == 'nccl' and RCCL_CUS > 0:
-            os.environ.setdefault('NCCL_MAX_NCHANNELS', str(RCCL_CUS))     # read when the communicator is created (first collective)
+        self._sync = True               # False inside no_sync(): accumulate locally, exchange nothing
+        if dist.get_backend(group) == 'nccl':
+            configure_rccl_env()        # too late for an eagerly created communicator (see configure_rccl_env), harmless otherwise
         eng = getattr(model, '_engine', None)
         if eng is not None and overlap:
             eng.grad_ready_hooks.append(self._on_grads_ready)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside this context only accumulate into the local arena (DDP.no_sync semantics)."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
 
     def _arena(self):
         arena = self.model._engine.arena if hasattr(self.model, '_engine') else self.model.arena
@@ -58,26 +88,8 @@ class DataParallelGrads:
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
 
-    def _on_grads_ready(self, which: str):
-        """Engine callback: 'decoder' fires before the encoder backward starts."""
-        if which == 'decoder' and self._reduced_upto is None:
-            arena = self._arena()
-            cut = self._split(arena)
-            if arena.g32.is_cuda and dist.get_backend(self.group) == 'nccl' and RCCL_CUS > 0:
-                from .. import ops
-                ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
-                self._reserved = True
-            work, need_div = self._reduce(arena.g32[cut:], async_op=True)
-            self._pending.append((work, arena.g32[cut:], need_div))
-            self._reduced_upto = cut
-
-    def all_reduce_mean(self):
-        """Finish the exchange: after this every rank holds mean-over-ranks gradients in its arena / p.grad."""
-        arena = self._arena()
-        hi = arena.total if self._reduced_upto is None else self._reduced_upto
-        if hi > 0:
-            work, need_div = self._reduce(arena.g32[:hi], async_op=True)
-            self._pending.append((work, arena.g32[:hi], need_div))
+    def _drain(self):
+        """Wait for every collective in flight, finish its mean, release the CU reservation, close the window."""
         for work, t, need_div in self._pending:
             work.wait()
             if need_div:
@@ -89,8 +101,39 @@ class DataParallelGrads:
             ops.gemm_reserve_cus(0)
             self._reserved = False
 
+    def _on_grads_ready(self, which: str):
+        """Engine callback.  'begin': a backward is about to write the gradient arena.  'decoder': the decoder's gradients
+        are final for this backward (fires before the encoder backward starts)."""
+        if which == 'begin':
+            self._drain()               # an exchange nobody finished must not race this backward's accumulation
+            return
+        if which != 'decoder' or not self._sync:
+            return
+        arena = self._arena()
+        cut = self._split(arena)
+        if cut >= arena.total:
+            return
+        if arena.g32.is_cuda and dist.get_backend(self.group) == 'nccl' and RCCL_CUS > 0:
+            from .. import ops
+            ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
+            self._reserved = True
+        work, need_div = self._reduce(arena.g32[cut:], async_op=True)
+        self._pending.append((work, arena.g32[cut:], need_div))
+        self._reduced_upto = cut
+
+    def all_reduce_mean(self):
+        """Finish the exchange: after this every rank holds mean-over-ranks gradients in its arena / p.grad."""
+        arena = self._arena()
+        hi = arena.total if self._reduced_upto is None else self._reduced_upto
+        if hi > 0:
+            work, need_div = self._reduce(arena.g32[:hi], async_op=True)
+            self._pending.append((work, arena.g32[:hi], need_div))
+        self._drain()
+
     def broadcast_parameters(self, src: int = 0):
-        """Initial parameter sync (what DDP does at wrap time)."""
+        """Initial parameter sync (what DDP does at wrap time).  Also closes any exchange window left open by a priming
+        backward (its gradients are the caller's to discard: zero_grad)."""
+        self._drain()
         arena = self._arena()
         dist.broadcast(arena.p32, src=src, group=self.group)
         arena._versions = None          # force a bf16 shadow refresh on the next forward

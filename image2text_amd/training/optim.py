@@ -1,63 +1,122 @@
-"""Fused AdamW over the flat parameter arena (one HIP launch per step; also refreshes the bf16 weight shadow).
+"""Fused optimizers over the flat parameter arena: ONE HIP launch per step, which also refreshes the bf16 weight shadow.
 
-Drop-in ``torch.optim.Optimizer`` with ``torch.optim.AdamW`` semantics (decoupled weight decay, bias correction).  The
-reference builds ``torch.optim.AdamW(param_groups)`` (trainer.py:145-172); that keeps working on the arena views (the
-engine re-casts the bf16 shadow when it sees parameter versions change) -- this class is the MI355X-native equivalent:
-per-group lr / weight-decay become a per-segment table read by the kernel.
+``FusedAdamW`` has ``torch.optim.AdamW`` semantics (decoupled weight decay, bias correction); ``SNRAdam`` (exported from
+``models/optimizer.py``, where the reference keeps it) has the reference's SNRAdam semantics.  The reference builds
+``optim_clazz(param_groups)`` (trainer.py:145-172); ``torch.optim.AdamW`` itself keeps working on the arena views (the
+engine re-casts the bf16 shadow when it sees parameter versions change) -- these classes are the MI355X-native
+equivalents: per-group lr / weight-decay become a per-segment table read by the kernel, moments live in two flat arenas.
+
+The arena is found through the parameters themselves (``engine.arena_of``): it exists once the model has run one
+forward on the GPU (``HotPath.prepare``), which is always the case by the first ``step()``.
 """
 import torch
 
 from .. import ops
+from ..engine import arena_of
 
 
-class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._model = model          # the VisionEncoderDecoder that owns the arena
+class _ArenaOptimizer(torch.optim.Optimizer):
+    _kernel = None                   # staticmethod: ops.adamw_step / ops.snradam_step
+
+    def __init__(self, params, defaults, model=None, grad_scale=1.0):
+        super().__init__(params, defaults)
+        self._model = model          # optional: the VisionEncoderDecoder that owns the arena (else found via the params)
         self._step = 0
         self._tables = None
+        self._arena = None
         self.grad_scale = grad_scale
         b = {tuple(g['betas']) for g in self.param_groups}
         e = {g['eps'] for g in self.param_groups}
         if len(b) != 1 or len(e) != 1:
-            raise ValueError('FusedAdamW needs the same betas/eps in every param group (lr / weight_decay may differ)')
+            raise NotImplementedError(f'{type(self).__name__} takes one (betas, eps) for all param groups (lr / weight_decay may '
+                                      'differ per group): the bias corrections are launch-wide scalars')
+
+    def _find_arena(self):
+        if self._model is not None:
+            arena = self._model._engine.arena
+        else:
+            arena = None
+            for g in self.param_groups:
+                for p in g['params']:
+                    arena = arena_of(p)
+                    break
+                if arena is not None or g['params']:
+                    break
+        if arena is None:
+            raise RuntimeError(f'{type(self).__name__}.step: the parameters are not views of a live parameter arena -- run one '
+                               'forward/backward of the VisionEncoderDecoder on the GPU first (there is no per-tensor CPU path)')
+        return arena
 
     def _build(self, arena):
         by_ptr = {}
         for g in self.param_groups:
             for p in g['params']:
-                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'])
-        ends, lrs, wds = [], [], []
+                if arena_of(p) is not arena:
+                    raise RuntimeError(f'{type(self).__name__}: a parameter of shape {tuple(p.shape)} lives outside the arena')
+                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p)
+        ends, lrs, wds, self._params = [], [], [], []
         items = sorted(arena.entries.items(), key=lambda kv: kv[1][0])
         for i, (name, (off, n, _)) in enumerate(items):
             end = items[i + 1][1][0] if i + 1 < len(items) else arena.total
-            lr, wd = by_ptr.get(arena.p32.data_ptr() + 4 * off, (0.0, 0.0))      # params outside every group stay frozen
+            lr, wd, p = by_ptr.get(arena.p32.data_ptr() + 4 * off, (0.0, 0.0, None))      # params outside every group stay frozen
             ends.append(end); lrs.append(lr); wds.append(wd)
+            if p is not None:
+                self._params.append((name, p))
         dev = arena.device
         self._tables = (torch.tensor(ends, dtype=torch.long, device=dev), torch.tensor(lrs, dtype=torch.float32, device=dev),
                         torch.tensor(wds, dtype=torch.float32, device=dev), len(ends),
-                        tuple(g['lr'] for g in self.param_groups))
-        self._m = torch.zeros_like(arena.p32)
-        self._v = torch.zeros_like(arena.p32)
+                        tuple((g['lr'], g['weight_decay']) for g in self.param_groups))
+        if self._arena is not arena:
+            self._m = torch.zeros_like(arena.p32)
+            self._v = torch.zeros_like(arena.p32)
         self._arena = arena
 
     @torch.no_grad()
     def step(self, closure=None):
-        arena = self._model._engine.arena
-        if arena is None:
-            raise RuntimeError('FusedAdamW.step before any forward/backward: the parameter arena does not exist yet')
-        if self._tables is None or self._arena is not arena or self._tables[4] != tuple(g['lr'] for g in self.param_groups):
-            m, v = getattr(self, '_m', None), getattr(self, '_v', None)
-            same = self._tables is not None and self._arena is arena
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        arena = self._find_arena()
+        if self._tables is None or self._arena is not arena or \
+                self._tables[4] != tuple((g['lr'], g['weight_decay']) for g in self.param_groups):      # lr schedulers edit the groups
             self._build(arena)
-            if same:
-                self._m, self._v = m, v
+        missing = [n for n, p in self._params if p.requires_grad and p.grad is None]
+        if missing:
+            raise RuntimeError(f'{type(self).__name__}.step: {len(missing)} parameters have no gradient (first: {missing[0]}); the '
+                               'fused step updates the whole arena at once')
         self._step += 1
         ends, lrs, wds, nseg, _ = self._tables
         g0 = self.param_groups[0]
-        ops.adamw_step(arena.p32, arena.g32, self._m, self._v, arena.pbf, arena.total, ends, lrs, wds, nseg,
-                       g0['betas'][0], g0['betas'][1], g0['eps'], self._step, self.grad_scale)
-        return None
+        type(self)._kernel(arena.p32, arena.g32, self._m, self._v, arena.pbf, arena.total, ends, lrs, wds, nseg,
+                           g0['betas'][0], g0['betas'][1], g0['eps'], self._step, self.grad_scale)
+        return loss
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=True)
+
+
+class FusedAdamW(_ArenaOptimizer):
+    _kernel = staticmethod(ops.adamw_step)
+
+    def __init__(self, params, model=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay), model=model, grad_scale=grad_scale)
+
+
+class SNRAdam(_ArenaOptimizer):
+    """Reference models/optimizer.py:6-113 (same constructor; ``trainer.py:169`` picks it with ``use_snr_optim``): the
+    denominator is the bias-corrected running standard deviation of the gradient around its running mean, so a parameter
+    whose gradient is consistent over time takes larger steps."""
+    _kernel = staticmethod(ops.snradam_step)
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), weight_decay: float = 0.0, eps: float = 1e-8):
+        if lr <= 0.0:
+            raise ValueError('Invalid learning rate: {}'.format(lr))
+        if eps < 0.0:
+            raise ValueError('Invalid epsilon value: {}'.format(eps))
+        for i in (0, 1):
+            if not 0.0 <= betas[i] < 1.0:
+                raise ValueError('Invalid beta parameter at index {}: {}'.format(i, betas[i]))
+        if weight_decay < 0:
+            raise ValueError('Invalid weight_decay value: {}'.format(weight_decay))
+        super().__init__(params, dict(lr=lr, betas=betas, weight_decay=weight_decay, eps=eps))

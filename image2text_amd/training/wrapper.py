@@ -53,6 +53,7 @@ class _LMLossFunction(torch.autograd.Function):
         wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls = ctx.pack
         eng: HotPath = wrapper.model._engine
         a = eng.arena
+        eng.notify_grads_ready('begin')          # e.g. the DP exchange drains whatever is still in flight on the arena
         a.begin_backward()
         gscale = g.reshape(1).to(F32).contiguous()              # stays on the device: no host sync
         ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, M, eng.dec.V)
@@ -142,7 +143,11 @@ class ModelTrainerWrapper(nn.Module):
         ids = torch.where(labels != self.ignore_index, labels, torch.full_like(labels, eos))
         bs, sl = ids.shape
         ids = torch.cat((torch.full((bs, 1), bos, dtype=torch.long, device=dev), ids), dim=1)[:, :sl].contiguous()
-        weights = self.get_weights(labels)
+        # the reference truncates the labels to the logits' length BEFORE weighting them (wrapper.py:122-133): the per-sequence
+        # normaliser only covers the positions that are kept
+        eng = self.model._engine
+        T = min(sl, eng.dec.block - (eng.enc.ncls if self.model.config.use_soft_prompting else 0))
+        weights = self.get_weights(labels[:, :T])
         save = torch.is_grad_enabled()
         loss = _LMLossFunction.apply(self.model._grad_hook(dev), self, images, ids, labels, weights, save)
         step = 'train' if is_train else 'val'

@@ -72,6 +72,8 @@ int i2t_gemm_bf16(void* stream,
  * data-parallel gradient exchange brackets its overlap window with it (training/dp.py).  Process-wide, takes effect at the
  * next launch. */
 int i2t_gemm_reserve_cus(int n_reserved);
+/* the reservation currently in force (>= 0); never fails */
+int i2t_gemm_reserved_cus(void);
 
 int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate);
 
@@ -221,6 +223,11 @@ int i2t_dropout_apply(void* stream, void* x, int is_f32, long rows, int cols, in
 int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                    const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                    float beta1, float beta2, float eps, int step, float grad_scale);
+/* SNRAdam (reference models/optimizer.py:56-113; trainer.py:169 `use_snr_optim`): Adam with the gradient's running VARIANCE
+ * in the denominator.  Same contract as i2t_adamw_step; segments with lr == 0 and wd == 0 are left untouched (no state). */
+int i2t_snradam_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+                     const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
+                     float beta1, float beta2, float eps, int step, float grad_scale);
 /* y[b][r][:] = src[r][:] for r < rows (broadcast a (rows,d) f32 block into a strided batch buffer) */
 int i2t_bcast_rows(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d);
 /* dst[r][:] (+)= sum_b x[b][r][:] */

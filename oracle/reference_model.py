@@ -386,3 +386,58 @@ def generate_greedy(sd: SD, cfg, images, prompt_ids, max_new_tokens: int, return
             margins.append(t2[:, 0] - t2[:, 1])
         ids = torch.cat((ids, last.argmax(dim=-1, keepdim=True)), dim=-1)
     return (ids, torch.stack(margins, dim=1)) if return_margins else ids
+
+
+# --------------------------------------------------------------------------------------------------------------
+# sampling modes of generate() (vision_encoder_decoder.py:150-180): the distribution the next token is drawn from
+# --------------------------------------------------------------------------------------------------------------
+def sampling_distribution(last_logits, ids, ngram_sizes, temperature=1.0, top_k=None, nucleus_p=None):
+    """``last_logits`` (B, V) of the final position, ``ids`` (B, t) everything decoded so far -> (B, V) probabilities in
+    vocabulary order, zero outside the kept set.  Order of operations as the reference: / temperature (:152), n-gram ban
+    (:153), top-k crop keeping ties at the k-th value (:155-157), softmax (:159), nucleus: sort descending, drop every
+    entry whose cumulative mass exceeds max(nucleus_p, largest probability), renormalise (:160-171)."""
+    logits = last_logits.clone().float() / temperature
+    logits = apply_ngram_ban(ids, logits, ngram_sizes)
+    if top_k is not None:
+        kth = torch.topk(logits, min(top_k, logits.size(-1)), dim=-1).values[:, -1:]
+        logits[logits < kth] = NEG_INF
+    probs = logits.softmax(dim=-1)
+    if nucleus_p is None:
+        return probs
+    sp, si = torch.sort(probs, descending=True, dim=-1)
+    cum = torch.cumsum(sp, dim=-1)
+    thr = torch.maximum(torch.full_like(sp[:, 0], nucleus_p), sp[:, 0]).unsqueeze(1)
+    sp = sp.masked_fill(cum > thr, 0.0)
+    sp = sp / sp.sum(dim=-1, keepdim=True)
+    return torch.zeros_like(probs).scatter_(1, si, sp)
+
+
+def inverse_cdf_token(dist, u):
+    """The HIP sampler's draw rule (not the reference's Philox multinomial, which cannot be matched): walk the kept
+    distribution in vocabulary order and take the first token whose cumulative mass reaches u * total (u in [0, 1))."""
+    cdf = torch.cumsum(dist.double(), dim=-1)
+    target = (u.double() * cdf[:, -1]).unsqueeze(1)
+    tok = (cdf <= target).sum(dim=-1)
+    kept = dist > 0
+    last_kept = (kept * torch.arange(1, dist.size(1) + 1)).amax(dim=1) - 1
+    return torch.minimum(tok, last_kept)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# SNRAdam (models/optimizer.py:56-113)
+# --------------------------------------------------------------------------------------------------------------
+def snradam_step(param, grad, state, lr, betas, weight_decay, eps):
+    """One step on one tensor, in place; ``state`` = {} before the first step.  Decoupled decay first (:86-87); the
+    second moment tracks (g - bias-corrected previous mean)^2 (:98-108); update m_hat / (sqrt(v_hat) + eps) (:110-111)."""
+    b1, b2 = betas
+    if weight_decay != 0:
+        param.mul_(1 - lr * weight_decay)
+    if not state:
+        state.update(t=1, m=torch.zeros_like(param), v=torch.zeros_like(param))
+    t, m, v = state['t'], state['m'], state['v']
+    dev = grad - (m if t == 1 else m / (1 - b1 ** (t - 1)))
+    m.mul_(b1).add_(grad, alpha=1 - b1)
+    v.mul_(b2).add_(dev * dev, alpha=1 - b2)
+    param.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + eps, value=-lr)
+    state['t'] = t + 1
+    return param

@@ -86,3 +86,80 @@ def test_world2_mean_of_per_shard_gradients(tmp_path):
     name = 'decoder.transformer.h.0.mlp.c_fc.weight'
     off, n, shape = r[0]['entries'][name]
     assert not torch.allclose(r[0]['g'][off:off + n].view(shape), full[name], rtol=1e-3, atol=1e-7)
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    """The engine-hooked exchange (overlap=True) through the event sequence a real training loop produces: a priming backward
+    that nobody finishes (bench.py builds the arena that way), broadcast, then an accumulation window of two micro-batches --
+    the first under no_sync(), the second starting the decoder slice's all-reduce from the 'decoder' hook."""
+    from types import SimpleNamespace
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from image2text_amd.engine import ParamArena
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.training.dp import DataParallelGrads
+    from conftest import load_golden
+    cfg = tiny_config()
+    model = VisionEncoderDecoder(cfg)
+    det_init_(model, seed=rank)
+    arena = ParamArena(model, torch.device('cpu'))
+    eng = SimpleNamespace(arena=arena, grad_ready_hooks=[])
+    holder = SimpleNamespace(_engine=eng)
+    dp = DataParallelGrads(holder, overlap=True)
+    assert len(eng.grad_ready_hooks) == 1
+    notify = lambda which: [h(which) for h in eng.grad_ready_hooks]
+
+    def backward(grads):                             # what _LMLossFunction.backward does to the arena, with oracle gradients
+        notify('begin')
+        for name, gr in grads.items():
+            arena.G(name).add_(gr)
+        notify('decoder')
+        notify('encoder')
+
+    g = load_golden('tiny_train_init.npz')
+    images, labels = torch.from_numpy(g['images']), torch.from_numpy(g['labels'])
+    # priming backward with garbage gradients, never followed by all_reduce_mean
+    backward({name: torch.full(shape, float(rank + 1)) for name, (_, _, shape) in arena.entries.items()})
+    arena.g32.zero_()                                # optimizer.zero_grad()
+    dp.broadcast_parameters(0)
+    assert dp._reduced_upto is None and not dp._pending
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # accumulation window: this rank's micro-batches are samples [2r] and [2r+1]
+    micro = [_shard_grads(cfg, sd0, images[2 * rank + i:2 * rank + i + 1], labels[2 * rank + i:2 * rank + i + 1]) for i in range(2)]
+    with dp.no_sync():
+        backward(micro[0])
+    assert not dp._pending, 'no_sync must not start an exchange'
+    backward(micro[1])
+    assert dp._reduced_upto is not None, "the 'decoder' hook must have started the decoder slice"
+    dp.all_reduce_mean()
+    first = arena.g32.clone()
+    # a second window right after (state fully reset): same inputs -> same result
+    arena.g32.zero_()
+    with dp.no_sync():
+        backward(micro[0])
+    backward(micro[1])
+    dp.all_reduce_mean()
+    assert torch.equal(first, arena.g32)
+    # un-annotated accumulation (no no_sync): wasteful, still the same mean (all-reduce is linear)
+    arena.g32.zero_()
+    backward(micro[0])
+    backward(micro[1])
+    dp.all_reduce_mean()
+    assert torch.allclose(first, arena.g32, rtol=1e-4, atol=1e-6 * float(first.abs().max()))      # other summation order
+    torch.save({'p': arena.p32.clone(), 'g': first, 'entries': arena.entries,
+                'local': {k: micro[0][k] + micro[1][k] for k in micro[0]}}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_overlap_priming_and_accumulation(tmp_path):
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'r{i}.pt', weights_only=False) for i in range(world)]
+    assert torch.equal(r[0]['p'], r[1]['p'])
+    assert torch.equal(r[0]['g'], r[1]['g']), 'every rank must hold the same reduced gradients (decoder AND encoder slices)'
+    for name, (off, n, shape) in r[0]['entries'].items():
+        want = (r[0]['local'][name] + r[1]['local'][name]) / 2      # mean over ranks of each rank's accumulated window
+        got = r[0]['g'][off:off + n].view(shape)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-8), name

@@ -1,0 +1,26 @@
+"""The data-parallel exchange on the GPU box: a fresh 1-rank torch.distributed.run child over RCCL (tools/dp_selfcheck.py).
+One GPU per box here, so this covers the engine hook -> early decoder all-reduce -> CU reservation -> finish path, not scaling."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_hooked_exchange_matches_unhooked():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('NCCL_MAX_NCHANNELS', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_selfcheck.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=540)
+    out = r.stdout.decode(errors='replace')
+    assert r.returncode == 0 and 'DP_SELFCHECK_OK' in out, out[-4000:]
+    assert 'nchannels=16' in out or os.environ.get('I2T_RCCL_CUS'), out[-500:]

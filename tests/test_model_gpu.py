@@ -348,6 +348,40 @@ def test_greedy_with_sliced_encoder_pass(tiny_model, tiny_decode, monkeypatch):
     assert torch.equal(m0, m1)
 
 
+def test_concurrent_decoder_equals_sequential():
+    """ConcurrentGreedyDecoder (one stream + one graph per lane, one shared HotPath) must emit exactly the tokens the
+    sequential decoder emits for the same batches: the lanes share the weights (read-only) and nothing else -- in particular
+    not the encoder's conv weight workspace, which each lane's conv launcher rewrites per layer (a cross-stream race when it
+    was engine-wide).  nano-224 at a batch big enough that the lanes really overlap on the chip; repeated to catch a race."""
+    from image2text_amd.decoding import ConcurrentGreedyDecoder, GreedyDecoder
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    cfg = nano224_config()
+    V = cfg.decoder_config.vocab_size
+    m = det_init_(VisionEncoderDecoder(cfg), seed=0).to(dev()).eval()
+    lanes, B, N = 3, 96, 12
+    imgs = [synthetic_batch(B, 224, 64, V, seed=40 + i)[0].to(dev()) for i in range(lanes)]
+    prompts = [torch.full((B, 1), V - 1, dtype=torch.long, device=dev()) for _ in range(lanes)]
+    seq = GreedyDecoder(m)
+    want = [seq.generate(imgs[i], prompts[i], N).clone() for i in range(lanes)]
+    assert not torch.equal(want[0], want[1])                   # different images -> different captions
+    con = ConcurrentGreedyDecoder(m, lanes)
+    for rep in range(4):
+        got = con.generate(imgs, prompts, N)
+        torch.cuda.synchronize()
+        for i in range(lanes):
+            assert torch.equal(got[i], want[i]), f'rep {rep} lane {i}: {(got[i] != want[i]).sum().item()} tokens differ'
+    # the weights change under the decoders (an optimizer step on the torch side): the shadow refresh happens once, on the
+    # parent stream, and every lane sees the new weights
+    with torch.no_grad():
+        m.decoder.transformer.wte.weight.mul_(1.5)
+    want2 = [seq.generate(imgs[i], prompts[i], N).clone() for i in range(lanes)]
+    with torch.no_grad():
+        m.decoder.transformer.wte.weight.add_(0.0)                          # version bump only: forces a shadow re-cast
+    got2 = con.generate(imgs, prompts, N)
+    for i in range(lanes):
+        assert torch.equal(got2[i], want2[i])
+
+
 def test_sampling_modes_shapes(tiny_model, tiny_decode):
     """The reference unit test's contract (models/vision_encoder_decoder_test.py:88-92): shapes of sampled ids."""
     d = tiny_decode

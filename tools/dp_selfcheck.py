@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""One-GPU rehearsal of the data-parallel exchange over a REAL 1-rank RCCL group (run under torch.distributed.run).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P tools/dp_selfcheck.py
+
+Checks, on the engine-hooked path (overlap=True) against the un-hooked one (overlap=False):
+  * the gradients after all_reduce_mean agree (a 1-rank mean is the identity; the dW GEMMs reduce their K slices with fp32
+    atomics, so two backward passes of the same step differ in the last bits whatever the exchange does: the bound is the
+    one two identical un-hooked steps meet, not bit-equality);
+  * the CU reservation is in force while the decoder slice is in flight and restored afterwards;
+  * a priming backward that nobody finishes and a no_sync() accumulation window leave the exchange state clean.
+Prints DP_SELFCHECK_OK on success; any failure raises.  Started as a fresh child process by tests/test_dp_gpu.py (a process
+that has initialised the GPU must never re-exec).
+"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from image2text_amd.training.dp import RCCL_CUS, DataParallelGrads, configure_rccl_env
+    configure_rccl_env()
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', device_id=dev)
+    from image2text_amd import ops
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import det_init_, fake_tokenizer, nano224_config, synthetic_batch
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+
+    cfg = nano224_config(dropout=0.0)
+    V = cfg.decoder_config.vocab_size
+    wrapper = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100)
+    det_init_(wrapper.model, seed=3, style='reference')
+    wrapper = wrapper.to(dev).train()
+    images, labels = synthetic_batch(16, 224, 64, V, seed=5)
+    images, labels = images.to(dev), labels.to(dev)
+    model = wrapper.model
+    eng = model._engine
+
+    def zero():
+        for p in model.parameters():
+            p.grad = None
+
+    def grads():
+        return eng.arena.g32.clone()
+
+    # un-hooked reference: two identical steps give the atomic-order noise floor
+    dp0 = DataParallelGrads(model, overlap=False)
+    with dp0.no_sync():
+        wrapper.train_step(images[:1], labels[:1])[0].backward()          # priming: builds the arena
+    zero()
+    dp0.broadcast_parameters()
+    ref = []
+    for _ in range(2):
+        wrapper.train_step(images, labels)[0].backward()
+        dp0.all_reduce_mean()
+        ref.append(grads())
+        zero()
+    scale = float(ref[0].abs().max())
+    floor = float((ref[0] - ref[1]).abs().max()) / scale
+
+    # hooked path: the decoder slice is launched from inside backward
+    dp1 = DataParallelGrads(model, overlap=True)
+    seen = []
+    eng.grad_ready_hooks.append(lambda which: seen.append((which, ops.gemm_reserved_cus(), dp1._reduced_upto)))
+    wrapper.train_step(images[:1], labels[:1])[0].backward()              # priming backward, never finished ...
+    zero()
+    dp1.broadcast_parameters()                                            # ... must be drained here
+    assert ops.gemm_reserved_cus() == 0 and dp1._reduced_upto is None and not dp1._pending
+    seen.clear()
+    wrapper.train_step(images, labels)[0].backward()
+    at_encoder = [s for s in seen if s[0] == 'encoder']
+    assert at_encoder and at_encoder[0][1] == RCCL_CUS and at_encoder[0][2] is not None, seen
+    dp1.all_reduce_mean()
+    assert ops.gemm_reserved_cus() == 0, 'CU reservation not restored'
+    got = grads()
+    zero()
+    err = float((got - ref[0]).abs().max()) / scale
+    assert err <= max(4 * floor, 1e-5), f'hooked vs un-hooked gradients: {err:.3e} (noise floor {floor:.3e})'
+
+    # accumulation window: micro-batch 1 under no_sync, micro-batch 2 exchanges; equals the un-hooked accumulation
+    with dp1.no_sync():
+        wrapper.train_step(images[:8], labels[:8])[0].backward()
+    assert not dp1._pending and ops.gemm_reserved_cus() == 0
+    wrapper.train_step(images[8:], labels[8:])[0].backward()
+    dp1.all_reduce_mean()
+    acc1 = grads()
+    zero()
+    eng.grad_ready_hooks.clear()
+    wrapper.train_step(images[:8], labels[:8])[0].backward()
+    wrapper.train_step(images[8:], labels[8:])[0].backward()
+    acc0 = grads()
+    err2 = float((acc1 - acc0).abs().max()) / float(acc0.abs().max())
+    assert err2 <= max(4 * floor, 1e-5), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
+    torch.cuda.synchronize()
+    print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
