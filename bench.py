@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_IMAGE = 32.6
 TRAIN_GFLOP_PER_IMAGE = 3 * FWD_GFLOP_PER_IMAGE
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s (spec)
 
 
 def parse():
@@ -130,15 +131,53 @@ def cpu_baseline(batch=8, steps=6, dropout=0.1):
         opt.zero_grad()
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / steps
-    log('cpu_baseline: oracle greedy decode')
+    log('cpu_baseline: oracle greedy decode (4 captions x 64 new tokens)')
     t0 = time.perf_counter()
     with torch.no_grad():
-        orc.generate_greedy({k: v.detach() for k, v in sd.items()}, cfg, images[:4], torch.full((4, 1), tok.bos_token_id), 8)
+        orc.generate_greedy({k: v.detach() for k, v in sd.items()}, cfg, images[:4], torch.full((4, 1), tok.bos_token_id), 64)
     dec = time.perf_counter() - t0
     return dict(value=batch / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'oracle fp32 train step (fwd+bwd+AdamW), nano-224, dropout {dropout}, batch {batch}, 1 warm-up + {steps} timed steps',
-                greedy_captions_per_sec_8tok=4 / dec,
-                greedy_sample='4 captions x 8 new tokens, cache-free loop as the reference runs it (cost grows O(t^2))')
+                greedy_captions_per_sec=4 / dec,
+                greedy_sample='4 captions x 64 new tokens (the benchmark\'s decode workload), cache-free loop as the reference runs it '
+                              '(full re-forward per token), 1 timed run')
+
+
+class DecodeAttnTimer:
+    """HIP events around every i2t_decode_attention launch of ONE eager (graph-free) greedy run on the launch stream, with the
+    algorithmic bytes of each launch: the new query and output rows plus every cached K and V row it reads (the self-attention
+    cache grows by one key per step; the cross-attention K/V of the 64 memory tokens are read in full every step)."""
+
+    def __init__(self, ops, n_layers, n_cross):
+        self.ops, self.orig, self.records = ops, ops.decode_attention, []
+        self.self_calls, self.n_layers = 0, n_layers
+
+    def __enter__(self):
+        def timed(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0):
+            if pos is not None:                   # self-attention: keys 0 .. step (the step's own key was just appended)
+                keys = self.self_calls // self.n_layers + 1
+                self.self_calls += 1
+            else:
+                keys = n_keys_fixed
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = self.orig(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm)
+            e1.record(torch.cuda.current_stream())
+            self.records.append((e0, e1, B * H * 64 * 2 * (2 * keys + 2)))
+            return r
+        self.ops.decode_attention = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.decode_attention = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        by = sum(r[2] for r in self.records)
+        n = max(1, len(self.records))
+        return dict(launches=len(self.records), total_ms=ms, avg_us=1e3 * ms / n, gbps=by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    bytes_per_launch=by / n)
 
 
 def main():
@@ -246,7 +285,7 @@ def main():
     fence()
 
     # ---- greedy decode: B captions x 64 new tokens per run (encoder + KV-cache decode under hipGraph replay)
-    cap_s = None
+    cap_s = dec_attn = None
     if not args.no_decode:
         wrapper.eval()
         opt.zero_grad()
@@ -287,6 +326,12 @@ def main():
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             n_caps = float(c)
         cap_s = n_caps / dt
+        # ---- dominant decode kernel (decode_attention: K/V cache streaming, HBM-bound): one eager greedy run of lane 0
+        if not args.no_kernel_timing:
+            eng = wrapper.model._engine
+            with DecodeAttnTimer(ops, eng.dec.L, sum(eng.dec_cross)) as dt_:
+                cdec.lanes[0][0].generate(dimgs[0], prompts[0], 64, use_graph=False)
+            dec_attn = dt_.summary()
         wrapper.train()
 
     if rank == 0:
@@ -321,6 +366,13 @@ def main():
                                'algorithmic_bytes_per_launch': round(gemm['bytes_per_launch']), 'launches_per_step': gemm['launches'] // 2,
                                'avg_launch_us': round(gemm['avg_us'], 2), 'gflop_per_launch': round(gemm['gflop_per_launch'], 3),
                                'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
+        if dec_attn is not None:
+            out['decode_roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_kernel (every self- and cross-attention launch of one 64-token greedy run, eager)',
+                                      'achieved': round(dec_attn['gbps'], 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                      'frac': round(dec_attn['gbps'] / HBM_PEAK_GBPS, 4), 'traffic': None,
+                                      'algorithmic_bytes_per_launch': round(dec_attn['bytes_per_launch']),
+                                      'launches': dec_attn['launches'], 'avg_launch_us': round(dec_attn['avg_us'], 2),
+                                      'decode_attention_ms_per_run': round(dec_attn['total_ms'], 2), 'captions': Bd, 'new_tokens': 64}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dropout=args.dropout)
         print(json.dumps(out), file=json_out, flush=True)

@@ -5,7 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libi2t_hip.so')
-SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip']
+SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 # per-file additions.  attention: keep MFMA accumulators in VGPRs -- the softmax rescales them every key tile, and the
 # AGPR form cost ~110 v_accvgpr_read/write per tile in kernels that are VALU-bound
@@ -30,21 +30,24 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not _stale():
             return LIB
-        return _build(verbose)
+        return _build(verbose, force_all=force)
 
 
-def _build(verbose: bool) -> str:
+def _build(verbose: bool, force_all: bool = False) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, '..', '..', 'include', 'i2t.h'), os.path.abspath(__file__)]
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')
+        objs.append(obj)
+        if not force_all and os.path.exists(obj) and all(os.path.getmtime(d) < os.path.getmtime(obj) for d in [src] + headers):
+            continue                                      # this object is newer than its source and the shared headers
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

@@ -12,9 +12,16 @@ for the n-gram ban (``.tolist()``).  Here
     the end.
 Because text rows never attend to the soft-prompt columns (see engine.py) the cache holds text positions only; the
 prompt shifts the position embedding by n_cls.
+
+The sampling modes of ``generate`` (temperature / top-k / nucleus, reference :152-180; ``eval_model``'s call shape
+trainer.py:41-56) run on the same cached step: only its last kernel differs -- ``i2t_sample_token`` (csrc/sample.hip)
+instead of the ban + argmax -- so a sampled token also costs one hipGraph replay and no host sync.  The draw is a
+counter-based function of (seed, step, row): ``Sampling.seed`` comes from torch's CPU generator once per call, so
+``torch.manual_seed`` reproduces a run.
 """
 import os
 from types import SimpleNamespace
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -25,7 +32,20 @@ from .engine import BF16, F32, HotPath
 ENC_CHUNK = int(os.environ.get('I2T_DECODE_ENC_CHUNK', '4096'))      # images per encoder pass inside generate()
 
 
+class Sampling(NamedTuple):
+    """How the next token is chosen when it is not the argmax (arguments of the reference's generate, :136-137)."""
+    temperature: float = 1.0
+    top_k: Optional[int] = None
+    nucleus_p: Optional[float] = None
+    seed: Optional[int] = None          # 64-bit; None: drawn from torch's CPU generator at the start of the call
+
+    def key(self):
+        return (float(self.temperature), int(self.top_k or 0), None if self.nucleus_p is None else float(self.nucleus_p))
+
+
 class GreedyDecoder:
+    """KV-cache decoder; greedy by default, ``generate(..., sampling=Sampling(...))`` draws tokens on the device instead."""
+
     def __init__(self, model):
         self.model = model
         self.eng: HotPath = model._engine
@@ -60,7 +80,9 @@ class GreedyDecoder:
         S = ncls
         st.cross_kv = {l: (e(B, S, 2 * d), S) for l in self._cross_layers()}
         st.ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
-        st.graph_full = st.graph_prefill = None
+        st.graphs = {}                      # None -> prefill step, 'greedy' / Sampling.key() -> full step
+        st.seed = torch.zeros(2, dtype=torch.int32, device=dev)
+        st.dist = None                      # optional [B, V] f32: the distribution of the last sampled step (tests)
         return st
 
     def _cross_layers(self):
@@ -69,8 +91,9 @@ class GreedyDecoder:
                 if cfg.use_cross_attn and (self.eng.dec_cross[l] or not cfg.decoder_config.skip_alternate_cross_attn)]
 
     # ------------------------------------------------------------------------------------------------ one token
-    def _step(self, st, with_head: bool):
-        """Consume the token at ids[:, pos]; when with_head also choose ids[:, len]; then advance pos and len."""
+    def _step(self, st, with_head: bool, sampling: Optional[Sampling] = None):
+        """Consume the token at ids[:, pos]; when with_head also choose ids[:, len] (argmax after the n-gram ban, or a draw from
+        the filtered distribution when ``sampling`` is given); then advance pos and len."""
         eng, a, dc = self.eng, self.eng.arena, self.eng.dec
         B, d, ff, H = st.B, dc.d, dc.ff, dc.H
         pos_ptr, len_ptr = st.counters[0:1], st.counters[1:2]
@@ -97,16 +120,20 @@ class GreedyDecoder:
         if with_head:
             ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
             ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
-            ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
+            if sampling is None:
+                ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
+            else:
+                ops.sample_token(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V,
+                                 sampling.temperature, sampling.top_k, sampling.nucleus_p, st.seed, dist_out=st.dist)
         ops.advance(st.counters, 1)                            # pos and len together
 
-    def _capture(self, st, with_head: bool):
+    def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None):
         side = torch.cuda.Stream(device=st.arena.device)
         side.wait_stream(torch.cuda.current_stream())
         g = ops.Graph()
         with torch.cuda.stream(side):
             g.begin()
-            self._step(st, with_head)
+            self._step(st, with_head, sampling)
             g.end()
         torch.cuda.current_stream().wait_stream(side)
         return g
@@ -114,7 +141,9 @@ class GreedyDecoder:
     # ------------------------------------------------------------------------------------------------ public
     @torch.no_grad()
     def generate(self, images, prompt_ids: torch.Tensor, max_new_tokens: int, return_margins: bool = False,
-                 use_graph: bool = True):
+                 use_graph: bool = True, sampling: Optional[Sampling] = None, return_dists: bool = False):
+        """-> ids (B, P + max_new_tokens) [, margins (B, N) greedy only] [, dists (B, N, V) sampling only: the filtered,
+        renormalised distribution every token was drawn from]."""
         eng = self.eng
         a = eng.prepare(False)
         dc = eng.dec
@@ -124,6 +153,7 @@ class GreedyDecoder:
         if st is None or st.B != B or st.arena is not a or st.ids_ld < total:
             st = self._state = self._build(B, max(total, dc.block))
         assert total <= st.tmax, f'prompt + new tokens ({total}) exceed the text window ({st.tmax})'
+        assert not (return_margins and sampling is not None) and not (return_dists and sampling is None)
         # encoder + per-layer cross K/V (once per image)
         # (in slices of ENC_CHUNK images -- 4096: +1.4 % captions/s over 1024 -- every image is independent in the encoder, and its activations -- ~20 MB per
         # image in eval mode -- would otherwise set the memory footprint of a large caption batch)
@@ -145,27 +175,46 @@ class GreedyDecoder:
                 p = f'{eng.dp}transformer.h.{l}.cross_attn'
                 ops.gemm(mem, a.W(f'{p}.in_proj_weight')[dc.d:], kv.view(B * S, 2 * dc.d), B * S, 2 * dc.d, dc.d,
                          bias=a.P(f'{p}.in_proj_bias')[dc.d:])
-        st.ids.zero_()
-        st.ids[:, :P] = prompt_ids
-        st.counters.copy_(st.counters_init)                     # device-to-device: no host sync in the loop
-        margins = torch.zeros(max_new_tokens, B, dtype=F32, device=a.device) if return_margins else None
-        if use_graph and st.graph_full is None:
-            # warm up eagerly once (code objects must be loaded before capture), then capture both step kinds
-            self._step(st, True)
-            self._step(st, False)
-            st.graph_full = self._capture(st, True)
-            st.graph_prefill = self._capture(st, False)
+        if sampling is not None:
+            seed = sampling.seed if sampling.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+            st.seed.copy_(torch.tensor([lo - (1 << 32) if lo >= (1 << 31) else lo, hi - (1 << 32) if hi >= (1 << 31) else hi],
+                                       dtype=torch.int32))
+            if return_dists != (st.dist is not None):         # captured sampling steps bake the dist pointer (or its absence)
+                st.dist = torch.zeros(B, dc.V, dtype=F32, device=a.device) if return_dists else None
+                st.graphs = {k: g for k, g in st.graphs.items() if k in (None, 'greedy')}
+        full_key = 'greedy' if sampling is None else sampling.key()
+
+        def reset():
             st.ids.zero_()
             st.ids[:, :P] = prompt_ids
-            st.counters.copy_(st.counters_init)
+            st.counters.copy_(st.counters_init)                 # device-to-device: no host sync in the loop
+        reset()
+        margins = torch.zeros(max_new_tokens, B, dtype=F32, device=a.device) if return_margins else None
+        dists = torch.zeros(max_new_tokens, B, dc.V, dtype=F32, device=a.device) if return_dists else None
+        if use_graph and (full_key not in st.graphs or None not in st.graphs):
+            # warm up eagerly once (code objects must be loaded before capture), then capture the step kinds that are missing
+            self._step(st, True, sampling)
+            self._step(st, False)
+            if full_key not in st.graphs:
+                st.graphs[full_key] = self._capture(st, True, sampling)
+            if None not in st.graphs:
+                st.graphs[None] = self._capture(st, False)
+            reset()
         for _ in range(P - 1):                                  # prompt tokens before the last: fill the cache only
-            st.graph_prefill.launch() if use_graph else self._step(st, False)
+            st.graphs[None].launch() if use_graph else self._step(st, False)
         for i in range(max_new_tokens):
-            st.graph_full.launch() if use_graph else self._step(st, True)
+            st.graphs[full_key].launch() if use_graph else self._step(st, True, sampling)
             if return_margins:
                 margins[i].copy_(st.margin)
+            if return_dists:
+                dists[i].copy_(st.dist)
         out = st.ids[:, :total].clone()
-        return (out, margins.t().contiguous()) if return_margins else out
+        if return_margins:
+            return out, margins.t().contiguous()
+        if return_dists:
+            return out, dists.transpose(0, 1).contiguous()
+        return out
 
 
 class ConcurrentGreedyDecoder:

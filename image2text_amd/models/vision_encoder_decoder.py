@@ -172,39 +172,20 @@ class VisionEncoderDecoder(nn.Module):
 
     @torch.no_grad()
     def generate(self, images, prompt_ids, max_new_tokens=128, temperature=1.0, top_k=None, nucleus_p=None) -> torch.LongTensor:
-        """Autoregressive sampling (reference :136-182).  ``top_k=1, temperature=1.0, nucleus_p=None`` is greedy decoding
-        and takes the KV-cache + hipGraph path; other modes re-run ``forward`` per token like the reference."""
+        """Autoregressive generation (reference :136-182) on the static KV cache under hipGraph replay, one replay per token.
+        ``top_k=1`` without a nucleus is greedy decoding (argmax after the n-gram ban; the temperature cannot change an argmax);
+        every other mode draws each token on the device from the reference's filtered distribution (temperature -> n-gram
+        ban -> top-k -> softmax -> nucleus), see ``decoding.Sampling``.  The draws are reproducible under ``torch.manual_seed``."""
         blk_size = self.decoder.block_size - self.space_for_prompt
         assert max_new_tokens <= blk_size - prompt_ids.size(-1)
         dev = next(self.parameters()).device
         prompt_ids = prompt_ids.to(dev)
+        from ..decoding import GreedyDecoder, Sampling
+        if self._greedy is None:
+            object.__setattr__(self, '_greedy', GreedyDecoder(self))
         if top_k == 1 and nucleus_p is None:
-            from ..decoding import GreedyDecoder
-            if self._greedy is None:
-                object.__setattr__(self, '_greedy', GreedyDecoder(self))
             return self._greedy.generate(images, prompt_ids, max_new_tokens)
-        encoder_output, decoder_ids = None, prompt_ids
-        for _ in range(max_new_tokens):
-            cond = decoder_ids if decoder_ids.size(-1) <= blk_size else decoder_ids[..., -blk_size:].contiguous()
-            out = self(images=images, ids=cond, encoder_output=encoder_output)
-            encoder_output = out.encoder_output
-            logits = out.logits[..., -1, :] / temperature
-            logits = self.processor(decoder_ids, logits)
-            if top_k is not None:
-                v, _ = torch.topk(logits, min(top_k, logits.size(-1)), sorted=True, dim=-1)
-                logits[logits < v[..., [-1]]] = -float('inf')
-            probs = logits.softmax(dim=-1)
-            if nucleus_p is not None:
-                sp, si = torch.sort(probs, descending=True, dim=-1)
-                cum = torch.cumsum(sp, dim=-1)
-                thr = torch.maximum(nucleus_p * torch.ones_like(sp[:, 0]), sp[:, 0]).unsqueeze(1)
-                sp = sp.masked_fill(cum > thr, 0.0)
-                sp = sp / sp.sum(dim=-1, keepdim=True)
-                idx_next = si.gather(dim=-1, index=torch.multinomial(sp, num_samples=1))
-            else:
-                idx_next = torch.multinomial(probs, num_samples=1)
-            decoder_ids = torch.cat((decoder_ids, idx_next), dim=-1)
-        return decoder_ids
+        return self._greedy.generate(images, prompt_ids, max_new_tokens, sampling=Sampling(temperature, top_k, nucleus_p))
 
 
 def _owner_of(module):

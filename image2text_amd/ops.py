@@ -277,6 +277,15 @@ def ngram_ban_argmax(logits, ld, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, 
                                          _p(ngram_sizes), n_sizes, B, V, _p(margin_out)), 'i2t_ngram_ban_argmax')
 
 
+def sample_token(logits, ld, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, V, temperature, top_k, nucleus_p, seed, dist_out=None):
+    """One sampling step (include/i2t.h::i2t_sample_token); top_k None/0 = no crop, nucleus_p None = no cut."""
+    _need_cuda(logits, ids, seed)
+    assert logits.dtype == F32 and seed.dtype == torch.int32 and seed.numel() >= 2
+    _l.check(_lib().i2t_sample_token(_stream(), _p(logits), ld, _p(ids), ids_ld, _p(len_ptr), _p(ngram_sizes), n_sizes, B, V,
+                                     float(temperature), int(top_k or 0), float(-1.0 if nucleus_p is None else nucleus_p),
+                                     _p(seed), _p(dist_out), 0 if dist_out is None else dist_out.stride(0)), 'i2t_sample_token')
+
+
 def embed_step(ids, ids_ld, len_ptr, wte, wpe, x, B, d, pos_offset, vocab):
     _l.check(_lib().i2t_embed_step(_stream(), _p(ids), ids_ld, _p(len_ptr), _p(wte), _p(wpe), _p(x), B, d, pos_offset, vocab),
              'i2t_embed_step')

@@ -41,3 +41,11 @@ def keep_mask(key: int, n: int, thr: int, offset: int = 0) -> torch.Tensor:
     x ^= x >> 16
     bits = torch.where((idx & 1) == 1, x >> 16, x & 0xFFFF)
     return bits >= thr
+
+
+def sample_uniform(seed: int, step: int, row: int) -> float:
+    """Host replica of the sampler's uniform draw (csrc/sample.hip): u in [0, 1) with 24 bits, a pure function of the 64-bit
+    ``seed``, the position being written (``step`` = current length of the id row) and the caption's ``row`` in the batch."""
+    lo, hi = seed & M32, (seed >> 32) & M32
+    h = lowbias32((lowbias32(lo ^ ((row * 0x9E3779B9) & M32)) + hi + step * 0x85EBCA6B) & M32)
+    return (h >> 8) / 16777216.0

@@ -257,6 +257,16 @@ int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, int logits_is
                          int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V, float* margin_out);
 int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
                    const float* wpe, float* x, int B, int d, int pos_offset, int vocab);
+/* One sampling step of generate() for B captions (reference models/vision_encoder_decoder.py:150-180, the non-greedy modes; the
+ * call shape of trainer.py:41-56 eval_model is temperature 0.7 / nucleus 0.6): logits f32 [B][ld] of the last position ->
+ * / temperature -> no-repeat-n-gram ban over ids[b][0 .. len) -> top-k crop (top_k <= 0: none; ties at the k-th value stay) ->
+ * softmax -> nucleus cut (nucleus_p < 0: none; keeps the sorted prefix whose running sum <= max(nucleus_p, largest probability))
+ * -> renormalise -> draw -> ids[b][len] = token.  *len_ptr (device) is the current length; seed = 2 device words.  The draw is
+ * the inverse CDF in vocabulary order at u = uniform(seed, len, b) (image2text_amd/rng.py::sample_uniform is the host replica):
+ * reproducible per (seed, step, row).  dist_out (optional, f32 [B][dist_ld]) receives the kept, renormalised distribution. */
+int i2t_sample_token(void* stream, const float* logits, int ld, int64_t* ids, int ids_ld, const int* len_ptr,
+                     const int* ngram_sizes, int n_sizes, int B, int V, float temperature, int top_k, float nucleus_p,
+                     const unsigned* seed, float* dist_out, int dist_ld);
 int i2t_advance(void* stream, int* counters, int n, int delta);   /* counters[0..n) += delta */
 
 /* hipGraph capture around any sequence of the calls above (replaces the Python loop of

@@ -259,8 +259,21 @@ def test_nano224_full_size_forward_and_loss(nano224_golden, large_tiles, monkeyp
     assert not bad, bad[:8]
 
 
-def test_nano224_reference_init_logits_within_1e2():
-    """North-star tolerance ("logits within 1e-2 bf16") at the reference's own initial distributions."""
+def test_nano224_reference_init_logits_bf16_floor():
+    """North-star criterion "logits within 1e-2 bf16" at the reference's own initial distributions (6.4 M logits, |logit| <= 2.5).
+
+    What is asserted, strongest first:
+      * REGRESSION PIN near the measured values: max |err| <= 1.9e-2 (measured 1.5-1.7e-2 across boxes), rms <= 4e-3
+        (measured 3.4-3.6e-3), >= 98.5 % of the logits within 1e-2 absolute (measured 99.4 %);
+      * the literal allclose form |err| <= 1e-2 + 1e-2 |ref| may fail for at most 0.05 % of the logits (measured 0.01-0.02 %):
+        the max over millions of O(1) logits of a bf16-operand pipeline is NOT within 1e-2 -- see the attribution table in
+        DESIGN.md section 2 (tools/diag_precision.py): the error is spread over conv stack (0.41 % rel-rms), encoder blocks,
+        decoder blocks (0.39 %) and lm_head (0.24 %), adding in quadrature to 0.63 % of the logit rms = 1.7e-2 at the 5-sigma
+        tail; no single stage can be fixed to reach 1e-2 (a hi+lo split of the lm_head operand moves the max by 3 %);
+      * calibration: the REFERENCE ITSELF under bf16 autocast (how trainer.py runs precision 'bf16') deviates from its own fp32
+        run by max 2.09e-2 / rms 4.1e-3 / 98.5 % within 1e-2 on the same inputs (stored in the fixture): this path must be at
+        least that close.
+    """
     from conftest import load_golden
     g = load_golden('nano224_refinit.npz')
     cfg = nano224_config()
@@ -274,20 +287,20 @@ def test_nano224_reference_init_logits_within_1e2():
     with torch.no_grad():
         out = w.model(images=images.to(dev()), ids=ids.to(dev()))
         vloss, _ = w.val_step(images.to(dev()), labels.to(dev()))
-    maxerr('nano224_refinit.encoder_output', out.encoder_output, g['encoder_output'], 3e-2)
-    # bf16 criterion: allclose(atol=1e-2, rtol=1e-2) on every logit; additionally >= 98.5 % of the logits are within
-    # 1e-2 ABSOLUTE and the rms error is < 5e-3 (measured: max 1.5e-2 at |logit| <= 2.2, rms 3.6e-3)
+    maxerr('nano224_refinit.encoder_output', out.encoder_output, g['encoder_output'], 2.2e-2)      # measured 1.7e-2 of absmax 2.6
+    ref_max, ref_rms, ref_frac = (float(v) for v in g['reference_bf16_autocast_dev'])
     for key, sl in (('logits_head', slice(0, 256)), ('logits_tail', slice(-64, None))):
         got = out.logits[:, :, sl].float().cpu().numpy()
         err = np.abs(got - g[key])
-        REPORT[f'nano224_refinit.{key}'] = {'max_abs_err': float(err.max()), 'rms_err': float(np.sqrt((err ** 2).mean())),
-                                             'frac_within_1e-2': float((err <= 1e-2).mean()), 'ref_absmax': float(np.abs(g[key]).max())}
-        # calibration stored in the fixture: the REFERENCE ITSELF under bf16 autocast (how trainer.py runs precision
-        # 'bf16') deviates from its own fp32 run by max 2.09e-2 / rms 4.1e-3 / 98.5 % within 1e-2 on these inputs.
-        ref_max, ref_rms, ref_frac = (float(v) for v in g['reference_bf16_autocast_dev'])
-        assert err.max() <= max(1e-2, ref_max), f'{key}: max abs err {err.max():.4g} > reference bf16 deviation {ref_max:.4g}'
-        assert np.sqrt((err ** 2).mean()) <= max(2.5e-3, ref_rms), f'{key}: rms {np.sqrt((err ** 2).mean()):.4g}'
-        assert (err <= 1e-2).mean() >= min(0.985, ref_frac), f'{key}: only {(err <= 1e-2).mean():.4f} within 1e-2'
+        viol = float((err > 1e-2 + 1e-2 * np.abs(g[key])).mean())
+        rms = float(np.sqrt((err ** 2).mean()))
+        REPORT[f'nano224_refinit.{key}'] = {'max_abs_err': float(err.max()), 'rms_err': rms, 'frac_within_1e-2': float((err <= 1e-2).mean()),
+                                             'frac_violating_allclose_1e-2_1e-2': viol, 'ref_absmax': float(np.abs(g[key]).max())}
+        assert err.max() <= 1.9e-2, f'{key}: max abs err {err.max():.4g} (regression pin 1.9e-2)'
+        assert rms <= 4e-3, f'{key}: rms {rms:.4g} (regression pin 4e-3)'
+        assert (err <= 1e-2).mean() >= 0.985, f'{key}: only {(err <= 1e-2).mean():.4f} within 1e-2'
+        assert viol <= 5e-4, f'{key}: {viol:.2e} of the logits violate allclose(atol=1e-2, rtol=1e-2)'
+        assert err.max() <= ref_max and rms <= ref_rms and (err <= 1e-2).mean() >= ref_frac, 'worse than the reference under bf16 autocast'
     maxerr('nano224_refinit.logits_lse', torch.logsumexp(out.logits.float(), -1), g['logits_lse'], 1e-2)
     assert abs(float(vloss) - float(g['val_loss'])) <= 1e-3 * float(g['val_loss'])
 

@@ -233,3 +233,132 @@ def test_nano224_greedy_64_tokens_8_captions():
     assert checked >= 0.5 * g['margins'].size
     # how many of ALL 512 decisions agree when the run is never re-synchronised by more than the flips themselves
     assert r <= int((g['margins'] < eps).sum())
+
+
+# ------------------------------------------------------------------------------------------------ on-device sampling
+SAMPLING_MODES = {'t07_k5': dict(temperature=0.7, top_k=5), 't10_p05': dict(temperature=1.0, nucleus_p=0.5),
+                  't07_p06': dict(temperature=0.7, nucleus_p=0.6), 't13_k20_p09': dict(temperature=1.3, top_k=20, nucleus_p=0.9),
+                  't10_plain': dict(temperature=1.0), 't20_p095': dict(temperature=2.0, nucleus_p=0.95)}
+
+
+def _check_step_against_oracle(dec, model, ids_prefix, dist_dev, kw, tag):
+    """The kept, renormalised distribution the device sampled from vs the oracle's on THE DEVICE'S OWN fp32 logits of that step
+    (same logits -> same filter decisions; the oracle itself is pinned to the reference by tests/test_oracle_golden.py)."""
+    from oracle import reference_model as orc
+    cfg = model.config
+    V = cfg.decoder_config.vocab_size
+    logits = dec._state.logits[:, :V].float().cpu()
+    want = orc.sampling_distribution(logits, ids_prefix.cpu(), cfg.no_repeat_n_grams, **kw).numpy()
+    got = dist_dev.cpu().numpy()
+    diff = (got > 0) != (want > 0)
+    # an entry may sit within float noise of the nucleus cut (different summation order): at most one such entry per row
+    assert diff.sum(axis=1).max() <= 1, (tag, diff.sum(axis=1))
+    assert np.abs(got - want)[~diff].max() <= 1e-5 + 1e-3 * want.max(), (tag, float(np.abs(got - want)[~diff].max()))
+    return want
+
+
+@pytest.mark.parametrize('wtag', ['trained', 'init'])
+def test_sampling_filters_match_reference_goldens(wtag, tiny_weights):
+    """generate() sampling modes on the tiny model, teacher-forced on the reference's recorded ids (tests/golden/tiny_sampling.npz):
+    per step (a) device filter == oracle filter on the device's logits (kept set exact, probabilities 1e-3), (b) the drawn token
+    is the inverse-CDF token of (seed, step, row), (c) the device distribution is close to the REFERENCE's recorded one in total
+    variation (bf16 logits: not bit-equal)."""
+    from image2text_amd import rng
+    from image2text_amd.decoding import GreedyDecoder, Sampling
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from oracle import reference_model as orc
+    g = load_golden('tiny_sampling.npz')
+    cfg = tiny_config()
+    m = VisionEncoderDecoder(cfg)
+    if wtag == 'trained':
+        m.load_state_dict(tiny_weights)
+    else:
+        det_init_(m, seed=0)
+    m = m.to(dev()).eval()
+    images = torch.from_numpy(g['images']).to(dev())
+    dec = GreedyDecoder(m)
+    seed = 0x1234_5678_9ABC_DEF0
+    tv_max = 0.0
+    for tag, kw in SAMPLING_MODES.items():
+        ids, dist = torch.from_numpy(g[f'{wtag}.{tag}.ids']), g[f'{wtag}.{tag}.dist']
+        for s in range(0, dist.shape[1], 2):
+            prefix = ids[:, :1 + s].contiguous()
+            out, dd = dec.generate(images, prefix.to(dev()), 1, sampling=Sampling(seed=seed, **kw), return_dists=True, use_graph=(s % 4 == 0))
+            want = _check_step_against_oracle(dec, m, prefix, dd[:, 0], kw, (wtag, tag, s))
+            # (b) the draw: inverse CDF at u(seed, step = current length, row)
+            u = torch.tensor([rng.sample_uniform(seed, 1 + s, b) for b in range(ids.shape[0])])
+            tok = orc.inverse_cdf_token(dd[:, 0].cpu(), u)
+            cdf = torch.cumsum(dd[:, 0].cpu().double(), -1)
+            near = ((cdf - u.double().unsqueeze(1)).abs().min(dim=1).values < 1e-5)      # u within rounding of a CDF step
+            assert bool(((out[:, -1].cpu() == tok) | near).all()), (wtag, tag, s, out[:, -1].tolist(), tok.tolist())
+            assert bool((dd[:, 0].cpu().gather(1, out[:, -1:].cpu()) > 0).all()), 'token outside the kept set'
+            # (c) vs the reference's own distribution
+            tv_max = max(tv_max, float(0.5 * np.abs(dd[:, 0].cpu().numpy() - dist[:, s]).sum(axis=1).max()))
+    REPORT[f'sampling.tiny.{wtag}.max_total_variation_vs_reference'] = tv_max
+    assert tv_max <= (0.25 if wtag == 'trained' else 0.05), tv_max      # trained: |logit| <= 27 in bf16 moves a near-tie pair's mass
+
+
+def test_sampling_nano224_full_vocabulary_and_statistics():
+    """Full-size vocabulary (50257 = 100 register-resident values per lane): filters against the oracle on the device's logits
+    for four modes; then the draw is checked statistically -- 4096 copies of one caption differ only in their row index, i.e.
+    in their uniform, so their tokens are i.i.d. draws from one distribution."""
+    from image2text_amd.decoding import GreedyDecoder, Sampling
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    cfg = nano224_config()
+    V = cfg.decoder_config.vocab_size
+    m = det_init_(VisionEncoderDecoder(cfg), seed=0).to(dev()).eval()
+    with torch.no_grad():                                     # sharper logits: a handful of tokens carry most of the mass
+        m.decoder.transformer.wte.weight.mul_(6.0)
+    images, _ = synthetic_batch(8, 224, 64, V, seed=2)
+    images = images.to(dev())
+    dec = GreedyDecoder(m)
+    prompt = torch.randint(0, V - 1, (8, 5), generator=torch.Generator().manual_seed(1))
+    prompt[:, 3] = prompt[:, 1]                                # a repeated token: the n-gram ban has something to do
+    for tag, kw in (('p06', dict(temperature=0.7, nucleus_p=0.6)), ('k50', dict(temperature=1.0, top_k=50)),
+                    ('k20p09', dict(temperature=1.3, top_k=20, nucleus_p=0.9)), ('plain', dict(temperature=1.0))):
+        out, dd = dec.generate(images, prompt.to(dev()), 1, sampling=Sampling(seed=7, **kw), return_dists=True, use_graph=False)
+        want = _check_step_against_oracle(dec, m, prompt, dd[:, 0], kw, tag)
+        REPORT[f'sampling.nano224.{tag}.kept'] = [int(x) for x in (want > 0).sum(axis=1)]
+    # statistics: one image, one prompt, 4096 rows
+    B = 4096
+    img1 = images[:1].expand(B, -1, -1, -1).contiguous()
+    p1 = prompt[:1].expand(B, -1).contiguous().to(dev())
+    big = GreedyDecoder(m)
+    out, dd = big.generate(img1, p1, 1, sampling=Sampling(temperature=1.0, top_k=8, seed=99), return_dists=True)
+    p = dd[0, 0].cpu().double()
+    assert float((dd[:, 0].cpu().double() - p).abs().max()) < 1e-6       # identical rows -> identical distributions
+    freq = torch.bincount(out[:, -1].cpu(), minlength=V).double() / B
+    kept = p > 0
+    assert int(kept.sum()) == 8 and float(freq[~kept].sum()) == 0.0
+    sigma = torch.sqrt(p * (1 - p) / B)
+    assert bool(((freq - p).abs()[kept] <= 4.5 * sigma[kept] + 1e-9).all()), (freq[kept], p[kept])
+
+
+def test_generate_sampling_api():
+    """VisionEncoderDecoder.generate in the reference's sampling call shapes (unit test models/vision_encoder_decoder_test.py:88-92,
+    eval_model trainer.py:41-56): shapes, prompt kept, reproducible under torch.manual_seed, different seeds differ, hipGraph
+    replay == eager steps, and the no-repeat-n-gram constraint holds on sampled captions too."""
+    from image2text_amd.decoding import GreedyDecoder, Sampling
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    m = det_init_(VisionEncoderDecoder(cfg), seed=0).to(dev()).eval()
+    images, _ = synthetic_batch(4, 32, 16, V, seed=3)
+    images = images.to(dev())
+    prompt = torch.full((4, 1), V - 1, dtype=torch.long)
+    torch.manual_seed(5)
+    a = m.generate(images, prompt, max_new_tokens=30, temperature=0.7, nucleus_p=0.6)
+    torch.manual_seed(5)
+    b = m.generate(images, prompt, max_new_tokens=30, temperature=0.7, nucleus_p=0.6)
+    c = m.generate(images, prompt, max_new_tokens=30, temperature=0.7, nucleus_p=0.6)
+    assert tuple(a.shape) == (4, 31) and torch.equal(a[:, :1].cpu(), prompt) and torch.equal(a, b) and not torch.equal(a, c)
+    for row in a.cpu().tolist():
+        for n in cfg.no_repeat_n_grams:
+            grams = [tuple(row[i:i + n]) for i in range(len(row) - n + 1)]
+            assert len(grams) == len(set(grams)), f'repeated {n}-gram in a sampled caption'
+    d = GreedyDecoder(m)
+    s = Sampling(temperature=1.1, top_k=12, nucleus_p=0.8, seed=1234)
+    assert torch.equal(d.generate(images, prompt.to(dev()), 20, sampling=s), d.generate(images, prompt.to(dev()), 20, sampling=s, use_graph=False))
+    # top_k = 1 is greedy whatever the temperature
+    assert torch.equal(m.generate(images, prompt, max_new_tokens=12, temperature=0.5, top_k=1),
+                       m.generate(images, prompt, max_new_tokens=12, temperature=1.0, top_k=1))
