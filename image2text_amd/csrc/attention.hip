@@ -142,8 +142,8 @@ __device__ __forceinline__ void attn_block_coords(int ntile, int H, int B, int& 
 
 // ================================================================================================== forward
 // All three kernels are VALU-bound (softmax + the dropout hash; ~4 VALU issue slots per MFMA slot), so the variants are
-// compile-time: DROP (probability dropout on) and EVEN (TkMax even: a lane's 4 consecutive keys are the fields of exactly
-// two hashes, no per-lane alignment case).  The dropout scale 1/(1-p) and the 1/sqrt(d) factor of dS are applied once to
+// compile-time: DROP (probability dropout on) and EVEN (TkMax % 4 == 0: a lane's 4 consecutive keys are the 4 bytes of exactly
+// one hash, no per-lane alignment case).  The dropout scale 1/(1-p) and the 1/sqrt(d) factor of dS are applied once to
 // the accumulators at the end instead of per probability.
 template <bool DROP, bool EVEN>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O,
@@ -519,26 +519,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_lds + qj * 16 + 4 * g);
             bool keep4[4] = {true, true, true, true};
             if constexpr (DROP) {
-                // This lane's 4 elements sit in 4 different query rows (one hash each).  With an even TkMax the lanes of
-                // keys (2c, 2c+1) read the two 16-bit fields of the SAME hash: the even lane hashes rows r = 0, 1, the
-                // odd lane rows 2, 3, and they swap (2 hashes + 2 lane exchanges instead of 4 hashes per lane).
+                // This lane's 4 elements sit in 4 different query rows (one hash word each).  With TkMax % 4 == 0 the four lanes
+                // of keys 4c .. 4c+3 (a lane quad: k0 is a multiple of 16) read the four BYTES of the same words: lane j of the
+                // quad hashes row j, the words are broadcast inside the quad (DPP quad_perm: a VALU move each) and every lane
+                // picks its own byte -- 1 hash + 4 moves instead of 4 hashes per lane.
                 const unsigned rb = ((unsigned)b * H + h) * TqMax;
                 if constexpr (EVEN) {
-                    const int odd = li & 1, ra_ = 2 * odd;
-                    unsigned mine[2], both[4];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int q = min(qt * 64 + qj * 16 + 4 * g + ra_ + e, Tq - 1);
-                        mine[e] = dropout_hash(drop_key, ((rb + q) * (unsigned)TkMax + (unsigned)key) >> 1);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const unsigned other = (unsigned)__shfl_xor((int)mine[e], 1, 64);
-                        both[e] = odd ? other : mine[e];            // rows 0, 1 (hashed by the even lane)
-                        both[2 + e] = odd ? mine[e] : other;        // rows 2, 3 (hashed by the odd lane)
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) keep4[r] = (odd ? (both[r] >> 16) : (both[r] & 0xffffu)) >= drop_thr;
+                    const int j = li & 3;
+                    const int qm = min(qt * 64 + qj * 16 + 4 * g + j, Tq - 1);
+                    const int mine = (int)dropout_hash(drop_key, ((rb + qm) * (unsigned)TkMax + (unsigned)key) >> 2);
+                    const unsigned sh = 8u * (unsigned)j;
+                    keep4[0] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;   // quad_perm [0,0,0,0]
+                    keep4[1] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;   // [1,1,1,1]
+                    keep4[2] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;   // [2,2,2,2]
+                    keep4[3] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xff, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;   // [3,3,3,3]
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -590,11 +584,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     }
 }
 
-// variant of a kernel template <bool DROP, bool EVEN> for this call (EVEN only matters with dropout)
+// variant of a kernel template <bool DROP, bool EVEN> for this call (EVEN = Tk % 4 == 0; only matters with dropout)
 #define ATTN_DISPATCH(KERNEL, drop_thr, Tk, ...)                                   \
     do {                                                                           \
         if (!(drop_thr)) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);   \
-        else if (((Tk) & 1) == 0) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); \
+        else if (((Tk) & 3) == 0) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__);               \
     } while (0)
 

@@ -67,39 +67,36 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {               // s + 
     return s + (x * s) * (1.0f - s) * (d0 + d1 * x2);
 }
 
-// ---- counter-based dropout: one lowbias32 hash of (site key, idx >> 1) yields two 16-bit uniforms; element idx of
-// site `key` is kept iff its field >= thr16 (thr16 = round(p * 65536), so the effective p is thr16 / 65536 and the host
-// scales by 65536 / (65536 - thr16)).  The same function is evaluated in forward and backward: no mask is ever stored.
-// Two decisions per hash because v_mul_lo_u32 is quarter rate -- per-element hashing cost more than a K = 512 MFMA loop.
-__device__ __forceinline__ unsigned dropout_hash(unsigned key, unsigned pair) {
-    unsigned x = pair ^ key;
+// ---- counter-based dropout: one lowbias32 hash of (site key, idx >> 2) yields FOUR 8-bit uniforms; element idx of site
+// `key` is kept iff byte (idx & 3) of the hash is >= thr8 (thr8 = round(p * 256), so the effective p is thr8 / 256 -- 0.1016
+// for p = 0.1 -- and the host scales by 256 / (256 - thr8): the mask stays mean-preserving at the rate actually realised).
+// The same function is evaluated in forward and backward: no mask is ever stored.  Four decisions per hash because
+// v_mul_lo_u32 is quarter rate: at two per hash the hash was ~half of the attention kernels' VALU time (they are VALU-bound)
+// and a per-element hash cost more than the MFMA loop of a K = 512 GEMM.  Single-multiply mixers were tried and fail the
+// lag-correlation screen by hundreds of sigma (tests/test_host_cpu.py::test_dropout_rule_statistics holds the screen).
+__device__ __forceinline__ unsigned dropout_hash(unsigned key, unsigned quad) {
+    unsigned x = quad ^ key;
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned idx, unsigned thr16) {
-    const unsigned h = dropout_hash(key, idx >> 1);
-    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;
+__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned idx, unsigned thr8) {
+    const unsigned h = dropout_hash(key, idx >> 2);
+    return ((h >> (8u * (idx & 3u))) & 0xffu) >= thr8;
 }
-// keep[r] for the 4 consecutive elements idx0 .. idx0 + 3 (2 hashes when idx0 is even, 3 otherwise)
-__device__ __forceinline__ void dropout_keep4(unsigned key, unsigned idx0, unsigned thr16, bool (&keep)[4]) {
-    const unsigned p0 = idx0 >> 1;
-    const unsigned h0 = dropout_hash(key, p0), h1 = dropout_hash(key, p0 + 1);
-    if (idx0 & 1u) {
-        const unsigned h2 = dropout_hash(key, p0 + 2);
-        keep[0] = (h0 >> 16) >= thr16; keep[1] = (h1 & 0xffffu) >= thr16;
-        keep[2] = (h1 >> 16) >= thr16; keep[3] = (h2 & 0xffffu) >= thr16;
-    } else {
-        keep[0] = (h0 & 0xffffu) >= thr16; keep[1] = (h0 >> 16) >= thr16;
-        keep[2] = (h1 & 0xffffu) >= thr16; keep[3] = (h1 >> 16) >= thr16;
-    }
+// keep[r] for the 4 consecutive elements idx0 .. idx0 + 3, any alignment (2 hashes, one 64-bit funnel shift)
+__device__ __forceinline__ void dropout_keep4(unsigned key, unsigned idx0, unsigned thr8, bool (&keep)[4]) {
+    const unsigned q0 = idx0 >> 2;
+    const unsigned long long w = ((unsigned long long)dropout_hash(key, q0 + 1) << 32) | dropout_hash(key, q0);
+    const unsigned h = (unsigned)(w >> (8u * (idx0 & 3u)));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r] = ((h >> (8 * r)) & 0xffu) >= thr8;
 }
 
-// idx0 even: the 4 elements are the two fields of two consecutive hashes (no per-lane alignment case)
-__device__ __forceinline__ void dropout_keep4_even(unsigned key, unsigned idx0, unsigned thr16, bool (&keep)[4]) {
-    const unsigned p0 = idx0 >> 1;
-    const unsigned h0 = dropout_hash(key, p0), h1 = dropout_hash(key, p0 + 1);
-    keep[0] = (h0 & 0xffffu) >= thr16; keep[1] = (h0 >> 16) >= thr16;
-    keep[2] = (h1 & 0xffffu) >= thr16; keep[3] = (h1 >> 16) >= thr16;
+// idx0 % 4 == 0: the 4 elements are the 4 bytes of ONE hash (no per-lane alignment case)
+__device__ __forceinline__ void dropout_keep4_even(unsigned key, unsigned idx0, unsigned thr8, bool (&keep)[4]) {
+    const unsigned h = dropout_hash(key, idx0 >> 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep[r] = ((h >> (8 * r)) & 0xffu) >= thr8;
 }
 
 // ---- wave reductions (64 lanes) ----

@@ -1,5 +1,5 @@
-"""Host replica of the kernels' counter-based dropout rule (csrc/common.h::dropout_hash), used to derive per-site keys
-and, in tests, to rebuild the exact masks a training step used."""
+"""Host replica of the kernels' counter-based dropout rule (csrc/common.h::dropout_hash: four 8-bit uniforms per lowbias32
+hash), used to derive per-site keys and, in tests, to rebuild the exact masks a training step used."""
 import torch
 
 M32 = 0xFFFFFFFF
@@ -21,26 +21,25 @@ def site_key(seed: int, site: int) -> int:
 
 
 def threshold(p: float) -> int:
-    """16-bit threshold thr16 = round(p * 65536): an element is dropped iff its 16-bit uniform < thr16."""
-    return max(0, min(65536, int(round(p * 65536.0))))
+    """8-bit threshold thr8 = round(p * 256): an element is dropped iff its 8-bit uniform < thr8 (p_eff = thr8 / 256)."""
+    return max(0, min(256, int(round(p * 256.0))))
 
 
-def scale(thr16: int) -> float:
-    """1 / (1 - p_eff) for the probability the kernels actually realise, p_eff = thr16 / 65536."""
-    return 65536.0 / max(1, 65536 - thr16)
+def scale(thr8: int) -> float:
+    """1 / (1 - p_eff) for the probability the kernels actually realise, p_eff = thr8 / 256."""
+    return 256.0 / max(1, 256 - thr8)
 
 
 def keep_mask(key: int, n: int, thr: int, offset: int = 0) -> torch.Tensor:
-    """bool[n]: element i kept iff the 16-bit field (i & 1) of hash(key, (offset + i) >> 1) >= thr (replica of dropout_keep)."""
+    """bool[n]: element i kept iff byte (i & 3) of hash(key, (offset + i) >> 2) >= thr (replica of csrc/common.h::dropout_keep)."""
     idx = torch.arange(offset, offset + n, dtype=torch.int64)
-    x = ((idx >> 1) ^ key) & M32
+    x = ((idx >> 2) ^ key) & M32
     x ^= x >> 16
     x = (x * 0x7FEB352D) & M32
     x ^= x >> 15
     x = (x * 0x846CA68B) & M32
     x ^= x >> 16
-    bits = torch.where((idx & 1) == 1, x >> 16, x & 0xFFFF)
-    return bits >= thr
+    return ((x >> (8 * (idx & 3))) & 0xFF) >= thr
 
 
 def sample_uniform(seed: int, step: int, row: int) -> float:

@@ -44,8 +44,8 @@ int i2t_last_error(char* buf, size_t n);
  *                   act 1: v = gelu_tanh(v);  act 2: v *= gelu_tanh'(aux_in[m][n])
  *                   dropout (training): drop_mode 1: v = keep(key, m*N+n) ? v*scale : 0  (resid / MLP dropout,
  *                   layers.py:469,485); drop_mode 2: v *= keep(key + n/(N/3), m) ? scale : 0  (the per-token q/k/v
- *                   multipliers of layers.py:454-461 on the fused c_attn output); keep(key, i) = u16(key, i) >= thr, where u16 is
- *                   bit field (i & 1) of lowbias32((i >> 1) ^ key) and thr = round(p * 65536)
+ *                   multipliers of layers.py:454-461 on the fused c_attn output); keep(key, i) = u8(key, i) >= thr, where u8 is
+ *                   byte (i & 3) of lowbias32((i >> 2) ^ key) and thr = round(p * 256); scale = 256 / (256 - thr)
  *                   v += residual[m][n] (f32);  accumulate: v += C[m][n] (f32 C only);  store C as f32 or bf16.
  *   K must be a multiple of 8.  Columns [N, ldc) of C are never written.
  * --------------------------------------------------------------------------------------------------------- */
@@ -121,8 +121,8 @@ int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch_stride, co
  *   packed variable-length batches (training skips the caption rows past the last label: they are dead under the causal
  *   mask and carry zero loss weight): cu_q / cu_k (device int[B+1], nullable) give sequence b the rows [cu[b], cu[b+1]) of
  *   a packed [total, width] tensor (batch strides then unused; Tq/Tk = the maxima); with cu_q, lse/delta are [H][total_q].
- *   dropout on the attention probabilities (SDPA dropout_p, layers.py:465; nn.MultiheadAttention dropout): drop_thr = round(p*65536)
- *   (0 = off), probability (b,h,q,key) kept iff u16(drop_key, ((b*H+h)*Tq+q)*Tk+key) >= drop_thr, scaled by drop_scale.
+ *   dropout on the attention probabilities (SDPA dropout_p, layers.py:465; nn.MultiheadAttention dropout): drop_thr = round(p*256)
+ *   (0 = off), probability (b,h,q,key) kept iff u8(drop_key, ((b*H+h)*Tq+q)*Tk+key) >= drop_thr, scaled by drop_scale.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                       const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
@@ -216,8 +216,8 @@ int i2t_nchw_to_nhwc_bf16(void* stream, const void* src, void* dst, int B, int C
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n);
 /* in-place dropout of x[rows][cols] (f32 or bf16) with the same counter-based keep rule as the fused epilogues:
- * mode 1: element (r, c) kept iff u16(key, r*cols + c) >= thr; mode 2: all of (r, third t of cols) kept iff
- * u16(key + t, r) >= thr (u16 and thr as for i2t_gemm_bf16).  Used for the embedding dropouts and to re-apply a forward mask to a gradient. */
+ * mode 1: element (r, c) kept iff u8(key, r*cols + c) >= thr; mode 2: all of (r, third t of cols) kept iff
+ * u8(key + t, r) >= thr (u8 and thr as for i2t_gemm_bf16).  Used for the embedding dropouts and to re-apply a forward mask to a gradient. */
 int i2t_dropout_apply(void* stream, void* x, int is_f32, long rows, int cols, int mode, unsigned key, unsigned thr,
                       float scale);
 int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
