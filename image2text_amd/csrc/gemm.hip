@@ -59,6 +59,12 @@ struct GemmParams {
     int g2_gn;                // 256^2 kernel: column tiles per group of the tile order
     int g2_dbg;               // experiment (I2T_G256_DBG): 1 = epilogue without its global stores, 2 = no epilogue at all
     int g2_stagger, g2_stagger_groups;   // experiment: start delay (units of s_sleep 127) x (workgroup index within its XCD mod groups)
+    // fused cross-attention (epilogue class 8, see xattn_epilogue): queries, outputs and shapes
+    const bf16_t* xq; long xq_bs; int xq_rs;      // Q [B, T, >= 64 H] (batch stride used when xcu is null) or packed [rows, >= 64 H]
+    const int* xcu;                               // packed queries: rows of image b = [xcu[b], xcu[b+1])
+    bf16_t* xo; long xo_bs; int xo_rs;            // attention output, same layout convention as Q
+    float* xlse;                                  // [H][total_q] (packed) or [B][H][TqMax]
+    int x_total_q, x_TqMax, x_H, x_d, x_B;
 };
 
 // Tile order inside an XCD's contiguous chunk of the grid.  PMC (round 1, B = 256): with M fastest the GEMM family moved
@@ -547,6 +553,163 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     });
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Fused cross-attention (epilogue class 8 of the 256^2 kernel): reference models/layers.py:537-542,600-605
+// (nn.MultiheadAttention over the encoder output: K/V projection of the memory tokens -> softmax(Q K^T / sqrt(dh)) V).
+//
+// The K/V projection GEMM  [K | V](b) = mem(b) . [W_k ; W_v]^T + bias  is tiled so that ONE WAVE ends its K loop holding,
+// for one image b (its 64 memory tokens) and one head h, K_h(b)^T and V_h(b) in its accumulators:
+//     acc[i][j],   i < 4:  K^T[dim 16 i + 4 g + r][key 16 j + li]     (un-swapped issue: dims in registers, keys on lanes)
+//     acc[4+i][j]       :  V  [key 16 j + 4 g + r][dim 16 i + li]     (swapped issue: keys in registers, dims on lanes)
+// (workgroup tile = head pair x 4 images; "A" = the weight rows [K_h | V_h | K_h+1 | V_h+1], "B" = 256 memory rows).
+// Those are exactly the operand forms of the two attention products when the scores are produced transposed
+// (cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand"):
+//     S^T[key][q]  = sum_dim K^T[dim][key] Q^T[dim][q]   A = pack(acc[2s][j], acc[2s+1][j])        (sums over K^T's ROW index)
+//     O^T[dim][q]  = sum_key V[key][dim]  P^T[key][q]    A = pack(acc[4+i][2s], acc[4+i][2s+1]),  B = pack(P^T tiles 2s, 2s+1)
+// so the image's attention runs straight out of the GEMM's registers: K and V are written to HBM once (the backward pass
+// reads them) and never read back in the forward -- the separate attention kernel re-read all of K and V (402 MB per layer
+// at 2048 images; it was HBM-bound on exactly those bytes) -- and the scores / probabilities never leave the wave.
+// Per wave: bias, K/V stores as full 128-byte lines through the wave's 4 KiB LDS pad, then for every 16-query block of the
+// image's (packed) query rows 8 + 8 MFMAs around a softmax whose row reductions are 2 shuffles (a lane owns one query).
+// Dropout on the probabilities uses the index space of i2t_attention_fwd, so the unfused backward kernels regenerate the mask.
+__device__ __forceinline__ bf16x8 xa_pack(const f32x4& a, const f32x4& b) {
+    const u32x4 v = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float xa_quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xa_quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int tile_m, int n0, int wr, int wc, int lane,
+                                               unsigned char* pad) {
+    const int g = lane >> 4, li = lane & 15;
+    const int h = 2 * tile_m + wr, b = (n0 >> 6) + wc, d = p.x_d;
+    if (b >= p.x_B || h >= p.x_H) return;                               // wave-uniform (no workgroup barrier in this epilogue)
+    // ---- queries of this (image, head): issue the first block's loads before anything else
+    int Tq = p.x_TqMax;
+    size_t qoff = (size_t)b * p.xq_bs, ooff = (size_t)b * p.xo_bs, stat = ((size_t)b * p.x_H + h) * p.x_TqMax;
+    if (p.xcu) {
+        const int s0 = p.xcu[b];
+        Tq = p.xcu[b + 1] - s0;
+        qoff = (size_t)s0 * p.xq_rs; ooff = (size_t)s0 * p.xo_rs;
+        stat = (size_t)h * p.x_total_q + s0;
+    }
+    const bf16_t* qb = p.xq + qoff + h * 64;
+    auto load_q = [&](int qblk, u32x4 (&qf)[2]) {                       // Q^T B-operands: k-slot (g, e) <-> dim 32 s + 16 (e >> 2) + 4 g + (e & 3)
+        const bf16_t* qp = qb + (size_t)min(16 * qblk + li, max(Tq - 1, 0)) * p.xq_rs + 4 * g;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(qp + 32 * s2), hi = *reinterpret_cast<const u32x2*>(qp + 32 * s2 + 16);
+            qf[s2] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    u32x4 qf[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if (Tq > 0) load_q(0, qf);
+    // ---- bias (in_proj_bias rows d + 64 h .. for K, 2 d + 64 h .. for V; p.bias points at the K part)
+    {
+        const float* bk = p.bias + h * 64;
+        const float* bv = p.bias + d + h * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(bk + 16 * i + 4 * g);
+            const float v1 = bv[16 * i + li];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] += k4;
+                acc[4 + i][j] += f32x4{v1, v1, v1, v1};
+            }
+        }
+    }
+    // ---- K and V rows of the image -> C = kv[b][key][0:d | d:2d] as full 128-byte lines: per 16-key block the wave's pad holds
+    // [16 keys][K dims 64 | V dims 64] bf16 (256-B rows, 16-B chunks XOR-swizzled by the row: conflict-free writes and reads)
+    bf16_t* kvb = reinterpret_cast<bf16_t*>(p.C) + (size_t)b * 64 * p.ldc + h * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x2 k2 = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
+            *reinterpret_cast<u32x2*>(pad + li * 256 + (((2 * i + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = k2;       // row = key li
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                                                          // row = key 4 g + r
+                const int row = 4 * g + r;
+                *reinterpret_cast<bf16_t*>(pad + row * 256 + (((8 + 2 * i + (li >> 3)) ^ row) << 4) + (li & 7) * 2) = f32_to_bf16(acc[4 + i][j][r]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = 4 * it + g;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(pad + row * 256 + ((li ^ row) << 4));
+            bf16_t* dst = kvb + (size_t)(16 * j + row) * p.ldc + (li < 8 ? li * 8 : d + (li - 8) * 8);
+            G2_STORE(reinterpret_cast<u32x4*>(dst), v);
+        }
+    }
+    if (Tq <= 0) return;
+    // ---- operand fragments of the two attention products (bf16: the same rounding the stored K / V carry)
+    bf16x8 ka[2][4], va_[4][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ka[s2][j] = xa_pack(acc[2 * s2][j], acc[2 * s2 + 1][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) va_[i][s2] = xa_pack(acc[4 + i][2 * s2], acc[4 + i][2 * s2 + 1]);
+    constexpr float kScale = 0.125f * 1.4426950408889634f;             // 1 / sqrt(64) x log2(e)
+    const bool drop = p.drop_thr != 0;
+    const int nqb = (Tq + 15) >> 4;
+    for (int qblk = 0; qblk < nqb; ++qblk) {
+        const bf16x8 q0 = __builtin_bit_cast(bf16x8, qf[0]), q1 = __builtin_bit_cast(bf16x8, qf[1]);
+        if (qblk + 1 < nqb) load_q(qblk + 1, qf);                      // next block's queries travel during this block's math
+        const int qrow = 16 * qblk + li;
+        f32x4 sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0][j], q0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1][j], q1, a, 0, 0, 0);
+            mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+            sc[j] = a;
+        }
+        mx = xa_quad_max(mx) * kScale;
+        float rs = 0.f;
+        const unsigned drow = (((unsigned)b * p.x_H + h) * (unsigned)p.x_TqMax + (unsigned)min(qrow, Tq - 1)) * 64u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool keep[4] = {true, true, true, true};
+            if (drop) dropout_keep4_even(p.drop_key, drow + 16 * j + 4 * g, p.drop_thr, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = __builtin_amdgcn_exp2f(sc[j][r] * kScale - mx);
+                rs += pr;                                               // the softmax denominator is dropout-free
+                sc[j][r] = keep[r] ? pr : 0.f;
+            }
+        }
+        const float l = xa_quad_sum(rs);
+        const bf16x8 p0 = xa_pack(sc[0], sc[1]), p1 = xa_pack(sc[2], sc[3]);
+        const float inv = (drop ? p.drop_scale : 1.0f) / l;
+        u32x2 ob[4];                                                    // (MFMAs stay outside the per-lane row predicate)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_[i][0], p0, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_[i][1], p1, o, 0, 0, 0);
+            ob[i] = u32x2{pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv)};
+        }
+        if (qrow < Tq) {
+            bf16_t* op = p.xo + ooff + (size_t)qrow * p.xo_rs + h * 64 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x2*>(op + 16 * i) = ob[i];
+            if (g == 0 && p.xlse) p.xlse[stat + qrow] = (mx + log2f(l)) * 0.6931471805599453f;
+        }
+    }
+}
+
 // SPLITK: gridDim.y slices of the reduction; every slice adds its partial tile into the fp32 C with float atomics
 // (C must already hold the value to accumulate onto -- the gradient arena does).  The MFMA is issued un-swapped
 // there so that one atomic wave-instruction covers 4 rows x 64 contiguous bytes instead of 16 rows x 4 scattered
@@ -708,7 +871,7 @@ struct G2Tile {                       // wave-uniform description of one output 
     int m0, n0, t0;                   // t0: first K-tile of this work item's K slice
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool UNSWAP = false>
+template <bool A_KMAJOR, bool B_KMAJOR, bool UNSWAP = false, bool XA = false>
 struct G2 {
     static constexpr bool PK = A_KMAJOR && B_KMAJOR;
     static constexpr int FA = A_KMAJOR ? 2 : 1, FB = B_KMAJOR ? 2 : 1;      // LGKM ops per fragment read
@@ -738,7 +901,12 @@ struct G2 {
         int tile_m, tile_n;
         tile_coords(p, idx - slice * tiles, tile_m, tile_n, p.g2_gn);
         d.m0 = tile_m * 256; d.n0 = tile_n * 256;
-        if (!A_KMAJOR) {
+        if (XA) {
+            // fused cross-attention: the tile's 256 "A rows" are [K_h | V_h | K_h+1 | V_h+1] for the head pair h = 2 tile_m: p.A points
+            // at W_k (in_proj rows d ..), W_v lies x_d rows further on; init_lane bakes the sub-panel offsets into the voffsets
+            d.a = p.A + (size_t)tile_m * 128 * p.lda;
+            d.a_bytes = (unsigned)((p.x_d + 128) * p.lda * 2);
+        } else if (!A_KMAJOR) {
             d.a = p.A + (size_t)d.m0 * p.lda;
             d.a_bytes = (unsigned)(min(p.M - d.m0, 256) * p.lda * 2);
         } else {
@@ -783,7 +951,10 @@ struct G2 {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = u * 512 + tid;
-                if (!A_KMAJOR) {
+                if (XA) {            // wave row r >> 6 = head of the pair; sub 0 = its 64 W_k rows, sub 1 = its 64 W_v rows
+                    const int r = c >> 3, kc = (c & 7) ^ (r & 7);
+                    va[sub][u] = ((r >> 6) * 64 + (r & 63) + sub * p.x_d) * p.lda * 2 + kc * 16;
+                } else if (!A_KMAJOR) {
                     const int r = c >> 3, kc = (c & 7) ^ (r & 7);
                     va[sub][u] = ((r >> 6) * 128 + sub * 64 + (r & 63)) * p.lda * 2 + kc * 16;
                 } else {
@@ -870,7 +1041,9 @@ struct G2 {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[SUBA * 4 + i][SUBB * 2 + j] =     // UNSWAP (atomic epilogue): lane holds C[4 (lane>>4) + r][lane&15] of each 16 x 16 block
-                    UNSWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[KS * 4 + i], rb[KS * 2 + j], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0)
+                    // XA: the K half of the wave tile (SUBA 0) is issued un-swapped -> K^T[dim][key] (dims in registers, keys on lanes);
+                    // the V half swapped -> V[key][dim]: exactly the forms the attention epilogue chains into its MFMAs
+                    (UNSWAP || (XA && SUBA == 0)) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra[KS * 4 + i], rb[KS * 2 + j], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[KS * 2 + j], ra[KS * 4 + i], acc[SUBA * 4 + i][SUBB * 2 + j], 0, 0, 0);
         if (G2_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
@@ -925,7 +1098,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int k = ((bid >> 3) % p.g2_stagger_groups) * p.g2_stagger;
         for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    G2<A_KMAJOR, B_KMAJOR, EPI == 6> g;
+    G2<A_KMAJOR, B_KMAJOR, EPI == 6, EPI == 8> g;
     g.init(p, smem, tid);
     g.cur = g.tile_desc(p, first, ntiles);
     g.nxt = g.tile_desc(p, first + G, ntiles);
@@ -950,7 +1123,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int m0 = g.cur.m0, n0 = g.cur.n0;
         g.cur = g.nxt;
         g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
-        if constexpr (EPI == 6) {        // split-K partial: fp32 atomics, one wave-instruction = 4 rows x 64 contiguous bytes
+        if constexpr (EPI == 8) {        // fused cross-attention: the wave's (image, head) attends out of the accumulators
+            int lane_e = tid & 63;
+            asm volatile("" : "+v"(lane_e));
+            xattn_epilogue(p, acc, m0 >> 8, n0, g.wr, g.wc, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+        } else if constexpr (EPI == 6) {        // split-K partial: fp32 atomics, one wave-instruction = 4 rows x 64 contiguous bytes
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
             float* C = reinterpret_cast<float*>(p.C);
@@ -1311,6 +1488,41 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, block, 0, s, p);
     }
     I2T_CHECK_LAUNCH("i2t_gemm_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_xattn_kv_fused(void* stream, const void* mem, int ld_mem, const void* w_kv, int ld_w, const float* bias_kv,
+                                  const void* q, long q_bs, int q_rs, const int* cu_q, int total_q, void* kv, int ld_kv, void* o,
+                                  long o_bs, int o_rs, float* lse, int B, int S, int H, int Tq, unsigned drop_key,
+                                  unsigned drop_thr, float drop_scale) {
+    const int d = 64 * H;
+    I2T_REQUIRE(mem && w_kv && bias_kv && q && kv && o && B > 0 && H > 0 && Tq > 0, "i2t_xattn_kv_fused: bad args");
+    I2T_REQUIRE(S == 64 && (H & 1) == 0, "i2t_xattn_kv_fused: needs 64 memory tokens per image and an even head count (S=%d H=%d)", S, H);
+    I2T_REQUIRE((ld_mem & 7) == 0 && (ld_w & 7) == 0 && ld_mem >= d && ld_w >= d && ALIGNED16(mem) && ALIGNED16(w_kv),
+                "i2t_xattn_kv_fused: mem / w_kv must be 16-byte aligned with leading dimensions >= d, %% 8 == 0");
+    I2T_REQUIRE((ld_kv & 7) == 0 && ld_kv >= 2 * d && ALIGNED16(kv), "i2t_xattn_kv_fused: kv rows must hold [K | V] (2 d), 16-byte aligned");
+    I2T_REQUIRE(((uintptr_t)q & 7) == 0 && ((uintptr_t)o & 7) == 0 && (q_rs & 3) == 0 && (o_rs & 3) == 0 && (q_bs & 3) == 0 && (o_bs & 3) == 0 &&
+                    q_rs >= d && o_rs >= d, "i2t_xattn_kv_fused: q / o must be 8-byte aligned with strides %% 4 == 0");
+    I2T_REQUIRE(!cu_q || total_q > 0, "i2t_xattn_kv_fused: packed queries need total_q");
+    I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * 64 < 4294967296.0, "i2t_xattn_kv_fused: dropout index overflows 32 bits");
+    I2T_REQUIRE((double)(d + 128) * ld_w * 2 < 4294967296.0 && (double)B * S * ld_mem * 2 < 1.8e19, "i2t_xattn_kv_fused: operand too large");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)w_kv; p.lda = ld_w;                  // "A" = the weight rows: [K_h | V_h] per wave tile
+    p.B = (const bf16_t*)mem; p.ldb = ld_mem;                 // "B" = 256 memory rows = 4 images per workgroup tile
+    p.C = kv; p.ldc = ld_kv;
+    p.M = 2 * d; p.N = B * S; p.K = d;
+    p.alpha = 1.f; p.bias = bias_kv;
+    p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
+    p.xq = (const bf16_t*)q; p.xq_bs = q_bs; p.xq_rs = q_rs; p.xcu = cu_q;
+    p.xo = (bf16_t*)o; p.xo_bs = o_bs; p.xo_rs = o_rs; p.xlse = lse;
+    p.x_total_q = total_q; p.x_TqMax = Tq; p.x_H = H; p.x_d = d; p.x_B = B;
+    p.g2_gn = 8;
+    p.tiles_m = H / 2; p.tiles_n = (p.N + 255) / 256;
+    p.g2_splits = 1; p.g2_nk = (((p.K + 63) >> 6) + 1) & ~1;
+    const int n_cu = g256_cus(), tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<false, false, 8>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, (hipStream_t)stream, p);
+    I2T_CHECK_LAUNCH("i2t_xattn_kv_fused");
     return I2T_OK;
 }
 

@@ -192,6 +192,8 @@ class HotPath:
         self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
         self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
                           for l in range(dcfg.n_layer)]
+        # fused cross-attention forward (K/V projection + attention in one launch) when the shapes allow; I2T_XATTN_FUSED=0: A/B runs
+        self.xattn_fused = os.environ.get('I2T_XATTN_FUSED') != '0'
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
         self.grad_ready_hooks = []      # callables(which: 'begin' | 'decoder' | 'encoder'), e.g. the data-parallel exchange
@@ -277,10 +279,16 @@ class HotPath:
             q = self._empty(M, d, dtype=BF16)
             ops.gemm(ln3, win[:d], q, M, d, d, bias=bin_[:d])
             kv = self._empty(B, S, 2 * d, dtype=BF16)
-            ops.gemm(mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, 2 * d, d, bias=bin_[d:])
             co, lse_c = self._empty(M, d, dtype=BF16), self._empty(H * M)
-            ops.attention_fwd(v3(q, d), kv[..., :d], kv[..., d:], v3(co, d), lse_c, B, H, T, S, False, drop=dr['xattn'],
-                              cu_q=cu, total_q=M)
+            if self.xattn_fused and S == 64 and H % 2 == 0 and d == 64 * H:
+                # ONE launch: K/V projection GEMM whose waves run the attention of their (image, head) out of the accumulators
+                # (K and V are written once for the backward pass and never read back here)
+                ops.xattn_kv_fused(mem_bf, win[d:], bin_[d:], v3(q, d), kv, v3(co, d), lse_c, B, S, H, T, drop=dr['xattn'],
+                                   cu_q=cu, total_q=M)
+            else:
+                ops.gemm(mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, 2 * d, d, bias=bin_[d:])
+                ops.attention_fwd(v3(q, d), kv[..., :d], kv[..., d:], v3(co, d), lse_c, B, H, T, S, False, drop=dr['xattn'],
+                                  cu_q=cu, total_q=M)
             x2 = self._empty(M, d)
             ops.gemm(co, a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
                      bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1)

@@ -134,6 +134,18 @@ def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causa
              'i2t_attention_bwd')
 
 
+def xattn_kv_fused(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, drop=None, cu_q=None, total_q=0):
+    """Fused cross-attention forward (include/i2t.h::i2t_xattn_kv_fused): kv = mem . w_kv^T + bias written once, attention of every
+    (image, head) out of the projection's accumulators.  q / o: [B, Tq, >= 64 H] views or packed [rows, >= 64 H] with cu_q."""
+    _need_cuda(mem, w_kv, q, kv, o)
+    qb, qr = _bs_rs(q); ob, orr = _bs_rs(o)
+    assert mem.dtype == BF16 and w_kv.dtype == BF16 and q.dtype == BF16 and kv.dtype == BF16 and o.dtype == BF16
+    _l.check(_lib().i2t_xattn_kv_fused(_stream(), _p(mem), mem.stride(0), _p(w_kv), w_kv.stride(0), _p(bias_kv), _p(q), qb, qr,
+                                       _p(cu_q), int(total_q), _p(kv), kv.stride(-2), _p(o), ob, orr, _p(lse), B, S, H, Tq,
+                                       *_drop(drop)[1:]), 'i2t_xattn_kv_fused')
+    return o
+
+
 def embed_fwd(ids, wte, wpe, x, B, T, d, pos_offset, vocab, pos=None):
     _need_cuda(ids, wte, x)
     _l.check(_lib().i2t_embed_fwd(_stream(), _p(ids), _p(wte), _p(wpe), _p(x), B, T, d, pos_offset, vocab, _p(pos)), 'i2t_embed_fwd')

@@ -64,6 +64,21 @@ int i2t_gemm_bf16(void* stream,
                   int accumulate,
                   int drop_mode, unsigned drop_key, unsigned drop_thr, float drop_scale);
 
+/* Fused cross-attention forward (reference models/layers.py:537-542,600-605: nn.MultiheadAttention over the encoder output):
+ *   kv[b][key][0:d | d:2d] = mem[b][key][:] . [W_k ; W_v]^T + bias_kv          (bf16, written once: the backward pass reads it)
+ *   o[q][64 h ..] = softmax(Q_h K_h^T / 8) V_h   per image b and head h,  lse as i2t_attention_fwd
+ * in ONE launch: the K/V projection is the persistent 256 x 256 MFMA GEMM, tiled so that a wave ends its K loop holding K_h(b)^T and
+ * V_h(b) of one (image, head) in its accumulators, and that wave runs the image's attention straight out of those registers
+ * (csrc/gemm.hip::xattn_epilogue) -- K and V are never read back from HBM in the forward.
+ * mem bf16 [B*S][ld_mem] (S must be 64), w_kv = in_proj_weight rows d..3d (bf16 [2d][ld_w], d = 64 H, H even), bias_kv f32 [2d];
+ * q / o bf16: [B][Tq] views (batch / row strides) or, with cu_q (device int[B+1]), packed rows (batch strides unused, Tq = max);
+ * dropout on the probabilities: same index space and rule as i2t_attention_fwd (drop_thr 0 = off), so i2t_attention_bwd on the
+ * stored q / kv / o / lse is its backward. */
+int i2t_xattn_kv_fused(void* stream, const void* mem, int ld_mem, const void* w_kv, int ld_w, const float* bias_kv,
+                       const void* q, long q_bs, int q_rs, const int* cu_q, int total_q, void* kv, int ld_kv, void* o,
+                       long o_bs, int o_rs, float* lse, int B, int S, int H, int Tq, unsigned drop_key, unsigned drop_thr,
+                       float drop_scale);
+
 /* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients; X bf16 [M][ld]) */
 /* The large-tile GEMM kernels are persistent: one 8-wave workgroup per CU holds the CU's whole LDS and register file and
  * walks a static share of the output tiles.  A kernel from another stream that needs whole CUs for a long time (an RCCL

@@ -888,3 +888,90 @@ def test_nchw_to_nhwc(ops, C, H, W):
     y = torch.empty(2, H, W, C, dtype=BF16, device=dev())
     ops.nchw_to_nhwc(x, y, 2, C, H, W)
     assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ fused cross-attention
+def _xattn_reference(mem, w_kv, bias, q_rows, lens, H, mask=None, sc=1.0):
+    """fp64 reference on the bf16-rounded K / V the kernel stores: per image b, queries q_rows[b] (n_b x d)."""
+    B, S, d = mem.shape
+    kv = (mem.double().reshape(B * S, d) @ w_kv.double().t() + bias.double()).reshape(B, S, 2 * d)
+    kvb = kv.to(BF16).double()
+    outs, lses = [], []
+    for b in range(B):
+        n = lens[b]
+        qh = q_rows[b].double().reshape(n, H, 64).permute(1, 0, 2)                 # (H, n, 64)
+        kh = kvb[b, :, :d].reshape(S, H, 64).permute(1, 0, 2)
+        vh = kvb[b, :, d:].reshape(S, H, 64).permute(1, 0, 2)
+        s = qh @ kh.transpose(-1, -2) / 8.0
+        lses.append(torch.logsumexp(s, -1))                                        # (H, n)
+        p = torch.softmax(s, -1)
+        if mask is not None:
+            p = p * mask[b][:, :n].double() * sc
+        outs.append((p @ vh).permute(1, 0, 2).reshape(n, d))
+    return kv, outs, lses
+
+
+@pytest.mark.parametrize('B,H,packed,drop', [(6, 2, True, False), (9, 12, True, True), (5, 4, False, False), (4, 2, False, True)])
+def test_xattn_kv_fused(ops, B, H, packed, drop):
+    """K/V projection + attention in one launch (i2t_xattn_kv_fused) against an fp64 reference: stored K/V, attention output,
+    log-sum-exp; partial workgroup tiles (B % 4 != 0), ragged packed queries including an image with no query row and one with
+    64, dense [B, T] queries with T > 64 (7 query blocks), probability dropout on the index space of i2t_attention_fwd -- and
+    the unfused backward kernels run on the fused forward's outputs."""
+    from image2text_amd import rng
+    S, d = 64, 64 * H
+    mem = rnd(B, S, d, dtype=BF16, seed=400)
+    w_in = rnd(3 * d, d, dtype=BF16, seed=401, scale=d ** -0.5)
+    b_in = rnd(3 * d, seed=402, scale=0.3)
+    T = 64 if packed else 100
+    if packed:
+        lens = [int(x) for x in torch.randint(1, 65, (B,), generator=torch.Generator().manual_seed(7))]
+        lens[0], lens[1 % B] = 64, 0
+        if B > 2:
+            lens[2] = 17
+    else:
+        lens = [T] * B
+    total = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    q = rnd(total, d, dtype=BF16, seed=403) if packed else rnd(B, T, d, dtype=BF16, seed=403)
+    key, thr = rng.site_key(31337, 4100), rng.threshold(0.1)
+    sc = rng.scale(thr)
+    dr = (1, key, thr, sc) if drop else None
+    kv = torch.zeros(B, S, 2 * d, dtype=BF16, device=dev())
+    o = torch.full_like(q, 7.0)
+    lse = torch.zeros(H * total if packed else B * H * T, device=dev())
+    ops.xattn_kv_fused(mem.view(B * S, d), w_in[d:], b_in[d:], q, kv, o, lse, B, S, H, T, drop=dr,
+                       cu_q=cu if packed else None, total_q=total if packed else 0)
+    torch.cuda.synchronize()
+    q_rows = [q[int(cu[b]):int(cu[b + 1])] for b in range(B)] if packed else [q[b] for b in range(B)]
+    mask = None
+    if drop:
+        mask = rng.keep_mask(key, B * H * T * S, thr).view(B, H, T, S).to(dev())
+    kv_ref, o_ref, lse_ref = _xattn_reference(mem, w_in[d:], b_in[d:], q_rows, lens, H, mask, sc)
+    check('fused kv', kv, kv_ref, 2e-2, 1 / 128)
+    for b in range(B):
+        n = lens[b]
+        if n == 0:
+            continue
+        ob = o[int(cu[b]):int(cu[b + 1])] if packed else o[b]
+        check(f'fused o[{b}]', ob, o_ref[b], 1e-2, 1 / 64)
+        for h in range(H):
+            got = lse[h * total + int(cu[b]):h * total + int(cu[b]) + n] if packed else lse.view(B, H, T)[b, h]
+            check(f'fused lse[{b},{h}]', got, lse_ref[b][h], 2e-3, 1e-3)
+    # the same call through the unfused kernels (GEMM + attention_fwd): stored K/V bit-identical?  outputs within bf16 rounding
+    kv2 = torch.empty_like(kv)
+    ops.gemm(mem.view(B * S, d), w_in[d:], kv2.view(B * S, 2 * d), B * S, 2 * d, d, bias=b_in[d:])
+    o2, lse2 = torch.zeros_like(q), torch.zeros_like(lse)
+    ops.attention_fwd(q, kv2[..., :d], kv2[..., d:], o2, lse2, B, H, T, S, False, drop=dr, cu_q=cu if packed else None, total_q=total if packed else 0)
+    assert float((kv.float() - kv2.float()).abs().max()) <= 2.0 ** -7 * float(kv2.float().abs().max())
+    live = torch.ones(q.shape[0] if packed else B * T, dtype=torch.bool, device=dev())
+    check('fused vs unfused o', o.reshape(-1, d)[live], o2.reshape(-1, d)[live], 2e-2, 1 / 32)
+    # backward of the fused forward = the unfused backward kernels on its saved tensors
+    do = rnd(*q.shape, dtype=BF16, seed=404)
+    dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+    ops.attention_bwd(q, kv[..., :d], kv[..., d:], o, do, lse, torch.empty_like(lse), dq, dkv[..., :d], dkv[..., d:], B, H, T, S, False,
+                      drop=dr, cu_q=cu if packed else None, total_q=total if packed else 0)
+    dq2, dkv2 = torch.zeros_like(q), torch.zeros_like(kv)
+    ops.attention_bwd(q, kv2[..., :d], kv2[..., d:], o2, do, lse2, torch.empty_like(lse), dq2, dkv2[..., :d], dkv2[..., d:], B, H, T, S, False,
+                      drop=dr, cu_q=cu if packed else None, total_q=total if packed else 0)
+    check('bwd dq on fused outputs', dq, dq2, 3e-2 * float(do.float().abs().max()), 1 / 16)
+    check('bwd dkv on fused outputs', dkv, dkv2, 3e-2 * float(do.float().abs().max()), 1 / 16)

@@ -43,12 +43,20 @@ def main():
         ('attention', lambda: ops.attention_fwd(q, kv[..., :d], kv[..., d:], co, lse, B, H, 64, S, False, cu_q=cu, total_q=M), 4.0 * M * S * d),
         ('out projection + res', lambda: ops.gemm(co, wout, x2, M, d, d, bias=bout, residual=x1), 2.0 * M * d * d),
     ]
+    fused = ('k/v projection + attention (fused)', lambda: ops.xattn_kv_fused(mem, win[d:], bin_[d:], q, kv, co, lse, B, S, H, 64, cu_q=cu, total_q=M),
+             2.0 * B * S * 2 * d * d + 4.0 * M * S * d)
     tot_t = tot_f = 0.0
+    ts = []
     for name, fn, fl in parts:
         t = timeit(fn, reps=20)
+        ts.append(t)
         tot_t += t
         tot_f += fl
         print(f'{name:22s} {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s', flush=True)
+    tf = timeit(fused[1], reps=20)
+    print(f'{fused[0]:36s} {tf * 1e6:8.1f} us  {fused[2] / tf / 1e12:7.1f} TFLOP/s   (unfused: {(ts[1] + ts[2]) * 1e6:.1f} us)', flush=True)
+    ft = ts[0] + tf + ts[3]
+    print(f'cross-attention block, fused  {ft * 1e6:8.1f} us  {tot_f / ft / 1e12:7.1f} TFLOP/s = {tot_f / ft / 2.5e15 * 100:.1f} % of 2.5 PF')
     print(f'cross-attention block   {tot_t * 1e6:8.1f} us  {tot_f / tot_t / 1e12:7.1f} TFLOP/s = {tot_f / tot_t / 2.5e15 * 100:.1f} % of 2.5 PF   '
           f'(B = {B}: {M} packed query rows, {B * S} memory rows, {tot_f / 1e9:.0f} GFLOP)')
 
