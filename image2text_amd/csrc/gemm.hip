@@ -1161,6 +1161,309 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// gemm3: 256 x 128 x 64 tiles with TWO accumulator sets per wave -- the epilogue of output tile i runs inside the K loop of
+// tile i + 1.  In the 256^2 kernel above a tile's epilogue (bias / GELU / conversions, LDS transposes, 128-256 KB of stores:
+// 6.5-13 us) runs with the matrix pipe idle, which is what holds the K = 512 .. 768 GEMMs of the model at 0.7-1.0 PF while the
+// K loop alone sustains 1.4 PF.  Here a wave owns a 64 x 64 tile (8 waves as 4 x 2): 64 accumulator registers per set, two sets
+// = the 128 of the 256^2 kernel; while set A accumulates tile i + 1, set B (tile i) is drained one 16-row group per K-tile:
+// scaled / biased / activated in registers, transposed through the wave's 2 KiB LDS pad as bf16, stored as full 128-byte
+// lines.  Price: 1.5x the L2->LDS bytes and 1.33x the LDS reads per MFMA of the 256^2 tile (both have room), a 3-stage
+// 48 KiB ring (one barrier per K-tile, DMA two K-tiles ahead) instead of the 8-phase schedule.
+// Every VMEM operation inside the loop is issued from inline asm and waited for by hand (counted vmcnt): one compiler-inserted
+// s_waitcnt vmcnt(0) for an epilogue load would drain the DMA ring once per K-tile.
+constexpr int G3_STAGE = 48 * 1024, G3_B_OFF = 32 * 1024, G3_PAD = 2048;
+constexpr int G3_SMEM = 3 * G3_STAGE + 8 * G3_PAD;          // 160 KiB
+
+__device__ __forceinline__ void g3_store16_nt(void* ptr, const u32x4& v) {
+    // s_nop: a store of more than 8 bytes reads its data registers after issue; the compiler pads that hazard for its own stores
+    // but not for inline asm (seen: the next instruction's zero-initialisation landing in the stored tile)
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+// In-place ("+v") on purpose: the destination is an existing variable that the load overwrites where it lives.  With a fresh
+// "=v" result assigned to a loop-carried variable the compiler copies the result registers at the join / back-edge -- BEFORE the
+// hand-placed wait, i.e. it copies registers the load has not filled yet (seen: garbage bias in every tile but the first).
+__device__ __forceinline__ void g3_load16(f32x4& v, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v) : "v"(ptr) : "memory");
+}
+
+struct G3Tile {
+    const bf16_t* a;
+    const bf16_t* b;
+    unsigned a_bytes, b_bytes;
+    int m0, n0;
+};
+
+template <int EPI>
+struct G3 {
+    unsigned lds0;
+    unsigned char* smem;
+    int lane, wave, wr, wc;
+    int va0, vb0;
+    unsigned sa64, sb64;
+    int nk;
+
+    __device__ __forceinline__ static G3Tile tile_desc(const GemmParams& p, int idx, int ntiles) {
+        G3Tile d;
+        if (idx >= ntiles) { d.a = p.A; d.b = p.B; d.a_bytes = 0; d.b_bytes = 0; d.m0 = 0; d.n0 = 0; return d; }
+        int tile_m, tile_n;
+        tile_coords(p, idx, tile_m, tile_n, p.g2_gn);
+        d.m0 = tile_m * 256; d.n0 = tile_n * 128;
+        d.a = p.A + (size_t)d.m0 * p.lda;
+        d.a_bytes = (unsigned)(min(p.M - d.m0, 256) * p.lda * 2);
+        d.b = p.B + (size_t)d.n0 * p.ldb;
+        d.b_bytes = (unsigned)(min(p.N - d.n0, 128) * p.ldb * 2);
+        return d;
+    }
+    __device__ __forceinline__ void init(const GemmParams& p, unsigned char* smem_, int tid) {
+        smem = smem_;
+        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem_;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        wr = wave >> 1; wc = wave & 1;
+        nk = (p.K + 63) >> 6;
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;               // R image: chunk ^= row & 7, applied on the SOURCE side
+        // piece u of a wave covers rows 8 (8 u + wave) + rl: the 64-row step between a wave's pieces goes into the scalar offset
+        va0 = (8 * wave + rl) * p.lda * 2 + c * 16;
+        vb0 = (8 * wave + rl) * p.ldb * 2 + c * 16;
+        sa64 = 64u * (unsigned)p.lda * 2u; sb64 = 64u * (unsigned)p.ldb * 2u;
+        init_frag_bases();
+    }
+    // K-tile kt of tile d -> ring slot `slot`: 4 + 2 one-KiB pieces per wave
+    __device__ __forceinline__ void stage(const G3Tile& d, int kt, int slot) {
+        const unsigned base = lds0 + slot * G3_STAGE + wave * 1024;
+        const unsigned so = (unsigned)kt * 128u;
+        const unsigned long long a = (unsigned long long)d.a, b = (unsigned long long)d.b;
+        const u32x4 ra_ = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, d.a_bytes, 0x00020000u};
+        const u32x4 rb_ = {(unsigned)b, (unsigned)(b >> 32) & 0xffffu, d.b_bytes, 0x00020000u};
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+                     "s_mov_b32 m0, %1\n\tbuffer_load_dwordx4 %4, %5, %7 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %4, %5, %8 offen lds\n\t"
+                     "s_mov_b32 m0, %3\n\tbuffer_load_dwordx4 %4, %5, %9 offen lds"
+                     ::"s"(base), "s"(base + 8192u), "s"(base + 16384u), "s"(base + 24576u), "v"(va0), "s"(ra_),
+                       "s"(so), "s"(so + sa64), "s"(so + 2u * sa64), "s"(so + 3u * sa64) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                     "s_mov_b32 m0, %1\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
+                     ::"s"(base + G3_B_OFF), "s"(base + G3_B_OFF + 8192u), "v"(vb0), "s"(rb_), "s"(so), "s"(so + sb64) : "memory");
+    }
+    // Fragment i of k-step ks: tile[r0 + 16 i + li][32 ks + 8 g .. + 7] at byte (r0 + 16 i + li) * 128 + (((4 ks + g) ^ (li & 7)) << 4): the
+    // swizzle does not depend on i (16 i is a multiple of 8) and ks only flips byte-offset bit 6, so every read is one per-lane
+    // base (fa / fb, set up once) + the slot base (one add per K-tile) + an immediate: 2 address registers per operand.
+    int fa, fb;
+    __device__ __forceinline__ void init_frag_bases() {
+        const int g = lane >> 4, li = lane & 15;
+        const int x = ((g ^ (li & 7)) & 7) << 4;                         // ks = 0 (g < 4: bit 2 of the chunk index comes from ks alone)
+        fa = (wr * 64 + li) * 128 + x;
+        fb = G3_B_OFF + (wc * 64 + li) * 128 + x;
+    }
+    template <int KS>
+    __device__ __forceinline__ void read_frags(int slot, bf16x8 (&ra)[4], bf16x8 (&rb)[4]) {
+        const unsigned char* sa = smem + slot * G3_STAGE + (fa ^ (KS * 64));
+        const unsigned char* sb = smem + slot * G3_STAGE + (fb ^ (KS * 64));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + i * 2048));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + j * 2048));
+    }
+    __device__ __forceinline__ static void mma(f32x4 (&acc)[4][4], const bf16x8 (&ra)[4], const bf16x8 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)      // swapped issue: lane holds C[row 16 i + (lane & 15)][cols 16 j + 4 (lane >> 4) .. + 3]
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[j], ra[i], acc[i][j], 0, 0, 0);
+    }
+};
+
+// One 16-row group (i) of a finished 64 x 64 wave tile, class 1 (bf16 C, optional bias, optional per-(row, third) multipliers):
+// registers -> bf16 -> the wave's pad (16 rows x 128 B, 16-B chunks XOR-swizzled by row & 7) -> 2 stores of 8 rows x 128 B.
+struct G3Pend {
+    int m0, n0;          // tile origin of the pending set (its wave offset is added by the step)
+    int live;            // the pending set holds a finished tile
+};
+// Epilogue steps of a finished 64 x 64 wave tile: class 1 (bf16 C [+ per-(row, third) multipliers]) = 4 steps, one 16-row group
+// each; class 2 (GELU with the bf16 pre-activation as a second output) = 7 steps: pre-activation of group s >> 1, then its GELU
+// (s = 0 .. 5), and both halves of group 3 in step 6 -- one K-tile of every tile must stay free of a step (the bias quads are
+// fetched there, when the registers of `old` are dead), and K = 512 has 8 K-tiles.
+template <int EPI>
+constexpr int g3_nsteps() { return EPI == 2 ? 7 : 4; }
+
+template <int EPI, int i, bool ACT, bool PRE>
+__device__ __forceinline__ void g3_epi_part(const GemmParams& p, const f32x4 (&acc)[4][4], const G3Pend& pd, int wr, int wc, int lane,
+                                            unsigned char* pad) {
+    if (PRE && !p.aux_out) return;                              // (uniform) nothing to emit
+    const int g = lane >> 4, li = lane & 15;
+    const int m = pd.m0 + wr * 64 + 16 * i + li, nb = pd.n0 + wc * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j];                                    // alpha = 1 (host), bias already inside
+        if (ACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        }
+        if (EPI == 1 && p.drop_mode == 2) {
+            const unsigned third = (unsigned)(nb + 16 * j + 4 * g) / (unsigned)(p.N / 3);
+            v *= dropout_keep(p.drop_key + third, (unsigned)min(m, p.M - 1), p.drop_thr) ? p.drop_scale : 0.f;
+        }
+        const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        const int slot8 = 4 * j + g;                            // 8-byte slot within the 128-B row
+        *reinterpret_cast<u32x2*>(pad + li * 128 + ((((slot8 >> 1) ^ (li & 7))) << 4) + (slot8 & 1) * 8) = pk;
+        if (ACT) __builtin_amdgcn_sched_barrier(0);             // one quad's GELU at a time: interleaving all four spilled registers
+    }
+    bf16_t* dst = PRE ? p.aux_out : reinterpret_cast<bf16_t*>(p.C);
+    const int ld = PRE ? p.ld_aux_out : p.ldc;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 8 * it + (lane >> 3), c = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(pad + row * 128 + ((c ^ (row & 7)) << 4));
+        const int mm = pd.m0 + wr * 64 + 16 * i + row, nn = nb + 8 * c;
+        if (mm < p.M && nn < p.N) g3_store16_nt(dst + (size_t)mm * ld + nn, v);
+    }
+}
+
+template <int EPI, int S>
+__device__ __forceinline__ void g3_epi_step(const GemmParams& p, const f32x4 (&acc)[4][4], const G3Pend& pd, int wr, int wc, int lane,
+                                            unsigned char* pad) {
+    if constexpr (EPI == 2) {
+        if constexpr (S == 6) {
+            g3_epi_part<EPI, 3, false, true>(p, acc, pd, wr, wc, lane, pad);
+            g3_epi_part<EPI, 3, true, false>(p, acc, pd, wr, wc, lane, pad);
+        } else {
+            g3_epi_part<EPI, (S >> 1), (S & 1) != 0, (S & 1) == 0>(p, acc, pd, wr, wc, lane, pad);
+        }
+    } else {
+        g3_epi_part<EPI, S, false, false>(p, acc, pd, wr, wc, lane, pad);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void g3_epi_all(const GemmParams& p, const f32x4 (&acc)[4][4], const G3Pend& pd, int wr, int wc, int lane,
+                                           unsigned char* pad) {
+    static_for<g3_nsteps<EPI>()>([&](auto S_) { g3_epi_step<EPI, decltype(S_)::value>(p, acc, pd, wr, wc, lane, pad); });
+}
+
+template <int EPI, bool OVERLAP>
+__global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G3_SMEM];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x, bid = blockIdx.x, ntiles = p.tiles_m * p.tiles_n;
+    const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
+    const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    G3<EPI> g;
+    g.init(p, smem, tid);
+    unsigned char* pad = smem + 3 * G3_STAGE + g.wave * G3_PAD;
+    const int nk = g.nk;
+    // producer state: the K-tile the DMA stream stages next (runs two K-tiles ahead of the MFMAs, across output tiles)
+    G3Tile pt = g.tile_desc(p, first, ntiles);
+    int p_idx = first, p_kt = 0, p_slot = 0;
+    auto produce = [&]() {
+        g.stage(pt, p_kt, p_slot);
+        p_slot = p_slot == 2 ? 0 : p_slot + 1;
+        if (++p_kt == nk) { p_kt = 0; p_idx += G; pt = g.tile_desc(p, p_idx, ntiles); }
+    };
+    produce();
+    produce();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 ra0[4], rb0[4], ra1[4], rb1[4];
+    int c_slot = 0;
+    g.template read_frags<0>(0, ra0, rb0);
+    // cur accumulates the tile in flight; old holds the finished tile whose epilogue is being drained (copied from cur at the
+    // tile boundary: 64 register moves per tile, instead of two copies of the loop with the roles swapped)
+    f32x4 cur[4][4], old[4][4];
+    G3Pend pend{0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) old[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int idx = first; idx < ntiles; idx += G) {
+        int tile_m, tile_n;
+        tile_coords(p, idx, tile_m, tile_n, p.g2_gn);
+        const int m0 = tile_m * 256, n0 = tile_n * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool drain = OVERLAP && pend.live && !(p.g2_dbg & 2);
+        // One K-tile.  LAST: the tile's final K-tile also fetches the bias quads of the tile (issued before this iteration's DMAs,
+        // so its wait covers them); they are added when the finished accumulators are moved to `old` right after the loop -- the
+        // accumulators themselves only ever see MFMAs (same summation order as the 256^2 kernel: bit-equal results).
+        // STEP >= 0: the iteration also drains 16-row group STEP of the previous tile (`old`); peeled, so STEP is a constant.
+        f32x4 bias4[4];
+        auto k_iter = [&](auto STEP_, auto LAST_) {
+            constexpr int STEP = decltype(STEP_)::value;
+            constexpr bool LAST = decltype(LAST_)::value;
+            const int n_slot = c_slot == 2 ? 0 : c_slot + 1;
+            if constexpr (LAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) g3_load16(bias4[j], p.bias + min(n0 + g.wc * 64 + 16 * j + 4 * (g.lane >> 4), p.N - 4));
+                }
+            }
+            produce();                                            // K-tile q + 2 -> the slot whose last readers passed the previous barrier
+            g.template read_frags<1>(c_slot, ra1, rb1);
+            G3<EPI>::mma(cur, ra0, rb0);
+            // K-tile q + 1 landed <=> at most the 6 DMAs of q + 2 are still in flight.  (Loads retire in order, so this holds however
+            // the epilogue stores of the previous iteration retire; a count of 8 "for the 2 stores" would be wrong if they retire early.)
+            // (Staging q + 3 right after the barrier instead -- two full iterations ahead -- measured 4 % SLOWER: the loop is bound by
+            // LDS bandwidth, 176 KB per K-tile = 0.65 us against 0.49 us of MFMA, not by DMA latency.)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            g.template read_frags<0>(n_slot, ra0, rb0);
+            // The two waves of a SIMD (w, w + 4) take their epilogue step on opposite sides of the second MFMA block: while one
+            // converts / transposes / stores, the other has the matrix pipe to itself.
+            if constexpr (STEP >= 0) {
+                if (g.wave < 4) g3_epi_step<EPI, STEP>(p, old, pend, g.wr, g.wc, g.lane, pad);
+            }
+            G3<EPI>::mma(cur, ra1, rb1);
+            if constexpr (STEP >= 0) {
+                if (g.wave >= 4) g3_epi_step<EPI, STEP>(p, old, pend, g.wr, g.wc, g.lane, pad);
+            }
+            c_slot = n_slot;
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        constexpr int NS = g3_nsteps<EPI>();
+        int kt = 0;
+        if (drain) {                       // nk > NS (host): the draining K-tiles first
+            static_for<NS>([&](auto S_) { k_iter(S_, F_{}); });
+            kt = NS;
+        }
+#pragma unroll 1
+        for (; kt < nk - 1; ++kt) k_iter(std::integral_constant<int, -1>{}, F_{});
+        k_iter(std::integral_constant<int, -1>{}, T_{});
+        if (!OVERLAP) {
+            const G3Pend now{m0, n0, 1};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[i][j] += bias4[j];
+            if (!(p.g2_dbg & 2)) {
+                g3_epi_all<EPI>(p, cur, now, g.wr, g.wc, g.lane, pad);
+            } else if (cur[0][0][0] == 12345.678f) {
+                reinterpret_cast<float*>(p.C)[0] = cur[3][3][3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) old[i][j] = cur[i][j] + bias4[j];
+            pend = G3Pend{m0, n0, 1};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (OVERLAP && pend.live) {
+        if (!(p.g2_dbg & 2)) {
+            g3_epi_all<EPI>(p, old, pend, g.wr, g.wc, g.lane, pad);
+        } else if (old[0][0][0] == 12345.678f) {
+            reinterpret_cast<float*>(p.C)[0] = old[3][3][3];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 int g256_epilogue_class(const GemmParams& p) {
     const bool fast4 = (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.aux_in || (p.ld_aux_in & 3) == 0) &&
                        (!p.aux_out || (p.ld_aux_out & 3) == 0);
@@ -1187,6 +1490,22 @@ int g256_cus() {
     }
     const int r = __atomic_load_n(&g_cu_reserve, __ATOMIC_RELAXED);
     return (r > 0 && r < n_cu - 8) ? n_cu - r : n_cu;
+}
+
+void launch_g3(hipStream_t s, GemmParams p, bool overlap) {
+    const int n_cu = g256_cus();
+    { const char* e = getenv("I2T_G3_DBG"); p.g2_stagger = e ? atoi(e) : 0; }
+    p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 127) / 128;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const dim3 grid(tiles < n_cu ? tiles : n_cu), block(512);
+    const int cls = g256_epilogue_class(p);
+    if (cls == 2) {
+        if (overlap) hipLaunchKernelGGL((gemm3_kernel<2, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm3_kernel<2, false>), grid, block, 0, s, p);
+    } else {
+        if (overlap) hipLaunchKernelGGL((gemm3_kernel<1, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm3_kernel<1, false>), grid, block, 0, s, p);
+    }
 }
 
 template <bool B_KMAJOR>
@@ -1469,6 +1788,22 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     // I2T_G256_MIN_TILES (read per call so that a test can flip it): tile count from which the large-tile kernel takes over
     const char* mt_env = getenv("I2T_G256_MIN_TILES");
     const long min_tiles = mt_env ? atol(mt_env) : 40;
+    {   // gemm3 (256 x 128 tiles, the previous tile's epilogue inside the K loop): bit-equal to the 256^2 kernel; measured on MI355X
+        // (tools/bench_gemm3.py) +8.5 % at K = 512 (class 1: 865 vs 797 TF), a tie at K = 768 (993 vs 979, 963 vs 953, 1026 vs 1058)
+        // and -14 % at K = 2048 (its K loop moves 1.33x the LDS bytes per MFMA and is LDS-bound); the GELU class LOSES (458 vs 704 TF:
+        // a 64-value GELU step per wave outlasts the MFMA block it is meant to hide behind).  Default: class 1 with K <= 512 only.
+        // I2T_GEMM3 = 0 never | 1 always, epilogue after the K loop | 2 always, overlapped | unset: the default rule.
+        const char* e3 = getenv("I2T_GEMM3");          // (read per call: a test flips it)
+        const int g3 = e3 ? atoi(e3) : ((g256_epilogue_class(p) == 1 && K <= 512) ? 2 : 0);
+        const int cls3 = g256_epilogue_class(p);
+        if (g3 && splits == 1 && !a_kmajor && !b_kmajor && K % 64 == 0 && alpha == 1.0f && (N & 7) == 0 && (ldc & 7) == 0 && ALIGNED16(C) &&
+            ((cls3 == 1 && K >= 5 * 64) || (cls3 == 2 && K >= 8 * 64 && (!aux_out || ((ld_aux_out & 7) == 0 && ALIGNED16(aux_out))))) &&
+            (long)((M + 255) / 256) * ((N + 127) / 128) >= 2 * min_tiles) {
+            launch_g3(s, p, g3 == 2);
+            I2T_CHECK_LAUNCH("i2t_gemm_bf16(g3)");
+            return I2T_OK;
+        }
+    }
     if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
         if (b_kmajor) launch_g256<true>(s, p);
         else launch_g256<false>(s, p);

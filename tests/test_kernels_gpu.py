@@ -975,3 +975,27 @@ def test_xattn_kv_fused(ops, B, H, packed, drop):
                       drop=dr, cu_q=cu if packed else None, total_q=total if packed else 0)
     check('bwd dq on fused outputs', dq, dq2, 3e-2 * float(do.float().abs().max()), 1 / 16)
     check('bwd dkv on fused outputs', dkv, dkv2, 3e-2 * float(do.float().abs().max()), 1 / 16)
+
+
+@pytest.mark.parametrize('M,N,K,drop', [(70001, 1160, 512, False), (33280, 1536, 512, True), (12345, 768, 768, False), (8200, 2304, 384, True)])
+def test_gemm3_overlapped_epilogue_is_bit_equal(ops, monkeypatch, M, N, K, drop):
+    """gemm3 (256 x 128 tiles, two accumulator sets: a tile's epilogue runs inside the next tile's K loop) against the 256^2
+    kernel on class-1 problems (bf16 C, bias, optional per-(row, third) dropout multipliers): same K order per output, so the
+    results must be BIT-equal -- in both of its modes, on ragged M / N edges, and across many tiles per workgroup."""
+    from image2text_amd import rng
+    a, w = rnd(M, K, dtype=BF16, seed=500, scale=0.5), rnd(N, K, dtype=BF16, seed=501, scale=0.05)
+    bias = rnd(N, seed=502)
+    dr = (2, rng.site_key(9, 9), rng.threshold(0.1), rng.scale(rng.threshold(0.1))) if drop else None
+    outs = {}
+    monkeypatch.setenv('I2T_G256_MIN_TILES', '1')
+    for mode in ('0', '1', '2'):
+        monkeypatch.setenv('I2T_GEMM3', mode)
+        c = torch.full((M, N), 7.0, dtype=BF16, device=dev())
+        ops.gemm(a, w, c, M, N, K, bias=bias, drop=dr)
+        torch.cuda.synchronize()
+        outs[mode] = c
+    ref = a[:512].float() @ w.float().t() + bias
+    if not drop:
+        check('gemm3 vs fp32', outs['2'][:512], ref, 2e-2, 1 / 128)
+    assert torch.equal(outs['1'], outs['0']), f'mode 1: {(outs["1"] != outs["0"]).sum().item()} elements differ'
+    assert torch.equal(outs['2'], outs['0']), f'mode 2: {(outs["2"] != outs["0"]).sum().item()} elements differ'
