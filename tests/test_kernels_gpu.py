@@ -759,7 +759,8 @@ def test_gemm_epilogue_dropout(ops):
 
 
 @pytest.mark.parametrize('B,H,Tq,Tk,causal', [(2, 2, 64, 64, True), (2, 3, 100, 40, False), (1, 2, 70, 37, False),
-                                                (2, 1, 33, 131, True)])      # Tk % 4 != 0: the per-lane alignment variant
+                                                (2, 1, 33, 131, True),       # Tk % 4 != 0: the per-lane alignment variant
+                                                (2, 2, 260, 260, False), (1, 2, 200, 200, True)])   # 64 n + r rows: 5-wave tail workgroups
 def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
     from image2text_amd import rng
     d = 64 * H
