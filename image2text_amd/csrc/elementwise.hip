@@ -193,6 +193,115 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(bf16_t* __restrict__
     }
 }
 
+// Momentum-distillation form of the loss (reference training/wrapper.py:134-144): the target of a labelled row is
+// alpha * softmax(teacher / T) + (1 - alpha) * onehot(label), so
+//   loss_row = lse(z/T) - (1 - alpha) z[label]/T - alpha/T * sum_v softmax(teacher/T)[v] z[v]
+//   dz[v]    = g w/T * (softmax(z/T)[v] - (1 - alpha) [v == label] - alpha softmax(teacher/T)[v])
+// `teacher` = the momentum model's logits for the same rows (bf16, never differentiated); its row lse is kept for backward.
+__device__ __forceinline__ float row_dot_softmax(const bf16_t* z, const bf16_t* t, int V, float inv_temp, float lse_t, float* red) {
+    float s = 0.f;
+    const int v8 = V >> 3;
+    for (int c = threadIdx.x; c < v8; c += CE_THREADS) {
+        const u32x4 a = reinterpret_cast<const u32x4*>(z)[c], b = reinterpret_cast<const u32x4*>(t)[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s += __expf(bf16lo(b[e]) * inv_temp - lse_t) * bf16lo(a[e]);
+            s += __expf(bf16hi(b[e]) * inv_temp - lse_t) * bf16hi(a[e]);
+        }
+    }
+    for (int c = v8 * 8 + threadIdx.x; c < V; c += CE_THREADS) s += __expf(bf16_to_f32(t[c]) * inv_temp - lse_t) * bf16_to_f32(z[c]);
+    return block_sum(s, red);
+}
+
+__global__ __launch_bounds__(CE_THREADS) void ce_distill_fwd_kernel(const bf16_t* __restrict__ logits, int ld, const bf16_t* __restrict__ teacher,
+                                                                    int ld_t, float alpha, const int64_t* __restrict__ labels,
+                                                                    const float* __restrict__ w, float inv_temp, int64_t ignore_index,
+                                                                    float* __restrict__ lse, float* __restrict__ lse_t,
+                                                                    float* __restrict__ loss, int V) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int64_t lab = labels[row];
+    if (lab == ignore_index || lab < 0 || lab >= V) {   // block-uniform (an ignored row's weight is zero)
+        if (threadIdx.x == 0) lse[row] = lse_t[row] = 0.f;
+        return;
+    }
+    const bf16_t* r = logits + (size_t)row * ld;
+    const bf16_t* t = teacher + (size_t)row * ld_t;
+    const float l = row_lse(r, V, inv_temp, red);
+    const float lt = row_lse(t, V, inv_temp, red);
+    const float dot = row_dot_softmax(r, t, V, inv_temp, lt, red);
+    if (threadIdx.x == 0) {
+        lse[row] = l;
+        lse_t[row] = lt;
+        atomicAdd(loss, w[row] * (l - (1.f - alpha) * bf16_to_f32(r[lab]) * inv_temp - alpha * inv_temp * dot));
+    }
+}
+
+__global__ __launch_bounds__(CE_THREADS) void ce_distill_bwd_kernel(bf16_t* __restrict__ logits, int ld, const bf16_t* __restrict__ teacher,
+                                                                    int ld_t, float alpha, const int64_t* __restrict__ labels,
+                                                                    const float* __restrict__ w, float inv_temp, int64_t ignore_index,
+                                                                    const float* __restrict__ lse, const float* __restrict__ lse_t,
+                                                                    const float* __restrict__ gscale_ptr, int V) {
+    const int row = blockIdx.x;
+    const int64_t lab = labels[row];
+    bf16_t* r = logits + (size_t)row * ld;
+    const bf16_t* t = teacher + (size_t)row * ld_t;
+    const bool live = !(lab == ignore_index || lab < 0 || lab >= V);
+    const float coef = live ? (*gscale_ptr) * w[row] * inv_temp : 0.f;
+    const float l = live ? lse[row] : 0.f, lt = live ? lse_t[row] : 0.f;
+    const float hard = 1.f - alpha;
+    for (int c = threadIdx.x; c < V; c += CE_THREADS) {
+        const float a = coef * (__expf(bf16_to_f32(r[c]) * inv_temp - l) - (c == lab ? hard : 0.f) - alpha * __expf(bf16_to_f32(t[c]) * inv_temp - lt));
+        r[c] = live ? f32_to_bf16(a) : (bf16_t)0;
+    }
+}
+
+// Momentum (EMA) update of the distillation twin over the flat arenas (reference wrapper.py:52-59): pm <- pm m + p (1 - m), plus
+// the twin's bf16 shadow in the same pass.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pm, const float* __restrict__ p, bf16_t* __restrict__ pmb, long n4,
+                                                  float momentum) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(pm)[i], b = reinterpret_cast<const f32x4*>(p)[i];
+        const f32x4 v = a * momentum + b * (1.f - momentum);
+        reinterpret_cast<f32x4*>(pm)[i] = v;
+        if (pmb) {
+            const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            reinterpret_cast<u32x2*>(pmb)[i] = pk;
+        }
+    }
+}
+
+// Decoder inputs of a training step from its labels, with the optional MLM corruption (reference wrapper.py:154-196): position 0
+// is BOS, position t the (corrupted) label t - 1; an ignored label reads EOS.  Corruption of a labelled token: with probability
+// mask_fraction it becomes the MASK id -- or, with probability random_mask_fraction of those, a uniformly random id.  The three
+// draws per token come from two counter hashes of (seed, element index): u_mask = top 24 bits of h1, u_rand = top 24 bits of h2,
+// id = h2's low bits folded into [0, vocab) by a 64-bit multiply (image2text_amd/rng.py::mlm_draws is the host replica).
+__device__ __forceinline__ unsigned mix32_(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void lm_inputs_kernel(const int64_t* __restrict__ labels, int64_t* __restrict__ ids, long n, int L,
+                                                        int64_t bos, int64_t eos, int64_t mask_id, int vocab, int64_t ignore_index,
+                                                        float mask_fraction, float random_fraction, unsigned seed_lo, unsigned seed_hi) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % L);
+        int64_t v = bos;
+        if (t > 0) {
+            const long src = i - 1;
+            const int64_t lab = labels[src];
+            v = lab == ignore_index ? eos : lab;
+            if (mask_fraction > 0.f && lab != ignore_index) {
+                const unsigned h1 = mix32_(mix32_(seed_lo ^ (unsigned)src) + seed_hi + (unsigned)(src >> 32) * 0x9E3779B9u);
+                const unsigned h2 = mix32_(h1 ^ 0x85EBCA6Bu);
+                const float u_mask = (float)(h1 >> 8) * (1.0f / 16777216.0f), u_rand = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+                if (u_mask <= mask_fraction)
+                    v = u_rand <= random_fraction ? (int64_t)(((unsigned long long)mix32_(h2 + 0x27D4EB2Fu) * (unsigned long long)vocab) >> 32) : mask_id;
+            }
+        }
+        ids[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- gradient normaliser
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ ws) {
     __shared__ float red[16];
@@ -517,5 +626,47 @@ extern "C" int i2t_snradam_step(void* stream, float* p, const float* g, float* m
     hipLaunchKernelGGL(snradam_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                        n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, inv_bc1_prev, inv_bc1, inv_bc2, grad_scale);
     I2T_CHECK_LAUNCH("i2t_snradam_step");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ce_distill_fwd(void* stream, const void* logits, int ld, const void* teacher, int ld_t, float alpha, const int64_t* labels,
+                                  const float* w, float inv_temp, int64_t ignore_index, float* lse, float* lse_t, float* loss, int M, int V) {
+    I2T_REQUIRE(logits && teacher && labels && w && lse && lse_t && loss && M > 0 && V > 0, "i2t_ce_distill_fwd: bad args");
+    I2T_REQUIRE(ld % 8 == 0 && ld >= V && ld_t % 8 == 0 && ld_t >= V && ALIGNED16(logits) && ALIGNED16(teacher), "i2t_ce_distill_fwd: leading dimensions must be multiples of 8 and >= V");
+    I2T_REQUIRE(alpha >= 0.f && alpha <= 1.f, "i2t_ce_distill_fwd: alpha out of [0, 1]");
+    hipLaunchKernelGGL(ce_distill_fwd_kernel, dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, (const bf16_t*)teacher,
+                       ld_t, alpha, labels, w, inv_temp, ignore_index, lse, lse_t, loss, V);
+    I2T_CHECK_LAUNCH("i2t_ce_distill_fwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ce_distill_bwd(void* stream, void* logits, int ld, const void* teacher, int ld_t, float alpha, const int64_t* labels,
+                                  const float* w, float inv_temp, int64_t ignore_index, const float* lse, const float* lse_t,
+                                  const float* gscale_ptr, int M, int V) {
+    I2T_REQUIRE(logits && teacher && labels && w && lse && lse_t && gscale_ptr && M > 0 && V > 0, "i2t_ce_distill_bwd: bad args");
+    I2T_REQUIRE(ld >= V && ld_t >= V, "i2t_ce_distill_bwd: leading dimensions must be >= V");
+    hipLaunchKernelGGL(ce_distill_bwd_kernel, dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (bf16_t*)logits, ld, (const bf16_t*)teacher,
+                       ld_t, alpha, labels, w, inv_temp, ignore_index, lse, lse_t, gscale_ptr, V);
+    I2T_CHECK_LAUNCH("i2t_ce_distill_bwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ema_update(void* stream, float* pm, const float* p, void* pm_bf16, long n, float momentum) {
+    I2T_REQUIRE(pm && p && n > 0 && n % 4 == 0 && ALIGNED16(pm) && ALIGNED16(p), "i2t_ema_update: arenas must be 16-byte aligned, n %% 4 == 0");
+    I2T_REQUIRE(momentum >= 0.f && momentum <= 1.f, "i2t_ema_update: momentum out of [0, 1]");
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, pm, p, (bf16_t*)pm_bf16, n >> 2, momentum);
+    I2T_CHECK_LAUNCH("i2t_ema_update");
+    return I2T_OK;
+}
+
+extern "C" int i2t_lm_inputs(void* stream, const int64_t* labels, int64_t* ids, int B, int L, int64_t bos, int64_t eos, int64_t mask_id,
+                             int vocab, int64_t ignore_index, float mask_fraction, float random_fraction, unsigned seed_lo,
+                             unsigned seed_hi) {
+    I2T_REQUIRE(labels && ids && B > 0 && L > 0 && vocab > 0, "i2t_lm_inputs: bad args");
+    I2T_REQUIRE(mask_fraction >= 0.f && mask_fraction <= 1.f && random_fraction >= 0.f && random_fraction <= 1.f, "i2t_lm_inputs: fractions out of [0, 1]");
+    const long n = (long)B * L;
+    hipLaunchKernelGGL(lm_inputs_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, labels, ids, n, L, bos, eos, mask_id, vocab,
+                       ignore_index, mask_fraction, random_fraction, seed_lo, seed_hi);
+    I2T_CHECK_LAUNCH("i2t_lm_inputs");
     return I2T_OK;
 }

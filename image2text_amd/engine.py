@@ -579,7 +579,8 @@ class HotPath:
         ops.cast_f32_bf16(enc_out.contiguous(), mem)
         return mem
 
-    def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0, vl=None):
+    def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0, vl=None,
+                       dropout_without_save: bool = False):
         """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [M,d], hidden bf16, ctx), M = B*T, or
         M = vl.total for packed variable-length rows (vl = namespace(cu, pos, total): ids is then the packed 1-D id list)."""
         a, dc = self.arena, self.dec
@@ -588,7 +589,8 @@ class HotPath:
         d, M = dc.d, (vl.total if vl is not None else B * T)
         x = self._empty(M, d)
         wpe = a.P(f'{self.dp}transformer.wpe.weight')
-        plan = self.dec_drop if save else None
+        # (dropout_without_save: a forward that is never differentiated but runs in training mode -- the momentum twin)
+        plan = self.dec_drop if (save or dropout_without_save) else None
         emb_drop = plan.get(0, 'emb') if plan is not None else None
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()

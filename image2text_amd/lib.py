@@ -28,6 +28,10 @@ SIGNATURES = {
     'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I, P],
     'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
     'i2t_ce_bwd': [P, P, I, P, P, F, I64, P, P, I, I],
+    'i2t_ce_distill_fwd': [P, P, I, P, I, F, P, P, F, I64, P, P, P, I, I],
+    'i2t_ce_distill_bwd': [P, P, I, P, I, F, P, P, F, I64, P, P, P, I, I],
+    'i2t_ema_update': [P, P, P, P, L, F],
+    'i2t_lm_inputs': [P, P, P, I, I, I64, I64, I64, I, I64, F, F, U, U],
     'i2t_grad_normalize': [P, P, L, P, P, U, U, F, I, P],
     'i2t_conv_fwd': [P, P, I, I, P, P, P, P, I, I, I, I, I, I],
     'i2t_conv_bwd_data': [P, P, P, P, I, P, P, I, I, I, I, I, I],

@@ -169,6 +169,33 @@ def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
                                _p(gscale), M, V), 'i2t_ce_bwd')
 
 
+def ce_distill_fwd(logits, ld, teacher, ld_t, alpha, labels, w, inv_temp, ignore_index, lse, lse_t, loss, M, V):
+    _need_cuda(logits, teacher, labels, w, lse, lse_t, loss)
+    _l.check(_lib().i2t_ce_distill_fwd(_stream(), _p(logits), ld, _p(teacher), ld_t, float(alpha), _p(labels), _p(w), float(inv_temp),
+                                       int(ignore_index), _p(lse), _p(lse_t), _p(loss), M, V), 'i2t_ce_distill_fwd')
+
+
+def ce_distill_bwd(logits, ld, teacher, ld_t, alpha, labels, w, inv_temp, ignore_index, lse, lse_t, gscale, M, V):
+    _need_cuda(logits, teacher, labels, w, lse, lse_t, gscale)
+    _l.check(_lib().i2t_ce_distill_bwd(_stream(), _p(logits), ld, _p(teacher), ld_t, float(alpha), _p(labels), _p(w), float(inv_temp),
+                                       int(ignore_index), _p(lse), _p(lse_t), _p(gscale), M, V), 'i2t_ce_distill_bwd')
+
+
+def ema_update(pm, p, pm_bf16, n, momentum):
+    _need_cuda(pm, p)
+    _l.check(_lib().i2t_ema_update(_stream(), _p(pm), _p(p), _p(pm_bf16), int(n), float(momentum)), 'i2t_ema_update')
+
+
+def lm_inputs(labels, ids, B, L, bos, eos, mask_id, vocab, ignore_index, mask_fraction=0.0, random_fraction=0.0, seed=0):
+    """ids = [BOS, labels[:-1]] with ignored labels -> EOS and the optional MLM corruption (include/i2t.h::i2t_lm_inputs)."""
+    _need_cuda(labels, ids)
+    assert labels.dtype == torch.long and ids.dtype == torch.long and labels.is_contiguous() and ids.is_contiguous()
+    _l.check(_lib().i2t_lm_inputs(_stream(), _p(labels), _p(ids), B, L, int(bos), int(eos), int(-1 if mask_id is None else mask_id), int(vocab),
+                                  int(ignore_index), float(mask_fraction), float(random_fraction), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF),
+             'i2t_lm_inputs')
+    return ids
+
+
 def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=None, presummed=False, clear_after=None,
                    keep_f32=False):
     """presummed: ws already holds sum(g^2) (layernorm_bwd's sumsq_out); clear_after: 1-float tensor zeroed afterwards;

@@ -48,3 +48,23 @@ def sample_uniform(seed: int, step: int, row: int) -> float:
     lo, hi = seed & M32, (seed >> 32) & M32
     h = lowbias32((lowbias32(lo ^ ((row * 0x9E3779B9) & M32)) + hi + step * 0x85EBCA6B) & M32)
     return (h >> 8) / 16777216.0
+
+
+def mlm_draws(seed: int, n: int):
+    """Host replica of the three per-token draws of csrc/elementwise.hip::lm_inputs_kernel for elements 0 .. n-1 of the label
+    tensor: (u_mask float32 in [0, 1), u_rand float32 in [0, 1), random id numerator uint32 -- id = (numerator * vocab) >> 32)."""
+    lo, hi = seed & M32, (seed >> 32) & M32
+    src = torch.arange(n, dtype=torch.int64)
+
+    def mix(x):
+        x = x & M32
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & M32
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & M32
+        x ^= x >> 16
+        return x
+    h1 = mix((mix((src & M32) ^ lo) + hi + ((src >> 32) * 0x9E3779B9)) & M32)
+    h2 = mix(h1 ^ 0x85EBCA6B)
+    num = mix((h2 + 0x27D4EB2F) & M32)
+    return (h1 >> 8).to(torch.float32) / 16777216.0, (h2 >> 8).to(torch.float32) / 16777216.0, num

@@ -177,6 +177,23 @@ int i2t_ce_fwd(void* stream, const void* logits, int ld, const int64_t* labels, 
                int64_t ignore_index, float* lse, float* loss, int M, int V);
 int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
                int64_t ignore_index, const float* lse, const float* gscale_ptr, int M, int V);
+/* Momentum-distillation loss (reference training/wrapper.py:134-144): targets alpha * softmax(teacher/T) + (1 - alpha) * onehot.
+ * teacher = the momentum twin's logits of the same rows (bf16 [M][ld_t], constant); lse_t [M] keeps its row lse for backward.
+ *   fwd: loss += sum_m w[m] (lse[m] - (1 - alpha) z[m][label]/T - alpha/T sum_v softmax(teacher[m]/T)[v] z[m][v])
+ *   bwd: z[m][:] <- bf16(gscale w[m]/T (softmax(z[m]/T) - (1 - alpha) onehot - alpha softmax(teacher[m]/T))), in place. */
+int i2t_ce_distill_fwd(void* stream, const void* logits, int ld, const void* teacher, int ld_t, float alpha, const int64_t* labels,
+                       const float* w, float inv_temp, int64_t ignore_index, float* lse, float* lse_t, float* loss, int M, int V);
+int i2t_ce_distill_bwd(void* stream, void* logits, int ld, const void* teacher, int ld_t, float alpha, const int64_t* labels,
+                       const float* w, float inv_temp, int64_t ignore_index, const float* lse, const float* lse_t,
+                       const float* gscale_ptr, int M, int V);
+/* EMA update of the momentum twin's flat arena (wrapper.py:52-59): pm <- pm momentum + p (1 - momentum); pm_bf16 (nullable) = its shadow */
+int i2t_ema_update(void* stream, float* pm, const float* p, void* pm_bf16, long n, float momentum);
+/* Decoder inputs of a training step from its labels (wrapper.py:154-196): ids[b][0] = bos, ids[b][t] = label t-1 (ignored -> eos), with
+ * the optional MLM corruption of labelled tokens: with probability mask_fraction -> mask_id, or (random_fraction of those) a random
+ * id in [0, vocab); draws are counter hashes of (seed, element) -- image2text_amd/rng.py::mlm_draws is the host replica. */
+int i2t_lm_inputs(void* stream, const int64_t* labels, int64_t* ids, int B, int L, int64_t bos, int64_t eos, int64_t mask_id, int vocab,
+                  int64_t ignore_index, float mask_fraction, float random_fraction, unsigned seed_lo, unsigned seed_hi);
+
 
 /* ---------------------------------------------------------------------------------------------------------
  * Gradient normaliser (functions.py:19-24): g <- g / (||g||_2 + 1e-6) over the whole f32 tensor, in place.

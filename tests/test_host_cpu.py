@@ -102,9 +102,16 @@ def test_no_cpu_path_fails_loudly():
 def test_unsupported_trainer_options_are_refused():
     from image2text_amd.training.wrapper import ModelTrainerWrapper
     cfg = tiny_config()
-    for kw in (dict(moco_momentum=0.995, moco_alpha=0.4), dict(mask_fraction=0.15), dict(add_contrastive_loss=True)):
-        with pytest.raises(NotImplementedError):
-            ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(**kw))
+    with pytest.raises(NotImplementedError):
+        ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(add_contrastive_loss=True))
+    with pytest.raises(ValueError):                         # MLM corruption needs a mask token (trainer.py:124-125 adds one)
+        ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(mask_fraction=0.15))
+    # momentum distillation builds the twin and starts it from the model's weights (wrapper.py:30-33,46-50)
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(moco_momentum=0.995, moco_alpha=0.4))
+    assert w.is_momentum and w.model_m is not None
+    for (n1, p1), (n2, p2) in zip(w.model.named_parameters(), w.model_m.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert sum(1 for n, _ in w.named_parameters() if n.startswith('model_m.')) == sum(1 for n, _ in w.named_parameters() if n.startswith('model.'))
 
 
 def test_loss_weights_match_the_oracle():
