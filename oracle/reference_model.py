@@ -441,3 +441,42 @@ def snradam_step(param, grad, state, lr, betas, weight_decay, eps):
     param.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + eps, value=-lr)
     state['t'] = t + 1
     return param
+
+
+# --------------------------------------------------------------------------------------------------------------
+# trainer extras (training/wrapper.py:46-59,134-144,161-196): MLM corruption of the decoder inputs, momentum distillation
+# --------------------------------------------------------------------------------------------------------------
+def lm_inputs(labels, bos: int, eos: int, ignore_index=-100, mask_id=None, mask_fraction=0.0, random_fraction=0.0, u_mask=None,
+              u_rand=None, r_ids=None):
+    """Decoder inputs of a step (wrapper.py:154-196): labelled token -> itself, or with probability mask_fraction (draw u_mask) the
+    MASK id -- or, for a share random_fraction of those (draw u_rand), the random id r_ids; ignored -> EOS; then BOS in front, last
+    position dropped.  The draws are explicit arguments (torch's RNG stream is not part of the contract)."""
+    ids = torch.where(labels != ignore_index, labels, torch.full_like(labels, eos))
+    if mask_fraction > 0:
+        repl = torch.where(u_rand <= random_fraction, r_ids, torch.full_like(labels, mask_id))
+        ids = torch.where(u_mask <= mask_fraction, repl, ids)
+        ids = torch.where(labels != ignore_index, ids, torch.full_like(labels, eos))
+    bs, sl = ids.shape
+    return torch.cat((torch.full((bs, 1), bos, dtype=torch.long), ids), dim=1)[:, :sl]
+
+
+def lm_step_distill(sd: SD, sd_m: SD, cfg, images, labels, tokenizer, alpha: float, ignore_index=-100, temperature=1.0, ids=None):
+    """train_step with momentum distillation (wrapper.py:134-144,197-214): the momentum model's logits (no gradient) give soft targets
+    alpha * softmax(z_m / T) + (1 - alpha) * onehot(label) (all-zero onehot for ignored labels, whose weight is zero anyway)."""
+    if ids is None:
+        ids, _ = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
+    _, logits, _ = forward(sd, cfg, images, ids, None, training=True)
+    with torch.no_grad():
+        _, logits_m, _ = forward(sd_m, cfg, images, ids, None, training=True)
+    labels = labels[..., :logits.size(-2)]
+    logits, logits_m = logits[..., :labels.size(-1), :], logits_m[..., :labels.size(-1), :]
+    w = loss_weights(labels, ignore_index)
+    V = logits.size(-1)
+    onehot = F.one_hot(torch.where(labels == ignore_index, torch.full_like(labels, V), labels), V + 1)[..., :-1]
+    target = alpha * F.softmax(logits_m / temperature, dim=-1) + (1 - alpha) * onehot
+    return -((F.log_softmax(logits / temperature, dim=-1) * target).sum(dim=-1) * w).sum()
+
+
+def ema(p_m, p, momentum: float):
+    """wrapper.py:52-59"""
+    return p_m * momentum + p * (1.0 - momentum)

@@ -209,3 +209,36 @@ def test_nano224_greedy64_prefix():
     ids, margins = orc.generate_greedy(sd, cfg, images[:2], torch.from_numpy(g['ids'][:2, :1]), 6, return_margins=True)
     assert np.array_equal(ids.numpy(), g['ids'][:2, :7])
     assert np.abs(margins.numpy() - g['margins'][:2, :6]).max() <= 2e-5
+
+
+def test_trainer_extras_moco_and_mlm():
+    """Momentum distillation (loss, every gradient, the twin after the EMA update) and the MLM corruption of the decoder inputs
+    against the reference (tests/golden/tiny_moco.npz, tiny_mlm.npz; tools/gen_goldens_r2.py trainer_extras)."""
+    from conftest import load_golden
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    g = load_golden('tiny_moco.npz')
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    tok = fake_tokenizer(V)
+
+    def state(seed):
+        sd = {k: v.detach().clone() for k, v in det_init_(VisionEncoderDecoder(cfg), seed=seed).state_dict().items() if k != 'decoder.lm_head.weight'}
+        sd['decoder.lm_head.weight'] = sd['decoder.transformer.wte.weight']
+        return sd
+    sd, sd_m = state(0), state(1)
+    for v in sd.values():
+        v.requires_grad_(True)
+    loss = orc.lm_step_distill(sd, sd_m, cfg, torch.from_numpy(g['images']), torch.from_numpy(g['labels']), tok, alpha=0.4, temperature=1.3)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * float(g['loss'])
+    for k in g:
+        if k.startswith('grad.') and k[5:] in sd:
+            close(sd[k[5:]].grad, g[k], 2e-5 * max(1.0, float(np.abs(g[k]).max())))
+        if k.startswith('ema.') and k[4:] in sd:
+            close(orc.ema(sd_m[k[4:]], sd[k[4:]].detach(), 0.9), g[k], 1e-6)
+    m = load_golden('tiny_mlm.npz')
+    ids = orc.lm_inputs(torch.from_numpy(m['labels']), V - 1, V - 1, -100, mask_id=V - 2, mask_fraction=0.3, random_fraction=0.4,
+                        u_mask=torch.from_numpy(m['u_mask']), u_rand=torch.from_numpy(m['u_rand']), r_ids=torch.from_numpy(m['r_ids']))
+    assert np.array_equal(ids.numpy(), m['ids'])
+    assert np.array_equal(orc.lm_inputs(torch.from_numpy(m['labels']), V - 1, V - 1).numpy(),
+                          orc.shifted_inputs(torch.from_numpy(m['labels']), V - 1, V - 1)[0].numpy())

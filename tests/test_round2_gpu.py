@@ -362,3 +362,112 @@ def test_generate_sampling_api():
     # top_k = 1 is greedy whatever the temperature
     assert torch.equal(m.generate(images, prompt, max_new_tokens=12, temperature=0.5, top_k=1),
                        m.generate(images, prompt, max_new_tokens=12, temperature=1.0, top_k=1))
+
+
+# ------------------------------------------------------------------------------------------------ trainer extras (f4)
+def test_momentum_distillation_matches_reference():
+    """train_step with moco_momentum / moco_alpha (reference wrapper.py:30-33,46-59,134-144): loss and every gradient of the model
+    against the reference fixture (twin at different weights, so the soft targets matter), the twin's parameters after the step's
+    EMA launch, validation = plain CE, copy_momentum_params re-synchronises."""
+    from types import SimpleNamespace
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    g = load_golden('tiny_moco.npz')
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    tok = SimpleNamespace(eos_token_id=V - 1, bos_token_id=V - 1, mask_token_id=V - 2, vocab_size=V)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(moco_momentum=0.9, moco_alpha=0.4, training_temperature=1.3), ignore_index=-100)
+    det_init_(w.model, seed=0)
+    det_init_(w.model_m, seed=1)
+    w = w.to(dev()).train()
+    p_before = {n: p.detach().clone() for n, p in w.model.named_parameters()}
+    pm_before = {n: p.detach().clone() for n, p in w.model_m.named_parameters()}
+    images, labels = torch.from_numpy(g['images']).to(dev()), torch.from_numpy(g['labels']).to(dev())
+    loss, _ = w.train_step(images, labels)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 1e-2 * float(g['loss'])
+    bad = []
+    for n, p in w.model.named_parameters():
+        ref = g[f'grad.{n}'].ravel().astype(np.float64)
+        got = p.grad.detach().float().cpu().numpy().ravel().astype(np.float64)
+        rel = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
+        cos = got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30)
+        if rel > 8e-2 or cos < 0.995:
+            bad.append((n, rel, cos))
+    assert not bad, bad[:6]
+    for n, p in w.model_m.named_parameters():               # EMA: exact fp32 arithmetic on the arenas
+        want = pm_before[n] * 0.9 + p_before[n] * (1.0 - 0.9)
+        assert float((p.detach() - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), n
+        assert np.abs(p.detach().cpu().numpy() - g[f'ema.{n}']).max() <= 1e-6 * max(1.0, float(np.abs(g[f'ema.{n}']).max())), n
+    em = w.model_m._engine                                    # the twin's bf16 shadow follows its fp32 arena
+    assert float((em.arena.pbf.float() - em.arena.p32).abs().max()) <= float(em.arena.p32.abs().max()) / 128
+    w.eval()
+    with torch.no_grad():
+        vloss, _ = w.val_step(images, labels)
+    assert abs(float(vloss) - float(g['val_loss'])) <= 1e-2 * float(g['val_loss'])
+    w.copy_momentum_params()
+    for (n, p), (_, pm) in zip(w.model.named_parameters(), w.model_m.named_parameters()):
+        assert torch.equal(p, pm), n
+    # model_m never receives gradients and stays out of the optimizer (trainer.py:158-159 filters 'model_m.')
+    assert all(p.grad is None for p in w.model_m.parameters())
+
+
+def test_mlm_corruption_inputs():
+    """The decoder-input kernel (BOS shift, ignored -> EOS, MLM corruption) against the oracle fed the kernel's own draws
+    (rng.mlm_draws), the corruption statistics, reproducibility, and the clean path == the reference's shifted inputs."""
+    from image2text_amd import ops, rng
+    from oracle import reference_model as orc
+    V, B, L = 50258, 64, 64
+    _, labels = synthetic_batch(B, 32, L, V - 1, seed=8)
+    lab = labels.to(dev())
+    ids = torch.empty_like(lab)
+    ops.lm_inputs(lab, ids, B, L, V - 2, V - 2, None, V, -100)
+    assert torch.equal(ids.cpu(), orc.shifted_inputs(labels, V - 2, V - 2)[0])
+    seed = 0xC0FFEE1234567
+    ops.lm_inputs(lab, ids, B, L, V - 2, V - 2, V - 1, V, -100, mask_fraction=0.3, random_fraction=0.4, seed=seed)
+    u_mask, u_rand, num = rng.mlm_draws(seed, B * L)
+    r_ids = ((num * V) >> 32).view(B, L)
+    want = orc.lm_inputs(labels, V - 2, V - 2, -100, mask_id=V - 1, mask_fraction=0.3, random_fraction=0.4, u_mask=u_mask.view(B, L),
+                         u_rand=u_rand.view(B, L), r_ids=r_ids)
+    assert torch.equal(ids.cpu(), want)
+    live = (labels != -100)[:, :-1]
+    changed = (ids.cpu()[:, 1:] != torch.where(labels != -100, labels, torch.full_like(labels, V - 2))[:, :-1]) & live
+    n_live = int(live.sum())
+    frac = float(changed.sum()) / n_live
+    assert abs(frac - 0.3) < 4 * (0.3 * 0.7 / n_live) ** 0.5 + 1e-3, frac
+    masked = (ids.cpu()[:, 1:] == V - 1) & live
+    assert abs(float(masked.sum()) / max(1, int(changed.sum())) - 0.6) < 0.08
+    ids2 = torch.empty_like(lab)
+    ops.lm_inputs(lab, ids2, B, L, V - 2, V - 2, V - 1, V, -100, mask_fraction=0.3, random_fraction=0.4, seed=seed)
+    assert torch.equal(ids, ids2)
+    ops.lm_inputs(lab, ids2, B, L, V - 2, V - 2, V - 1, V, -100, mask_fraction=0.3, random_fraction=0.4, seed=seed + 1)
+    assert not torch.equal(ids, ids2)
+
+
+def test_mlm_train_step_runs_and_val_is_clean():
+    """mask_fraction > 0: training steps see corrupted inputs (loss differs from the clean step and from step to step), validation
+    steps never do (wrapper.py:161,183-185)."""
+    from types import SimpleNamespace
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    tok = SimpleNamespace(eos_token_id=V - 1, bos_token_id=V - 1, mask_token_id=V - 2, vocab_size=V)
+    images, labels = synthetic_batch(8, 32, 16, V - 2, seed=12)
+    images, labels = images.to(dev()), labels.to(dev())
+    losses = {}
+    for tag, kw in (('clean', {}), ('mlm', dict(mask_fraction=0.5, random_mask_fraction=0.2))):
+        w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(**kw), ignore_index=-100)
+        det_init_(w.model, seed=0)
+        w = w.to(dev()).train()
+        torch.manual_seed(3)
+        l1, _ = w.train_step(images, labels)
+        l1.backward()
+        l2, _ = w.train_step(images, labels)
+        w.eval()
+        with torch.no_grad():
+            v, _ = w.val_step(images, labels)
+        losses[tag] = (float(l1.detach()), float(l2.detach()), float(v))
+    assert abs(losses['clean'][0] - losses['clean'][1]) < 1e-4 * losses['clean'][0]
+    assert abs(losses['mlm'][0] - losses['clean'][0]) > 1e-3 and abs(losses['mlm'][0] - losses['mlm'][1]) > 1e-4
+    assert abs(losses['mlm'][2] - losses['clean'][2]) < 1e-4 * losses['clean'][2]

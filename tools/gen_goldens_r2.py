@@ -2,7 +2,7 @@
 """Round-2 golden fixtures, produced by RUNNING THE REFERENCE (container-only tooling; same import recipe as
 tools/gen_goldens.py, whose fixtures this script leaves untouched).
 
-    python tools/gen_goldens_r2.py [snradam] [greedy64] [trunc] [sampling]      # default: all
+    python tools/gen_goldens_r2.py [snradam] [greedy64] [trunc] [sampling] [trainer_extras]      # default: all
 
   snradam.npz           reference models/optimizer.py::SNRAdam: 6 steps on 3 small tensors, two param groups with different
                         lr / weight decay -> parameters after every step
@@ -157,12 +157,72 @@ def gen_sampling():
     np.savez_compressed(os.path.join(OUT, 'tiny_sampling.npz'), **out)
 
 
+def gen_trainer_extras():
+    """tiny_moco.npz: train_step with momentum distillation (moco_momentum 0.9, moco_alpha 0.4, training_temperature 1.3), twin at
+    DIFFERENT weights than the model (det_init_ seed 1 vs 0) so that the soft targets matter: loss, every gradient, and the twin's
+    parameters after the step's EMA update.  tiny_mlm.npz: the decoder inputs the reference builds with mask_fraction 0.3 /
+    random_mask_fraction 0.4 when torch.rand_like / randint_like are replaced by recorded draws (the draws are stored)."""
+    from types import SimpleNamespace
+    from image2text_amd.synth import det_init_, synthetic_batch, tiny_config
+    from configs.trainer import TrainerWrapperConfig as RefTrainerCfg
+    from training.wrapper import ModelTrainerWrapper as RefWrapper
+    cfg = tiny_config(dropout=0.0)
+    V = cfg.decoder_config.vocab_size
+    tok = SimpleNamespace(eos_token_id=V - 1, bos_token_id=V - 1, mask_token_id=V - 2, vocab_size=V)
+    images, labels = synthetic_batch(4, 32, 16, V, seed=31)
+    # ---- momentum distillation
+    w = RefWrapper(to_ref_config(cfg), tok, RefTrainerCfg(moco_momentum=0.9, moco_alpha=0.4, training_temperature=1.3), ignore_index=-100)
+    det_init_(w.model, seed=0)
+    det_init_(w.model_m, seed=1)
+    w.train()
+    pm_before = {n: p.detach().clone() for n, p in w.model_m.named_parameters()}
+    loss, _ = w.train_step(images, labels)
+    loss.backward()
+    out = {'images': images.numpy(), 'labels': labels.numpy(), 'loss': np.float32(loss.item())}
+    for n, p in w.model.named_parameters():
+        out[f'grad.{n}'] = p.grad.numpy().copy()
+    for n, p in w.model_m.named_parameters():
+        out[f'ema.{n}'] = p.detach().numpy().copy()
+        assert torch.allclose(p.detach(), 0.9 * pm_before[n] + 0.1 * dict(w.model.named_parameters())[n].detach(), atol=1e-7)
+    w.eval()
+    with torch.no_grad():
+        vloss, _ = w.val_step(images, labels)               # validation: plain CE, no distillation
+    out['val_loss'] = np.float32(vloss.item())
+    np.savez_compressed(os.path.join(OUT, 'tiny_moco.npz'), **out)
+    print('moco loss', loss.item(), 'val', vloss.item())
+    # ---- MLM corruption: record the decoder inputs
+    w2 = RefWrapper(to_ref_config(cfg), tok, RefTrainerCfg(mask_fraction=0.3, random_mask_fraction=0.4), ignore_index=-100)
+    det_init_(w2.model, seed=0)
+    w2.train()
+    g = torch.Generator().manual_seed(77)
+    u_rand = torch.rand(labels.shape, generator=g)          # first rand_like call: random-vs-mask choice (wrapper.py:165)
+    u_mask = torch.rand(labels.shape, generator=g)          # second: which tokens are corrupted (wrapper.py:172)
+    r_ids = torch.randint(0, V, labels.shape, generator=g)
+    seen = {}
+    real_rand_like, real_randint_like, real_forward = torch.rand_like, torch.randint_like, w2.forward
+    draws = [u_rand, u_mask]
+    torch.rand_like = lambda x, **k: draws.pop(0).to(k.get('dtype', torch.float))
+    torch.randint_like = lambda x, low=0, high=None, **k: r_ids.clone()
+
+    def spy(images, input_ids, attn_msk=None):
+        seen['ids'] = input_ids.clone()
+        return real_forward(images, input_ids, attn_msk)
+    w2.forward = spy
+    try:
+        loss2, _ = w2.train_step(images, labels)
+    finally:
+        torch.rand_like, torch.randint_like = real_rand_like, real_randint_like
+    np.savez_compressed(os.path.join(OUT, 'tiny_mlm.npz'), labels=labels.numpy(), u_rand=u_rand.numpy(), u_mask=u_mask.numpy(),
+                        r_ids=r_ids.numpy(), ids=seen['ids'].numpy(), loss=np.float32(loss2.item()), images=images.numpy())
+    print('mlm corrupted positions', int((seen['ids'][:, 1:] != torch.where(labels != -100, labels, torch.full_like(labels, V - 1))[:, :-1]).sum()))
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    want = sys.argv[1:] or ['snradam', 'greedy64', 'trunc', 'sampling']
+    want = sys.argv[1:] or ['snradam', 'greedy64', 'trunc', 'sampling', 'trainer_extras']
     for name in want:
         t0 = time.time()
         globals()[f'gen_{name}']()
