@@ -5,8 +5,9 @@ Mirror of the reference's YAML/pydantic surface (reference: configs/models.py:9-
 names and their defaults are the on-disk format and therefore identical to the reference; everything else
 (validation helpers, ``hot_path_supported``) is ours.
 
-Only the dense from-scratch families are executed by the HIP hot path; the other
-families parse fine but ``Encoder.from_config`` / ``Decoder.from_config`` refuse them loudly.
+The from-scratch families (dense nano-224 and the multi-query / MoE / sparse nano-mini family) are executed by the
+HIP hot path; the pretrained families parse fine but ``Encoder.from_config`` /
+``Decoder.from_config`` refuse them loudly.
 """
 from enum import Enum
 from typing import List, Optional, Tuple, Union
@@ -29,7 +30,7 @@ class MLPConfig(BaseModel):
 
 
 class MoEConfig(BaseModel):
-    """Mixture-of-experts rotator (reference configs/models.py:21-26). Out of hot-path scope."""
+    """Mixture-of-experts rotator (reference configs/models.py:21-26)."""
     num_experts: int
     proj_features: int
     ff_mult_factor: float
@@ -63,18 +64,28 @@ class TransformerConfig(BaseModel):
     attn_config: SelfAttentionConfig
 
     def hot_path_unsupported_reason(self) -> Optional[str]:
-        """None when the dense HIP path can run this block, else a human-readable reason."""
-        if not isinstance(self.rotator_config, MLPConfig):
-            return 'MoE rotator (SURVEY.md 8(f) next #2)'
-        if self.attn_config.attn_type != SelfAttentionType.MULTI_HEAD:
-            return 'multi-query attention (SURVEY.md 8(f) next #2)'
-        if self.is_sparse_attn:
-            return 'sparse token-subset attention (SURVEY.md 8(f) next #2)'
-        if self.attn_config.n_embd % self.attn_config.n_head != 0:
+        """None when the HIP path can run this block, else a human-readable reason."""
+        ac = self.attn_config
+        if ac.n_embd % ac.n_head != 0:
             return 'n_embd not divisible by n_head'
-        if self.attn_config.n_embd // self.attn_config.n_head != 64:
-            return 'head_dim != 64 (the gfx950 attention kernels are built for 64-wide heads)'
+        hd = ac.n_embd // ac.n_head
+        if hd not in (16, 32, 64, 128):
+            return 'head_dim must be 16, 32, 64 or 128'
+        if self.is_sparse_attn and self.max_block_size is None:
+            return 'need to specify max_block_size for sparse attention'       # reference layers.py:547
+        if isinstance(self.rotator_config, MoEConfig):
+            rc = self.rotator_config
+            if rc.top_k > rc.num_experts:
+                return 'top_k > num_experts'
+            if rc.num_experts * (rc.proj_features + 1) > 256:
+                return 'num_experts * (proj_features + 1) > 256 (the fused expert GEMM holds every expert in one K panel)'
         return None
+
+    @property
+    def is_family(self) -> bool:
+        """True for blocks that run on the generalised (nano-mini family) block path instead of the dense one."""
+        return (self.attn_config.attn_type != SelfAttentionType.MULTI_HEAD or self.is_sparse_attn
+                or not isinstance(self.rotator_config, MLPConfig) or self.attn_config.n_embd != 64 * self.attn_config.n_head)
 
 
 class ImageInputSpec(BaseModel):

@@ -43,6 +43,10 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def _ff_mult(rotator) -> float:
+    return rotator.ff_mult if hasattr(rotator, 'ff_mult') else rotator.ff_mult_factor
+
+
 def _dp_rank() -> int:
     import torch.distributed as dist
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
@@ -171,13 +175,13 @@ class HotPath:
         eac, dac = ecfg.transformer_config.attn_config, dcfg.transformer_config.attn_config
         self.enc = SimpleNamespace(d=eac.n_embd, H=eac.n_head, L=ecfg.n_layer, ncls=ecfg.n_cls,
                                    P2=ecfg.num_patches ** 2, causal=ecfg.transformer_config.is_causal,
-                                   ff=int(ecfg.transformer_config.rotator_config.ff_mult * eac.n_embd),
+                                   ff=int(_ff_mult(ecfg.transformer_config.rotator_config) * eac.n_embd),
                                    dropout=eac.dropout, attn_dropout=eac.attn_dropout,
                                    k=ecfg.feature_extractor_kernel_size[0])
         self.dec = SimpleNamespace(d=dac.n_embd, H=dac.n_head, L=dcfg.n_layer, V=dcfg.vocab_size,
                                    Vp=_round_up(dcfg.vocab_size, 8), block=dcfg.block_size,
                                    causal=dcfg.transformer_config.is_causal,
-                                   ff=int(dcfg.transformer_config.rotator_config.ff_mult * dac.n_embd),
+                                   ff=int(_ff_mult(dcfg.transformer_config.rotator_config) * dac.n_embd),
                                    dropout=dac.dropout, attn_dropout=dac.attn_dropout)
         gates = list(ecfg.feature_extractor_gate_sizes or [])
         chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]

@@ -7,10 +7,11 @@ The module tree, attribute names, parameter shapes and initial distributions mat
 import math
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
-from ..configs.models import MLPConfig, SelfAttentionConfig, SelfAttentionType, TransformerConfig
+from ..configs.models import MLPConfig, MoEConfig, SelfAttentionConfig, SelfAttentionType, TransformerConfig
 
 _STANDALONE = ('{} is a parameter container in image2text_amd: its arithmetic runs inside the fused HIP path '
                '(VisionEncoderDecoder / Encoder / Decoder forward), not as a standalone torch module')
@@ -67,12 +68,79 @@ class MultiHeadAttention(_Container):
         self.n_head, self.n_embd, self.dropout = config.n_head, config.n_embd, config.dropout
 
 
+class MultiQueryAttention(_Container):
+    """q_proj (d -> d), kv_proj (d -> 2 d/h: ONE key/value head shared by all query heads) and out_proj (d -> d)
+    (reference layers.py:391-403)."""
+
+    def __init__(self, config: SelfAttentionConfig):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.config = config
+        self.q_proj = nn.Linear(config.n_embd, config.n_embd, bias=config.bias)
+        self.kv_proj = nn.Linear(config.n_embd, 2 * config.n_embd // config.n_head, bias=config.bias)
+        self.out_proj = nn.Linear(config.n_embd, config.n_embd, bias=config.bias)
+        self.n_head, self.n_embd, self.dropout = config.n_head, config.n_embd, config.dropout
+
+
 class SelfAttention:
     @classmethod
     def from_config(cls, config: SelfAttentionConfig):
         if config.attn_type == SelfAttentionType.MULTI_HEAD:
             return MultiHeadAttention(config)
-        raise NotImplementedError('multi_query attention is outside the HIP hot path (SURVEY.md 8(f) next #2)')
+        if config.attn_type == SelfAttentionType.MULTI_QUERY:
+            return MultiQueryAttention(config)
+        raise ValueError('unknown self attn implementation!')
+
+
+class MLP(_Container):
+    """Linear [GELU(tanh) Linear]* -- Sequential slots 0,2,4,... hold the Linears (reference layers.py:222-255); here only as
+    the expert gate of MoELinear (no residual connector)."""
+
+    def __init__(self, in_features: int, out_features: int, gate_sizes: Optional[Tuple[int, ...]] = None, bias: bool = True):
+        super().__init__()
+        blocks, prev = [], in_features
+        for width in (gate_sizes or []):
+            blocks += [nn.Linear(prev, width, bias=bias), nn.GELU(approximate='tanh')]
+            prev = width
+        blocks.append(nn.Linear(prev, out_features, bias=bias))
+        self.add_residual_connection = False
+        self.model = nn.Sequential(*blocks)
+        self.residual_connector = nn.Identity()
+
+
+class _MoEUnit(_Container):
+    """One low-rank expert: l1 (in -> proj), GELU(tanh), l2 (proj -> out), both always biased (reference layers.py:285-298)."""
+
+    def __init__(self, in_features: int, out_features: int, proj_features: int):
+        super().__init__()
+        self.l1 = nn.Linear(in_features, proj_features)
+        self.l2 = nn.Linear(proj_features, out_features)
+        self.activation = nn.GELU(approximate='tanh')
+
+
+class MoELinear(_Container):
+    """softmax(gate(x) / sqrt(in)) -> top-k experts, y = sum_k w_k expert_k(x); the weights are NOT renormalised
+    (reference layers.py:301-346)."""
+
+    def __init__(self, in_features: int, out_features: int, proj_features: int, num_experts: int, bias: bool = True, top_k: int = 1,
+                 gate_sizes: Optional[Tuple[int, ...]] = None):
+        super().__init__()
+        self._in_features, self._out_features = in_features, out_features
+        self.expert_gates = MLP(in_features, num_experts, gate_sizes=gate_sizes, bias=bias)
+        self.experts = nn.ModuleList([_MoEUnit(in_features, out_features, proj_features) for _ in range(num_experts)])
+        self.top_k = top_k
+
+
+class _MoEMLP(_Container):
+    """c_fc / c_proj as MoELinear with GELU(tanh) between and dropout after (reference layers.py:489-518)."""
+
+    def __init__(self, n_embd: int, bias: bool, dropout: float, config: MoEConfig):
+        super().__init__()
+        hidden = int(config.ff_mult_factor * n_embd)
+        kw = dict(proj_features=config.proj_features, num_experts=config.num_experts, bias=bias, top_k=config.top_k,
+                  gate_sizes=config.gate_sizes)
+        self.c_fc = MoELinear(n_embd, hidden, **kw)
+        self.c_proj = MoELinear(hidden, n_embd, **kw)
 
 
 class _MLP(_Container):
@@ -99,8 +167,9 @@ class _CrossAttentionParams(_Container):
 
 
 class TransformerBlock(_Container):
-    """Pre-LN block: x += attn(ln_1 x); x += cross(ln_3 x, enc); x += mlp(ln_2 x); normalize_gradients(x)
-    (reference layers.py:521-608, dense branch only)."""
+    """Pre-LN block: x += attn(ln_1 x); x += cross(ln_3 x, enc); x += mlp(ln_2 x); normalize_gradients(x).  With
+    ``is_sparse_attn`` the block runs on a fixed random subset of the positions and every other position takes
+    x + null_connector(x) (reference layers.py:521-614)."""
 
     def __init__(self, config: TransformerConfig, seed: Optional[int] = None, n_cls: int = 0):
         super().__init__()
@@ -112,12 +181,28 @@ class TransformerBlock(_Container):
         self.ln_1 = LayerNorm(ac.n_embd, bias=ac.bias)
         self.attn = SelfAttention.from_config(ac)
         self.ln_2 = LayerNorm(ac.n_embd, bias=ac.bias)
-        self.mlp = _MLP(ac.n_embd, ac.bias, ac.dropout, config.rotator_config)
+        if isinstance(config.rotator_config, MLPConfig):
+            self.mlp = _MLP(ac.n_embd, ac.bias, ac.dropout, config.rotator_config)
+        elif isinstance(config.rotator_config, MoEConfig):
+            self.mlp = _MoEMLP(ac.n_embd, ac.bias, ac.dropout, config.rotator_config)
+        else:
+            raise ValueError('Unknown rotator config')
         self.is_cross_attn = config.is_cross_attn
         self.cross_attn = _CrossAttentionParams(ac.n_embd) if config.is_cross_attn else nn.Identity()
         self.ln_3 = LayerNorm(ac.n_embd, bias=ac.bias) if config.is_cross_attn else nn.Identity()
-        self.is_sparse = False
-        self.null_connector = nn.Identity()
+        self.is_sparse = config.is_sparse_attn
+        if self.is_sparse:
+            # the kept positions: the first n_cls always, then a seeded permutation of the rest (layers.py:545-559); sorted --
+            # causality inside the subset depends on it
+            n_non_zeros = int(config.sparsity_factor * config.max_block_size)
+            gen = np.random.Generator(np.random.PCG64(seed=seed)) if seed is not None else np.random.default_rng()
+            full_mask = torch.cat((torch.arange(0, n_cls),
+                                   torch.tensor(gen.permutation(config.max_block_size - n_cls) + n_cls, dtype=torch.long)), dim=0)
+            self.register_buffer('input_mask_idx', full_mask[:n_non_zeros].sort().values, persistent=True)
+            self.register_buffer('input_mask_not_idx', full_mask[n_non_zeros:].sort().values, persistent=True)
+            self.null_connector = nn.Linear(ac.n_embd, ac.n_embd, bias=ac.bias)
+        else:
+            self.null_connector = nn.Identity()
 
 
 def init_gpt_weights_(module: nn.Module, n_layer: int):

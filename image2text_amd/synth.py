@@ -20,6 +20,7 @@ import torch
 from .configs.models import (
     ImageInputSpec,
     MLPConfig,
+    MoEConfig,
     SelfAttentionConfig,
     SelfAttentionType,
     TransformerConfig,
@@ -94,6 +95,59 @@ def tiny_config(dropout: float = 0.0, **overrides) -> VisionEncoderDecoderConfig
               dropout=dropout)
     kw.update(overrides)
     return _model_config(**kw)
+
+
+def _family_config(*, img: int, num_patches: int, conv_gates, conv_out: int, kernel: int, n_cls: int, d: int, heads: int,
+                   enc_layers: int, dec_layers: int, block_size: int, vocab: int, dropout: float, experts: int, proj: int, gate_sizes,
+                   enc_ff: float, dec_ff: float, enc_top_k: int, dec_top_k: int, sparsity: float, sparse: bool = True,
+                   attn_type=SelfAttentionType.MULTI_QUERY, moe: bool = True, use_cross_attn: bool = True,
+                   use_soft_prompting: bool = True, skip_alternate_cross_attn: bool = True) -> VisionEncoderDecoderConfig:
+    """The nano-mini topology (reference training_configs/gpu/nano-mini.yaml:17-78): multi-query attention, MoE rotators,
+    sparse token subsets with max_block_size = patches + n_cls (encoder) / block_size + n_cls (decoder)."""
+    P2 = num_patches ** 2
+
+    def rot(ff, top_k):
+        if not moe:
+            return MLPConfig(ff_mult=ff)
+        return MoEConfig(num_experts=experts, proj_features=proj, gate_sizes=tuple(gate_sizes) if gate_sizes else None,
+                         ff_mult_factor=ff, top_k=top_k)
+
+    def tf(bias, ff, top_k, causal, cross, max_block):
+        return TransformerConfig(
+            rotator_config=rot(ff, top_k), is_causal=causal, is_cross_attn=cross, max_block_size=max_block,
+            is_sparse_attn=sparse, sparsity_factor=sparsity,
+            attn_config=SelfAttentionConfig(attn_dropout=dropout, bias=bias, dropout=dropout, n_head=heads, n_embd=d, attn_type=attn_type))
+
+    enc = VisionTransformerEncoderConfig(
+        transformer_config=tf(False, enc_ff, enc_top_k, False, False, P2 + n_cls),
+        enable_gradient_checkpointing=False, input=ImageInputSpec(n_channels=3, width=img, height=img), n_layer=enc_layers,
+        n_cls=n_cls, num_patches=num_patches, n_channels=conv_out, feature_extractor_gate_sizes=tuple(conv_gates),
+        feature_extractor_kernel_size=(kernel, kernel))
+    dec = TransformerDecoderConfig(
+        transformer_config=tf(True, dec_ff, dec_top_k, True, True, block_size + n_cls),
+        n_layer=dec_layers, block_size=block_size, vocab_size=vocab, enable_gradient_checkpointing=False,
+        skip_alternate_cross_attn=skip_alternate_cross_attn)
+    return VisionEncoderDecoderConfig(vision_encoder_config=enc, decoder_config=dec, use_cross_attn=use_cross_attn,
+                                      use_soft_prompting=use_soft_prompting, no_repeat_n_grams=(2, 3, 4, 5))
+
+
+def nano_mini_config(dropout: float = 0.0) -> VisionEncoderDecoderConfig:
+    """reference training_configs/gpu/nano-mini.yaml: 12x1024 ViT over 128x128 images (256 flat patches of 2048 + 64 CLS) and a
+    12x1024 decoder (block 256, vocab 50258); 8 query heads of 128 on one shared K/V head, 4 experts of rank 16 (top-2 in the
+    encoder, top-1 in the decoder), half of the positions attended per layer."""
+    return _family_config(img=128, num_patches=16, conv_gates=(8, 16), conv_out=32, kernel=6, n_cls=64, d=1024, heads=8,
+                          enc_layers=12, dec_layers=12, block_size=256, vocab=50258, dropout=dropout, experts=4, proj=16,
+                          gate_sizes=(32,), enc_ff=2, dec_ff=4, enc_top_k=2, dec_top_k=1, sparsity=0.5)
+
+
+def mini_config(dropout: float = 0.0, **overrides) -> VisionEncoderDecoderConfig:
+    """nano-mini at fixture size: 32x32 images, 16 flat patches of 512 + 8 CLS, 2+2 layers of width 256 (2 heads of 128),
+    block 40, vocab 384."""
+    kw = dict(img=32, num_patches=4, conv_gates=(4, 8), conv_out=8, kernel=6, n_cls=8, d=256, heads=2, enc_layers=2, dec_layers=2,
+              block_size=40, vocab=384, dropout=dropout, experts=4, proj=16, gate_sizes=(32,), enc_ff=2, dec_ff=4, enc_top_k=2,
+              dec_top_k=1, sparsity=0.5)
+    kw.update(overrides)
+    return _family_config(**kw)
 
 
 def fake_tokenizer(vocab_size: int, eos: Optional[int] = None):
@@ -178,4 +232,19 @@ def det_init_(module: torch.nn.Module, seed: int = 0, style: str = 'stress') -> 
         else:
             x = 0.02 * x
         p.copy_(x.to(p.device, p.dtype))
+    return module
+
+
+@torch.no_grad()
+def sharpen_gates_(module: torch.nn.Module, gain: float = 4.0) -> torch.nn.Module:
+    """Scale the last Linear of every MoE expert gate by gain * sqrt(in_features).  MoELinear divides its gate logits by
+    sqrt(in_features) (reference layers.py:335), so freshly initialised gates are uniform to three decimals and the top-k choice
+    is decided by noise; with this the logits differ by O(1) and the fixtures exercise a decisive, input-dependent routing.
+    Works on the reference's modules and on ours (same attribute names)."""
+    for m in module.modules():
+        if hasattr(m, 'expert_gates') and hasattr(m, '_in_features'):
+            last = m.expert_gates.model[-1]
+            last.weight.mul_(gain * m._in_features ** 0.5)
+            if last.bias is not None:
+                last.bias.mul_(gain * m._in_features ** 0.5)
     return module

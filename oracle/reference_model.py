@@ -150,25 +150,119 @@ def gelu_mlp(sd: SD, p: str, x, dropout=0.0, training=False, plan=None, layer=0)
     return _planned(plan.get(layer, 'mlp'), out) if plan is not None else _drop(out, dropout, training)
 
 
+def multi_query_attention(sd: SD, p: str, x, n_head: int, add_mask, dropout=0.0, attn_dropout=0.0, training=False, plan=None, layer=0):
+    """layers.py:391-430 MultiQueryAttention: q_proj for all heads, ONE key/value head from kv_proj shared by every query
+    head, the same per-token dropout multipliers as the multi-head form, SDPA, out_proj."""
+    B, T, C = x.shape
+    hd = C // n_head
+    q = F.linear(x, sd[f'{p}.q_proj.weight'], _get(sd, f'{p}.q_proj.bias'))
+    k, v = F.linear(x, sd[f'{p}.kv_proj.weight'], _get(sd, f'{p}.kv_proj.bias')).split(hd, dim=-1)
+    ones = torch.ones((B, 1, T, 1), dtype=x.dtype)
+    if plan is not None:      # HIP-path masks: sections 0/1/2 = q/k/v token multipliers
+        e = plan.get(layer, 'qkv')
+        q_do, k_do, v_do = (_planned(e, ones, t) for t in range(3))
+    else:
+        k_do, q_do, v_do = (_drop(ones, attn_dropout, training) for _ in range(3))   # layers.py:414-416 order
+    qh = q_do * q.view(B, T, n_head, hd).transpose(1, 2)
+    kh = k_do * k.view(B, T, 1, hd).transpose(1, 2)
+    vh = v_do * v.view(B, T, 1, hd).transpose(1, 2)
+    y = softmax_attention(qh, kh, vh, add_mask, dropout, training, planned=plan.get(layer, 'sdpa') if plan is not None else None)
+    y = y.transpose(1, 2).contiguous().view(B, T, C)
+    out = F.linear(y, sd[f'{p}.out_proj.weight'], _get(sd, f'{p}.out_proj.bias'))
+    return _planned(plan.get(layer, 'resid'), out) if plan is not None else _drop(out, dropout, training)
+
+
+def gate_mlp(sd: SD, p: str, x):
+    """layers.py:222-255 MLP without residual connector: Linear [GELU(tanh) Linear]* at Sequential slots 0, 2, 4, ..."""
+    i = 0
+    while f'{p}.model.{i}.weight' in sd:
+        if i > 0:
+            x = F.gelu(x, approximate='tanh')
+        x = F.linear(x, sd[f'{p}.model.{i}.weight'], _get(sd, f'{p}.model.{i}.bias'))
+        i += 2
+    return x
+
+
+def moe_linear(sd: SD, p: str, x, top_k: int, moe_io: Optional[dict] = None):
+    """layers.py:301-346 MoELinear: gates = softmax(gate_mlp(x) / sqrt(in)); the top-k gate VALUES (not renormalised) weight the
+    outputs of the chosen low-rank experts l2(gelu(l1(x))).
+
+    moe_io (tests): {'forced': {site: LongTensor [N, top_k]}} replaces the top-k choice at a site by the given experts (their
+    weights are still this function's gate values) -- the HIP path's bf16 gate can pick differently at a near-tie, and the
+    comparison is then made on the same choice; {'record': {}} receives (gates [N, E], indices [N, top_k]) per site."""
+    shape = x.shape
+    in_f = shape[-1]
+    xf = x.reshape(-1, in_f)
+    gates = (gate_mlp(sd, f'{p}.expert_gates', xf) / math.sqrt(in_f)).softmax(dim=-1)
+    w, idx = torch.topk(gates, top_k, dim=-1)
+    if moe_io is not None:
+        forced = moe_io.get('forced', {}).get(p)
+        if forced is not None:
+            idx = forced.to(torch.long)
+            w = gates.gather(1, idx)
+        if 'record' in moe_io:
+            moe_io['record'][p] = (gates.detach().clone(), idx.clone())
+    E = gates.size(-1)
+    outs = torch.stack([F.linear(F.gelu(F.linear(xf, sd[f'{p}.experts.{e}.l1.weight'], sd[f'{p}.experts.{e}.l1.bias']), approximate='tanh'),
+                                 sd[f'{p}.experts.{e}.l2.weight'], sd[f'{p}.experts.{e}.l2.bias']) for e in range(E)], dim=1)   # [N, E, out]
+    sel = outs.gather(1, idx.unsqueeze(-1).expand(-1, -1, outs.size(-1)))
+    y = (sel * w.unsqueeze(-1)).sum(dim=1)
+    return y.view(*shape[:-1], -1)
+
+
+def moe_mlp(sd: SD, p: str, x, top_k: int, dropout=0.0, training=False, plan=None, layer=0, moe_io=None):
+    """layers.py:489-518 -- MoELinear d->ff d, GELU(tanh), MoELinear ff d->d, dropout."""
+    h = F.gelu(moe_linear(sd, f'{p}.c_fc', x, top_k, moe_io), approximate='tanh')
+    out = moe_linear(sd, f'{p}.c_proj', h, top_k, moe_io)
+    return _planned(plan.get(layer, 'mlp'), out) if plan is not None else _drop(out, dropout, training)
+
+
 def transformer_block(sd: SD, p: str, x, n_head: int, causal: bool, mem, add_mask, dropout=0.0, attn_dropout=0.0,
-                      training=False, plan=None, layer=0):
-    """layers.py:565-608 dense branch: pre-LN residual wiring attn -> (cross) -> mlp, then the gradient normaliser."""
+                      training=False, plan=None, layer=0, top_k=1, moe_io=None, pos_offset=0):
+    """layers.py:565-614: pre-LN residual wiring attn -> (cross) -> mlp, then the gradient normaliser.  The variant is read off
+    the state dict: ``attn.q_proj`` = multi-query, ``mlp.c_fc.experts`` = MoE rotator, ``input_mask_idx`` = sparse block (the
+    block runs on the kept positions < T only; every other position takes x + null_connector(x); <= 1 kept position: the
+    whole input takes the null path, :570-573).  pos_offset (text-segment form, see lm_step_text_segment): x holds positions
+    pos_offset .. pos_offset + T - 1 of a longer sequence whose earlier rows it never attends to."""
+    x_orig, idx, not_idx = x, None, None
+    if f'{p}.input_mask_idx' in sd:
+        T = pos_offset + x_orig.size(1)
+        idx = sd[f'{p}.input_mask_idx'][sd[f'{p}.input_mask_idx'] < T]
+        null = lambda t: F.linear(t, sd[f'{p}.null_connector.weight'], _get(sd, f'{p}.null_connector.bias'))
+        if idx.numel() <= 1:
+            return x_orig + null(x_orig)
+        not_idx = sd[f'{p}.input_mask_not_idx'][sd[f'{p}.input_mask_not_idx'] < T]
+        idx, not_idx = idx[idx >= pos_offset] - pos_offset, not_idx[not_idx >= pos_offset] - pos_offset
+        if idx.numel() == 0:
+            return x_orig + null(x_orig)
+        x = x_orig[:, idx]
+        add_mask = add_mask[..., idx, :][..., idx] if add_mask is not None else None
     if causal:
         L = x.size(-2)
         tri = torch.ones((L, L), dtype=torch.bool).tril()
         cm = torch.zeros((L, L), dtype=x.dtype).masked_fill(~tri, NEG_INF)[None, None]
         add_mask = cm if add_mask is None else add_mask + cm
-    x = x + self_attention(sd, f'{p}.attn', layer_norm(x, sd[f'{p}.ln_1.weight'], _get(sd, f'{p}.ln_1.bias')),
-                           n_head, add_mask, dropout, attn_dropout, training, plan, layer)
+    attn = multi_query_attention if f'{p}.attn.q_proj.weight' in sd else self_attention
+    x = x + attn(sd, f'{p}.attn', layer_norm(x, sd[f'{p}.ln_1.weight'], _get(sd, f'{p}.ln_1.bias')),
+                 n_head, add_mask, dropout, attn_dropout, training, plan, layer)
     if mem is not None:
         if f'{p}.cross_attn.in_proj_weight' not in sd:
             raise ValueError('Model not configured for cross attn inputs!!!')        # layers.py:598-599
         x = x + cross_attention(sd, f'{p}.cross_attn',
                                 layer_norm(x, sd[f'{p}.ln_3.weight'], _get(sd, f'{p}.ln_3.bias')), mem, n_head,
                                 dropout, training, plan, layer)
-    x = x + gelu_mlp(sd, f'{p}.mlp', layer_norm(x, sd[f'{p}.ln_2.weight'], _get(sd, f'{p}.ln_2.bias')), dropout,
-                     training, plan, layer)
-    return _UnitNormGrad.apply(x)
+    h2 = layer_norm(x, sd[f'{p}.ln_2.weight'], _get(sd, f'{p}.ln_2.bias'))
+    if f'{p}.mlp.c_fc.experts.0.l1.weight' in sd:
+        x = x + moe_mlp(sd, f'{p}.mlp', h2, top_k, dropout, training, plan, layer, moe_io)
+    else:
+        x = x + gelu_mlp(sd, f'{p}.mlp', h2, dropout, training, plan, layer)
+    x = _UnitNormGrad.apply(x)
+    if idx is None:
+        return x
+    out = torch.zeros_like(x_orig)
+    out[:, idx] = x
+    out[:, not_idx] = x_orig[:, not_idx] + null(x_orig[:, not_idx])
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -179,7 +273,31 @@ def _sub(sd: SD, prefix: str) -> SD:
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def vit_encoder(sd: SD, cfg, images, training=False, plan=None):
+class _PrefixedDict(dict):
+    """View of a dict whose keys are stored with a prefix (moe_io sites are keyed by full parameter paths)."""
+
+    def __init__(self, base: dict, prefix: str):
+        super().__init__()
+        self.base, self.prefix = base, prefix
+
+    def get(self, k, default=None):
+        return self.base.get(self.prefix + k, default)
+
+    def __setitem__(self, k, v):
+        self.base[self.prefix + k] = v
+
+
+def _moe_sub(moe_io, prefix: str):
+    if moe_io is None:
+        return None
+    return {k: _PrefixedDict(v, prefix) for k, v in moe_io.items()}
+
+
+def _top_k(tcfg) -> int:
+    return getattr(tcfg.rotator_config, 'top_k', 1)
+
+
+def vit_encoder(sd: SD, cfg, images, training=False, plan=None, moe_io=None):
     """encoder.py:163-178.  ``sd`` keys are relative to the VisionTransformerEncoder module.
 
     conv stack -> FLAT reshape to (n, P^2, C*ph*pw) (a chunking of the contiguous CHW buffer, not spatial patches,
@@ -199,21 +317,21 @@ def vit_encoder(sd: SD, cfg, images, training=False, plan=None):
     x = _planned(plan.get(0, 'emb'), x) if plan is not None else _drop(x, ac.dropout, training)
     for i in range(cfg.n_layer):
         x = transformer_block(sd, f'transformer.h.{i}', x, ac.n_head, cfg.transformer_config.is_causal, None, None,
-                              ac.dropout, ac.attn_dropout, training, plan, i)
+                              ac.dropout, ac.attn_dropout, training, plan, i, _top_k(cfg.transformer_config), moe_io)
     return layer_norm(x[:, :cfg.n_cls].contiguous(), sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
 
 
-def encode(sd: SD, cfg, images, training=False, plan=None):
+def encode(sd: SD, cfg, images, training=False, plan=None, moe_io=None):
     """vision_encoder_decoder.py:26-39,58-59: encoder, then the bias-free bridge Linear when the widths differ
     (state-dict keys then carry the nn.Sequential prefixes ``encoder.0.`` / ``encoder.1.``)."""
     if 'encoder.1.weight' in sd:
-        y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training, plan)
+        y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training, plan, _moe_sub(moe_io, 'encoder.0.'))
         return F.linear(y, sd['encoder.1.weight'])
-    return vit_encoder(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images, training, plan)
+    return vit_encoder(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images, training, plan, _moe_sub(moe_io, 'encoder.'))
 
 
 def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=None, attn_msk=None, training=False, plan=None,
-                pos_offset=0):
+                pos_offset=0, moe_io=None):
     """decoder.py:214-256.  ``sd`` keys relative to TransformerDecoder.  Returns (logits, hidden)."""
     assert (idx is None) != (inputs_embeds is None)
     ac = cfg.transformer_config.attn_config
@@ -226,7 +344,8 @@ def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=Non
     for depth in range(cfg.n_layer):
         mem = cross_attn_embeds if (depth % 2 == 0 or not cfg.skip_alternate_cross_attn) else None
         x = transformer_block(sd, f'transformer.h.{depth}', x, ac.n_head, cfg.transformer_config.is_causal, mem,
-                              attn_msk, ac.dropout, ac.attn_dropout, training, plan, depth)
+                              attn_msk, ac.dropout, ac.attn_dropout, training, plan, depth, _top_k(cfg.transformer_config), moe_io,
+                              pos_offset)
     x = layer_norm(x, sd['transformer.ln_f.weight'], _get(sd, 'transformer.ln_f.bias'))
     return F.linear(x, sd['transformer.wte.weight']), x          # lm_head is tied to wte (decoder.py:189-204)
 
@@ -262,11 +381,12 @@ def _mask_to_additive(allowed):
     return filled
 
 
-def forward(sd: SD, cfg, images, ids, attn_msk=None, encoder_output=None, training=False):
+def forward(sd: SD, cfg, images, ids, attn_msk=None, encoder_output=None, training=False, moe_io=None):
     """VisionEncoderDecoder.forward -> (encoder_output, logits, hidden_state)."""
     dcfg = cfg.decoder_config
+    dio = _moe_sub(moe_io, 'decoder.')
     if encoder_output is None:
-        encoder_output = encode(sd, cfg, images, training)
+        encoder_output = encode(sd, cfg, images, training, moe_io=moe_io)
     bs, ncls, _ = encoder_output.shape
     L = ids.size(-1)
     allowed = torch.ones((L, L), dtype=torch.bool).tril()[None, None]
@@ -283,26 +403,26 @@ def forward(sd: SD, cfg, images, ids, attn_msk=None, encoder_output=None, traini
         add = add[..., :dcfg.block_size, :dcfg.block_size]      # text rows never see prompt columns
         logits, hidden = gpt_decoder(dsd, dcfg, inputs_embeds=emb,
                                      cross_attn_embeds=encoder_output if cfg.use_cross_attn else None,
-                                     attn_msk=add, training=training)
+                                     attn_msk=add, training=training, moe_io=dio)
         return encoder_output, logits[..., ncls:, :], hidden
     add = _mask_to_additive(allowed)                            # (:117-119)
     logits, hidden = gpt_decoder(dsd, dcfg, idx=ids,
                                  cross_attn_embeds=encoder_output if cfg.use_cross_attn else None,
-                                 attn_msk=add, training=training)
+                                 attn_msk=add, training=training, moe_io=dio)
     return encoder_output, logits, hidden
 
 
-def lm_step_text_segment(sd: SD, cfg, images, labels, tokenizer, plans=(None, None), ignore_index=-100, temperature=1.0):
+def lm_step_text_segment(sd: SD, cfg, images, labels, tokenizer, plans=(None, None), ignore_index=-100, temperature=1.0, moe_io=None):
     """The factorisation the HIP path runs (engine.py): because text rows never see prompt columns and prompt-row
     logits are sliced off, the loss only needs the TEXT segment -- a plain causal pass over the ids with the position
     embedding offset by n_cls and cross-attention on the encoder output.  Without dropout this equals ``lm_step``
     (test_oracle_golden); with ``plans`` = (encoder DropPlan, decoder DropPlan) it applies the HIP path's exact masks."""
     ids, _ = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
-    enc = encode(sd, cfg, images, True, plans[0])
+    enc = encode(sd, cfg, images, True, plans[0], moe_io)
     off = enc.size(1) if cfg.use_soft_prompting else 0
     logits, _ = gpt_decoder(_sub(sd, 'decoder.'), cfg.decoder_config, idx=ids,
                             cross_attn_embeds=enc if cfg.use_cross_attn else None, attn_msk=None, training=True,
-                            plan=plans[1], pos_offset=off)
+                            plan=plans[1], pos_offset=off, moe_io=_moe_sub(moe_io, 'decoder.'))
     w = loss_weights(labels, ignore_index)
     ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)) / temperature, labels.reshape(-1), ignore_index=ignore_index,
                          reduction='none')
@@ -337,10 +457,10 @@ def shifted_inputs(labels, bos: int, eos: int, ignore_index=-100):
 
 
 def lm_step(sd: SD, cfg, images, labels, tokenizer, training: bool, ignore_index=-100, temperature=1.0,
-            weight_fn='constant', eos_token_weight=None):
+            weight_fn='constant', eos_token_weight=None, moe_io=None):
     """ModelTrainerWrapper.train_step / val_step for the default trainer config -> scalar loss."""
     ids, msk = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
-    _, logits, _ = forward(sd, cfg, images, ids, msk, training=training)
+    _, logits, _ = forward(sd, cfg, images, ids, msk, training=training, moe_io=moe_io)
     labels = labels[..., :logits.size(-2)]
     logits = logits[..., :labels.size(-1), :]
     w = loss_weights(labels, ignore_index, weight_fn, tokenizer.eos_token_id, eos_token_weight)
