@@ -5,18 +5,19 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libi2t_hip.so')
-SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip']
+SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip',
+           'attention_g.hip', 'family.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 # per-file additions.  attention: keep MFMA accumulators in VGPRs -- the softmax rescales them every key tile, and the
 # AGPR form cost ~110 v_accvgpr_read/write per tile in kernels that are VALU-bound
-EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'attention_g.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'attention_common.h'),
                                                       os.path.join(CSRC, '..', '..', 'include', 'i2t.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -37,7 +38,8 @@ def _build(verbose: bool, force_all: bool = False) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, '..', '..', 'include', 'i2t.h'), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'attention_common.h'), os.path.join(CSRC, '..', '..', 'include', 'i2t.h'),
+               os.path.abspath(__file__)]
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')

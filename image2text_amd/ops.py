@@ -134,6 +134,79 @@ def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causa
              'i2t_attention_bwd')
 
 
+def gq_attention_fwd(q, k, v, o, lse, B, H, Hkv, hd, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0):
+    """Grouped-query attention (include/i2t.h::i2t_gq_attention_fwd): H query heads of width hd on Hkv shared key/value heads."""
+    _need_cuda(q, k, v, o, lse)
+    qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o)
+    _l.check(_lib().i2t_gq_attention_fwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(lse), B, H, Hkv, hd,
+                                         Tq, Tk, int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q)), 'i2t_gq_attention_fwd')
+    return o
+
+
+def gq_attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Hkv, hd, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None,
+                     total_q=0, out_drop=None):
+    _need_cuda(q, k, v, o, do, dq, dk, dv)
+    qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
+    dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
+    _l.check(_lib().i2t_gq_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
+                                         _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Hkv, hd, Tq,
+                                         Tk, int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q), *_drop(out_drop)[1:]),
+             'i2t_gq_attention_bwd')
+
+
+def row_sections_dropout(x, rows, cols, section, drop, key_offset=0):
+    """drop = (2, key, thr, scale): x[m, n] *= multiplier(key + key_offset + n // section, m)  (bf16 [rows, ld], in place)."""
+    if drop is None:
+        return x
+    _need_cuda(x)
+    assert x.dtype == BF16 and x.stride(-1) == 1
+    _l.check(_lib().i2t_row_sections_dropout(_stream(), _p(x), x.stride(-2), rows, cols, section, (int(drop[1]) + key_offset) & 0xFFFFFFFF,
+                                             int(drop[2]), float(drop[3])), 'i2t_row_sections_dropout')
+    return x
+
+
+def gather_rows(src, idx, n, d, out_f32=None, out_bf16=None):
+    _need_cuda(src, idx, out_f32, out_bf16)
+    assert src.dtype == F32 and idx.dtype == torch.int32
+    _l.check(_lib().i2t_gather_rows(_stream(), _p(src), _p(idx), _p(out_f32), _p(out_bf16), n, d), 'i2t_gather_rows')
+
+
+def scatter_rows(src, idx, dst, n, d):
+    _need_cuda(src, idx, dst)
+    assert src.dtype == F32 and dst.dtype == F32 and idx.dtype == torch.int32
+    _l.check(_lib().i2t_scatter_rows(_stream(), _p(src), _p(idx), _p(dst), n, d), 'i2t_scatter_rows')
+
+
+def moe_gate_fwd(U, wg2, bg2, A, gates, wsel, M, E, P, G, top_k, inv_sqrt_in):
+    _need_cuda(U, A, gates, wsel)
+    assert U.dtype == F32 and A.dtype == BF16
+    _l.check(_lib().i2t_moe_gate_fwd(_stream(), _p(U), U.stride(0), _p(wg2), _p(bg2), _p(A), A.stride(0), _p(gates), _p(wsel), M, E, P, G,
+                                     top_k, float(inv_sqrt_in)), 'i2t_moe_gate_fwd')
+
+
+def moe_gate_bwd_blocks(M: int) -> int:
+    return _lib().i2t_moe_gate_bwd_blocks(M)
+
+
+def moe_gate_bwd(dA, U, gates, wsel, wg2, D1, dwg2, dbg2, part_ws, M, E, P, G, top_k, inv_sqrt_in):
+    _need_cuda(dA, U, D1)
+    assert dA.dtype == BF16 and D1.dtype == BF16 and U.dtype == F32
+    _l.check(_lib().i2t_moe_gate_bwd(_stream(), _p(dA), dA.stride(0), _p(U), U.stride(0), _p(gates), _p(wsel), _p(wg2), _p(D1), D1.stride(0),
+                                     _p(dwg2), _p(dbg2), _p(part_ws), M, E, P, G, top_k, float(inv_sqrt_in)), 'i2t_moe_gate_bwd')
+
+
+def moe_pack_w2(l2w, l2b, W, out, E, P):
+    _need_cuda(l2w, l2b, W)
+    assert l2w.dtype == BF16 and l2b.dtype == F32 and W.dtype == BF16
+    _l.check(_lib().i2t_moe_pack_w2(_stream(), _p(l2w), _p(l2b), _p(W), out, E, P, W.stride(0)), 'i2t_moe_pack_w2')
+
+
+def moe_unpack_dw2(dW, gw, gb, out, E, P):
+    _need_cuda(dW, gw, gb)
+    assert dW.dtype == F32 and gw.dtype == F32
+    _l.check(_lib().i2t_moe_unpack_dw2(_stream(), _p(dW), _p(gw), _p(gb), out, E, P, dW.stride(0)), 'i2t_moe_unpack_dw2')
+
+
 def xattn_kv_fused(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, drop=None, cu_q=None, total_q=0):
     """Fused cross-attention forward (include/i2t.h::i2t_xattn_kv_fused): kv = mem . w_kv^T + bias written once, attention of every
     (image, head) out of the projection's accumulators.  q / o: [B, Tq, >= 64 H] views or packed [rows, >= 64 H] with cu_q."""

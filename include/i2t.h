@@ -301,6 +301,54 @@ int i2t_sample_token(void* stream, const float* logits, int ld, int64_t* ids, in
                      const unsigned* seed, float* dist_out, int dist_ld);
 int i2t_advance(void* stream, int* counters, int n, int delta);   /* counters[0..n) += delta */
 
+/* -----------------------------------------------------------------------------------------------------------
+ * The nano-mini block family (reference training_configs/gpu/nano-mini.yaml).
+ *
+ * Grouped-query attention, head_dim 16 / 32 / 64 / 128 (reference models/layers.py:391-430 MultiQueryAttention = H query heads
+ * on ONE shared key/value head, Hkv = 1; Hkv = H is multi-head attention at widths i2t_attention_* does not cover, i.e.
+ * nn.MultiheadAttention with 128-wide heads, layers.py:537-542).  Same conventions as i2t_attention_fwd / _bwd (strides, packed
+ * rows, lse layout, causal rule, dropout index space, out_drop multipliers); query head h starts at column hd*h of q / o / dq,
+ * key/value head h / (H / Hkv) at column hd*(h / (H / Hkv)) of k / v / dk / dv; dk / dv hold the SUM over the query heads that
+ * share a key/value head. */
+int i2t_gq_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                         const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
+                         int B, int H, int Hkv, int hd, int Tq, int Tk, int causal,
+                         unsigned drop_key, unsigned drop_thr, float drop_scale,
+                         const int* cu_q, const int* cu_k, int total_q);
+int i2t_gq_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                         const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
+                         const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,
+                         void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
+                         void* dv, long dv_bs, int dv_rs, int B, int H, int Hkv, int hd, int Tq, int Tk, int causal,
+                         unsigned drop_key, unsigned drop_thr, float drop_scale,
+                         const int* cu_q, const int* cu_k, int total_q,
+                         unsigned out_drop_key, unsigned out_drop_thr, float out_drop_scale);
+/* x[m][n] *= keep(key0 + n / section, m) ? scale : 0 on a bf16 [rows][ld] matrix: the per-token q / k / v multipliers of
+ * layers.py:412-420 on the separate q_proj (section = d, key0 = key) and kv_proj (section = hd, key0 = key + 1) outputs. */
+int i2t_row_sections_dropout(void* stream, void* x, int ld, long rows, int cols, int section, unsigned key0, unsigned thr, float scale);
+
+/* Sparse token subsets (layers.py:570-577, 609-614): out[i][:] = src[idx[i]][:] (fp32 and / or bf16 copy), dst[idx[i]][:] = src[i][:]. */
+int i2t_gather_rows(void* stream, const float* src, const int* idx, float* out_f32, void* out_bf16, long n, int d);
+int i2t_scatter_rows(void* stream, const float* src, const int* idx, float* dst, long n, int d);
+
+/* MoELinear routing (layers.py:330-346).  U f32 [M][ldu] = x [l1_0; ..; l1_{E-1}; gate layer 0]^T + bias: columns [0, E P) the
+ * experts' pre-activations, then G gate-hidden pre-activations (G > 0: gate = Linear-GELU-Linear, wg2 f32 [E][G], bg2 f32 [E] or
+ * null) or the E gate logits themselves (G = 0).  gates = softmax(logits * inv_sqrt_in); the top_k largest are the routing
+ * weights w (not renormalised), all others 0.  A bf16 [M][Kp] = [w_e gelu(U[e P + j]) | w_0 .. w_{E-1} | 0 pad] is the left
+ * operand of y = A W2aug^T (i2t_moe_pack_w2).  gates / wsel f32 [M][E] are kept for the backward pass.
+ * bwd: dA bf16 [M][Kp] = dy W2aug -> D1 bf16 [M][ldd] = dL/dU (pad columns zeroed), dwg2 / dbg2 += the gate's second layer
+ * gradients (fixed summation order; part_ws f32 [i2t_moe_gate_bwd_blocks(M)][E G + E]). */
+int i2t_moe_gate_fwd(void* stream, const float* U, int ldu, const float* wg2, const float* bg2, void* A, int Kp, float* gates,
+                     float* wsel, int M, int E, int P, int G, int top_k, float inv_sqrt_in);
+int i2t_moe_gate_bwd_blocks(int M);
+int i2t_moe_gate_bwd(void* stream, const void* dA, int Kp, const float* U, int ldu, const float* gates, const float* wsel,
+                     const float* wg2, void* D1, int ldd, float* dwg2, float* dbg2, float* part_ws, int M, int E, int P, int G,
+                     int top_k, float inv_sqrt_in);
+/* W2aug bf16 [out][Kp] = [l2_0.weight | .. | l2_{E-1}.weight | l2_0.bias .. l2_{E-1}.bias | 0] from the stacked parameters
+ * l2w bf16 [E][out][P], l2b f32 [E][out]; unpack adds a gradient dW f32 [out][Kp] back onto gw f32 [E][out][P], gb f32 [E][out]. */
+int i2t_moe_pack_w2(void* stream, const void* l2w, const float* l2b, void* W, int out, int E, int P, int Kp);
+int i2t_moe_unpack_dw2(void* stream, const float* dW, float* gw, float* gb, int out, int E, int P, int Kp);
+
 /* hipGraph capture around any sequence of the calls above (replaces the Python loop of
  * vision_encoder_decoder.py:143-180 with one replayed launch per token) */
 int i2t_graph_capture_begin(void* stream);
