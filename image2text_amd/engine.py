@@ -27,13 +27,16 @@ Reference quirks reproduced on purpose (each pinned by a golden fixture):
     every block output, per replica.
 """
 import os
+import re
 import weakref
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import ops, rng
+from .engine_family import FamilyBlocks, family_spec
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -93,6 +96,51 @@ def arena_of(param: torch.Tensor):
     return None
 
 
+_MOE_PARAM = re.compile(r'^(.*)\.experts\.(\d+)\.(l1|l2)\.(weight|bias)$')
+
+
+def _arena_order(named):
+    """Arena order = ``named_parameters()`` order, except that the parameters of one MoELinear (reference layers.py:301-328) are
+    regrouped so that the operands of its two GEMMs are single contiguous views (engine_family.py):
+
+        [experts.*.l1.weight | gate layer 0 weight]   -> one [E P + G, in] matrix: every expert's l1 and the gate's first layer
+        [experts.*.l1.bias   | gate layer 0 bias]     -> its bias vector (a zero pad entry stands in for a bias-free gate)
+        [experts.*.l2.weight] [experts.*.l2.bias]     -> stacked [E, out, P] / [E, out] for the W2aug pack kernel
+        gate layer 2 weight / bias (when the gate has a hidden layer)
+
+    Returns (name, parameter | None, numel, shape) tuples; None marks a pad entry (zeros, never trained: no optimizer group holds
+    it, so the fused optimizers keep it frozen)."""
+    groups, order = {}, []
+    for name, p in named:
+        m = _MOE_PARAM.match(name)
+        key = m.group(1) if m else (name.split('.expert_gates.')[0] if '.expert_gates.model.' in name else None)
+        if key is None:
+            order.append((name, p))
+            continue
+        if key not in groups:
+            groups[key] = {}
+            order.append((key, None))
+        groups[key][name[len(key) + 1:]] = p
+    out = []
+    for name, p in order:
+        if p is not None:
+            out.append((name, p, p.numel(), p.shape))
+            continue
+        g = groups[name]
+        E = 1 + max(int(k.split('.')[1]) for k in g if k.startswith('experts.'))
+        gate0_w = g['expert_gates.model.0.weight']
+        seq = [f'experts.{e}.l1.weight' for e in range(E)] + ['expert_gates.model.0.weight']
+        seq += [f'experts.{e}.l1.bias' for e in range(E)] + ['expert_gates.model.0.bias']
+        seq += [f'experts.{e}.l2.weight' for e in range(E)] + [f'experts.{e}.l2.bias' for e in range(E)]
+        seq += [k for k in g if k.startswith('expert_gates.') and k not in seq]
+        for k in seq:
+            if k in g:
+                out.append((f'{name}.{k}', g[k], g[k].numel(), g[k].shape))
+            else:       # bias-free gate: zeros of the gate's first-layer width keep the bias vector of the fused GEMM contiguous
+                out.append((f'{name}.{k}', None, gate0_w.shape[0], torch.Size([gate0_w.shape[0]])))
+    return out
+
+
 class ParamArena:
     """Flat fp32 parameters + fp32 gradients + bf16 shadow; parameters of ``module`` become views into it."""
 
@@ -102,10 +150,11 @@ class ParamArena:
         self.entries: Dict[str, Tuple[int, int, torch.Size]] = {}
         self.params: Dict[str, torch.nn.Parameter] = {}
         off = 0
-        for name, p in module.named_parameters():          # de-duplicates tied parameters
-            self.entries[name] = (off, p.numel(), p.shape)
-            self.params[name] = p
-            off += _round_up(p.numel(), 8)
+        for name, p, numel, shape in _arena_order(list(module.named_parameters())):          # (tied parameters appear once)
+            self.entries[name] = (off, numel, shape)
+            if p is not None:
+                self.params[name] = p
+            off += _round_up(numel, 8)
         self.total = off
         self.p32 = torch.zeros(off, dtype=F32, device=device)
         self.g32 = torch.zeros(off, dtype=F32, device=device)
@@ -161,7 +210,7 @@ class ParamArena:
                 p.grad = self.G(name)
 
 
-class HotPath:
+class HotPath(FamilyBlocks):
     """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
 
     def __init__(self, model: torch.nn.Module):
@@ -183,6 +232,13 @@ class HotPath:
                                    causal=dcfg.transformer_config.is_causal,
                                    ff=int(_ff_mult(dcfg.transformer_config.rotator_config) * dac.n_embd),
                                    dropout=dac.dropout, attn_dropout=dac.attn_dropout)
+        # the nano-mini block family (multi-query / MoE / sparse / head widths other than 64): engine_family.FamilyBlocks
+        self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
+        self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer)
+        self._sparse_idx = {'enc': self._sparse_sets(model, self.ep, ecfg.n_layer) if self.enc.fam and self.enc.fam.sparse else None,
+                            'dec': self._sparse_sets(model, self.dp, dcfg.n_layer) if self.dec.fam and self.dec.fam.sparse else None}
+        self._moe_cache, self._sub_cache = {}, {}
+        self.moe_trace = None           # tests set a dict: site -> (gate values, routing weights) of every MoELinear forward
         gates = list(ecfg.feature_extractor_gate_sizes or [])
         chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
         self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]
@@ -191,7 +247,8 @@ class HotPath:
                           and chans[0] <= 8 and chans[-1] <= 32 and all(c <= 16 for c in chans[:-1]))
         # non-causal encoder: its output reads only the CLS rows, so the last block runs on those rows (block_fwd_cls);
         # I2T_FULL_LAST_BLOCK=1 keeps the full-row form (A/B runs)
-        self.cls_only_last = (not self.enc.causal) and self.enc.L >= 1 and os.environ.get('I2T_FULL_LAST_BLOCK') != '1'
+        self.cls_only_last = ((not self.enc.causal) and self.enc.L >= 1 and os.environ.get('I2T_FULL_LAST_BLOCK') != '1'
+                              and self.enc.fam is None)
         self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
         self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
         self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
@@ -201,6 +258,13 @@ class HotPath:
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
         self.grad_ready_hooks = []      # callables(which: 'begin' | 'decoder' | 'encoder'), e.g. the data-parallel exchange
+
+    @staticmethod
+    def _sparse_sets(model, prefix: str, n_layer: int):
+        """Host copies of every layer's kept / skipped position sets (the persistent buffers of layers.py:557-558)."""
+        bufs = dict(model.named_buffers())
+        return [(bufs[f'{prefix}transformer.h.{l}.input_mask_idx'].cpu().numpy().astype(np.int64),
+                 bufs[f'{prefix}transformer.h.{l}.input_mask_not_idx'].cpu().numpy().astype(np.int64)) for l in range(n_layer)]
 
     def notify_grads_ready(self, which: str):
         for hook in self.grad_ready_hooks:
@@ -217,6 +281,8 @@ class HotPath:
             self._conv_ws_pool = {}
             self._conv_scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev)
             self._logits_cache.clear()
+            self._moe_cache.clear()
+            self._sub_cache.clear()
         self.arena.refresh_shadow()
         self.enc_drop = self.dec_drop = None
         if training:
@@ -489,7 +555,11 @@ class HotPath:
             ops.dropout_apply(x, B * T, d, emb_drop)
         saves, cur_x = [], x.view(B * T, d)
         for l in range(e.L - 1 if self.cls_only_last else e.L):
-            cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save, plan, l)
+            if e.fam is not None:
+                cur_x, sv = self.fam_layer_fwd(f'{self.ep}transformer.h.{l}', e.fam, cur_x, B, T, None, 0, save, plan, l, None,
+                                               self.sparse_subset('enc', l, B, T, 0, None))
+            else:
+                cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save, plan, l)
             saves.append(sv)
         Mc = B * e.ncls
         if self.cls_only_last:      # the last block's patch rows are never read: compute its CLS rows only
@@ -535,6 +605,12 @@ class HotPath:
         if self.cls_only_last:
             self.block_bwd_cls(f'{self.ep}transformer.h.{e.L - 1}', ctx.saves[-1], dcls, dx, B, T, d, e.H, e.ff, e.ncls)
             self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, presummed_slot=1)
+        elif e.fam is not None:
+            ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
+            dxf = dx.view(B * T, d)
+            for l in reversed(range(e.L)):
+                dxf = self.fam_layer_bwd(f'{self.ep}transformer.h.{l}', e.fam, ctx.saves[l], dxf, B, T, 0, None, None)
+            dx = dxf.view(B, T, d)
         else:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
             self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
@@ -610,7 +686,11 @@ class HotPath:
         saves, cur = [], x
         for l in range(dc.L):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
-            cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l, vl)
+            if dc.fam is not None:
+                cur, sv = self.fam_layer_fwd(f'{self.dp}transformer.h.{l}', dc.fam, cur, B, T, m, S, save, plan, l, vl,
+                                             self.sparse_subset('dec', l, B, T, pos_offset, vl))
+            else:
+                cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l, vl)
             saves.append(sv)
         hid, mf, rf = self._empty(M, d), self._empty(M), self._empty(M)
         ops.layernorm_fwd(cur, a.P(f'{self.dp}transformer.ln_f.weight'), a.P(f'{self.dp}transformer.ln_f.bias'), hid, mf, rf, M, d)
@@ -651,7 +731,11 @@ class HotPath:
         dx = self._empty(M, d)
         ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
-        self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl)
+        if dc.fam is not None:
+            for l in reversed(range(dc.L)):
+                dx = self.fam_layer_bwd(f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, B, T, ctx.S, dmem, ctx.vl)
+        else:
+            self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl)
         if ctx.ids is not None:
             if ctx.emb_drop is not None:
                 ops.dropout_apply(dx, M, d, ctx.emb_drop)

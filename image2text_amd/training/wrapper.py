@@ -135,7 +135,7 @@ class ModelTrainerWrapper(nn.Module):
         mask = idx[None, :] <= lens[:, None]
         pos = (idx - 1).to(torch.int32).expand(B, T)[mask].contiguous()
         from types import SimpleNamespace
-        return SimpleNamespace(cu=cu, pos=pos, total=total, mask=mask)
+        return SimpleNamespace(cu=cu, pos=pos, total=total, mask=mask, lens_host=lens_host)
 
     @torch.no_grad()
     def copy_momentum_params(self):
