@@ -256,6 +256,131 @@ __global__ __launch_bounds__(256) void moe_unpack_dw2_kernel(const float* __rest
     else gb[(size_t)(c - EP) * out + o] += v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------- decode step (KV cache)
+// One wave per (sequence, query head): the new query against the cached keys 0 .. *pos_ptr of its key/value head, head width HD.
+// Same access pattern as decode.hip::decode_attention_kernel (HD / 8 lanes per key, 16-byte loads, xor-shuffle reductions), with
+// the query heads of a group reading one shared K/V head (multi-query: the cache is H times smaller than the multi-head one, and
+// the step is HBM-bound on exactly that cache).  k_new / v_new: this token's key / value rows (appended to the cache at slot
+// *pos_ptr by the group's first head, and attended to from LDS by all of them); null for a fixed memory of n_keys_fixed keys.
+constexpr int GDEC_MAX_KEYS = 1024;
+template <int HD>
+__global__ __launch_bounds__(64) void gq_decode_attention_kernel(const bf16_t* __restrict__ q, int q_rs, const bf16_t* __restrict__ k_new,
+                                                                 const bf16_t* __restrict__ v_new, int kv_rs, bf16_t* __restrict__ kc,
+                                                                 bf16_t* __restrict__ vc, long cache_bs, int cache_rs,
+                                                                 bf16_t* __restrict__ o, int o_rs, const int* __restrict__ pos_ptr,
+                                                                 int n_keys_fixed, int G, float scale) {
+    constexpr int LPK = HD / 8, KPP = 64 / LPK;             // lanes per key, keys per pass
+    __shared__ float qs[HD], kn[HD], vn[HD];
+    __shared__ float ps[GDEC_MAX_KEYS];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, hk = h / G;
+    const bool append = k_new != nullptr;
+    const int n = pos_ptr ? (*pos_ptr + 1) : n_keys_fixed;
+    bf16_t* kb = kc + (size_t)b * cache_bs + hk * HD;
+    bf16_t* vb = vc + (size_t)b * cache_bs + hk * HD;
+    for (int i = lane; i < HD; i += 64) {
+        qs[i] = bf16_to_f32(q[(size_t)b * q_rs + h * HD + i]);
+        if (append) {
+            const bf16_t kv = k_new[(size_t)b * kv_rs + hk * HD + i], vv = v_new[(size_t)b * kv_rs + hk * HD + i];
+            kn[i] = bf16_to_f32(kv);
+            vn[i] = bf16_to_f32(vv);
+            if (h % G == 0) {
+                kb[(size_t)(n - 1) * cache_rs + i] = kv;
+                vb[(size_t)(n - 1) * cache_rs + i] = vv;
+            }
+        }
+    }
+    __syncthreads();
+    const int n_cached = append ? n - 1 : n;
+    const int kg = lane / LPK, c = lane % LPK;
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = qs[c * 8 + e];
+    float mx = -INFINITY;
+    if (append && lane == 0) {
+        float s = 0.f;
+        for (int e = 0; e < HD; ++e) s += kn[e] * qs[e];
+        s *= scale;
+        ps[n - 1] = s;
+        mx = s;
+    }
+    for (int k0 = 0; k0 < n_cached; k0 += KPP) {
+        const int key = k0 + kg;
+        float s = 0.f;
+        if (key < n_cached) {
+            const u32x4 kk = *reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(kk[e]) * qv[2 * e] + bf16hi(kk[e]) * qv[2 * e + 1];
+        }
+#pragma unroll
+        for (int o_ = 1; o_ < LPK; o_ <<= 1) s += __shfl_xor(s, o_, 64);
+        s *= scale;
+        if (key < n_cached) {
+            if (c == 0) ps[key] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    float sum = 0.f;
+    for (int key = lane; key < n; key += 64) {
+        const float p = __expf(ps[key] - mx);
+        ps[key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < n_cached; k0 += KPP) {
+        const int key = k0 + kg;
+        if (key < n_cached) {
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)key * cache_rs + c * 8);
+            const float p = ps[key];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += p * bf16lo(vv[e]);
+                acc[2 * e + 1] += p * bf16hi(vv[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int o_ = LPK; o_ < 64; o_ <<= 1) acc[e] += __shfl_xor(acc[e], o_, 64);      // sum the key stripes (lanes with equal c)
+    if (kg == 0) {
+        const float inv = 1.0f / sum;
+        if (append) {
+            const float pn = ps[n - 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pn * vn[c * 8 + e];
+        }
+        const u32x4 pk = {pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv),
+                          pack_bf16x2(acc[4] * inv, acc[5] * inv), pack_bf16x2(acc[6] * inv, acc[7] * inv)};
+        *reinterpret_cast<u32x4*>(o + (size_t)b * o_rs + h * HD + c * 8) = pk;
+    }
+}
+
+// per-layer cache slot and membership of the token at *pos_ptr: lpos[l] = rank[l][pos], lmem[l] = member[l][pos]
+__global__ void sparse_step_setup_kernel(const int* __restrict__ pos_ptr, const int* __restrict__ rank, const int* __restrict__ member,
+                                         int* __restrict__ lpos, int* __restrict__ lmem, int L, int tmax) {
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= L) return;
+    const int pos = min(*pos_ptr, tmax - 1);
+    lpos[l] = rank[(size_t)l * tmax + pos];
+    lmem[l] = member[(size_t)l * tmax + pos];
+}
+
+// out = *flag ? a : b   (fp32, n multiple of 4)
+__global__ __launch_bounds__(256) void select_rows_kernel(const int* __restrict__ flag, const float* __restrict__ a,
+                                                          const float* __restrict__ b, float* __restrict__ out, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float* src = *flag ? a : b;
+    *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + i * 4);
+}
+
 long blocks_for(long n) { return (n + 255) / 256; }
 
 int moe_check(const char* who, int M, int E, int P, int G, int top_k, int ldu, int Kp) {
@@ -343,5 +468,45 @@ extern "C" int i2t_moe_unpack_dw2(void* stream, const float* dW, float* gw, floa
     hipLaunchKernelGGL(moe_unpack_dw2_kernel, dim3((unsigned)blocks_for((long)out * (E * P + E))), dim3(256), 0, (hipStream_t)stream, dW, gw, gb,
                        out, E, P, Kp);
     I2T_CHECK_LAUNCH("i2t_moe_unpack_dw2");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gq_decode_attention(void* stream, const void* q, int q_rs, const void* k_new, const void* v_new, int kv_rs, void* kcache,
+                                       void* vcache, long cache_bs, int cache_rs, void* out, int out_rs, const int* pos_ptr,
+                                       int n_keys_fixed, int max_keys, int B, int H, int Hkv, int hd) {
+    I2T_REQUIRE(q && kcache && vcache && out && B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "i2t_gq_decode_attention: bad args");
+    I2T_REQUIRE(hd == 16 || hd == 32 || hd == 64 || hd == 128, "i2t_gq_decode_attention: head_dim %d (16, 32, 64 or 128)", hd);
+    I2T_REQUIRE((k_new != nullptr) == (v_new != nullptr) && (pos_ptr || n_keys_fixed > 0), "i2t_gq_decode_attention: no key count");
+    I2T_REQUIRE(max_keys > 0 && max_keys <= GDEC_MAX_KEYS && n_keys_fixed <= max_keys, "i2t_gq_decode_attention: at most %d keys", GDEC_MAX_KEYS);
+    I2T_REQUIRE(cache_rs % 8 == 0 && cache_bs % 8 == 0 && out_rs % 8 == 0 && ALIGNED16(kcache) && ALIGNED16(vcache) && ALIGNED16(out),
+                "i2t_gq_decode_attention: cache / output rows must be 16-byte aligned");
+    const float scale = 1.0f / sqrtf((float)hd);
+    dim3 grid(H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define GDEC_LAUNCH(HD)                                                                                                              \
+    hipLaunchKernelGGL(gq_decode_attention_kernel<HD>, grid, dim3(64), 0, s, (const bf16_t*)q, q_rs, (const bf16_t*)k_new,             \
+                       (const bf16_t*)v_new, kv_rs, (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)out, out_rs, pos_ptr, \
+                       n_keys_fixed, H / Hkv, scale)
+    if (hd == 16) GDEC_LAUNCH(16);
+    else if (hd == 32) GDEC_LAUNCH(32);
+    else if (hd == 64) GDEC_LAUNCH(64);
+    else GDEC_LAUNCH(128);
+#undef GDEC_LAUNCH
+    I2T_CHECK_LAUNCH("i2t_gq_decode_attention");
+    return I2T_OK;
+}
+
+extern "C" int i2t_sparse_step_setup(void* stream, const int* pos_ptr, const int* rank, const int* member, int* lpos, int* lmem, int L,
+                                     int tmax) {
+    I2T_REQUIRE(pos_ptr && rank && member && lpos && lmem && L > 0 && tmax > 0, "i2t_sparse_step_setup: bad args");
+    hipLaunchKernelGGL(sparse_step_setup_kernel, dim3((L + 63) / 64), dim3(64), 0, (hipStream_t)stream, pos_ptr, rank, member, lpos, lmem, L, tmax);
+    I2T_CHECK_LAUNCH("i2t_sparse_step_setup");
+    return I2T_OK;
+}
+
+extern "C" int i2t_select_rows(void* stream, const int* flag, const float* a, const float* b, float* out, long n) {
+    I2T_REQUIRE(flag && a && b && out && n > 0 && n % 4 == 0 && ALIGNED16(a) && ALIGNED16(b) && ALIGNED16(out), "i2t_select_rows: bad args");
+    hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, flag, a, b, out, n / 4);
+    I2T_CHECK_LAUNCH("i2t_select_rows");
     return I2T_OK;
 }

@@ -75,15 +75,110 @@ class GreedyDecoder:
         st.hid = e(B, d)
         st.logits = e(B, dc.Vp, dtype=F32)                      # rows padded to 8 columns: 16-byte aligned rows for the GEMM epilogue
         st.margin = e(B, dtype=F32)
-        st.kc = [e(B, tmax, d) for _ in range(dc.L)]
-        st.vc = [e(B, tmax, d) for _ in range(dc.L)]
+        if dc.fam is None:
+            st.kc = [e(B, tmax, d) for _ in range(dc.L)]
+            st.vc = [e(B, tmax, d) for _ in range(dc.L)]
         S = ncls
         st.cross_kv = {l: (e(B, S, 2 * d), S) for l in self._cross_layers()}
+        if dc.fam is not None:
+            self._build_family(st, e)
         st.ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
         st.graphs = {}                      # None -> prefill step, 'greedy' / Sampling.key() -> full step
         st.seed = torch.zeros(2, dtype=torch.int32, device=dev)
         st.dist = None                      # optional [B, V] f32: the distribution of the last sampled step (tests)
         return st
+
+    def _build_family(self, st, e):
+        """Buffers of the nano-mini family's decode step (engine_family.py): a K/V cache of Hkv heads per layer that, in a sparse
+        layer, holds the kept positions only (slot = number of kept positions before the token), the per-layer slot / membership
+        tables, and the MoE routing workspaces."""
+        import numpy as np
+        eng, dc = self.eng, self.eng.dec
+        sp, dev = dc.fam, st.arena.device
+        B, d, hd, tmax, off = st.B, dc.d, sp.hd, st.tmax, st.off
+        st.Hkv = 1 if sp.mqa else dc.H
+        st.slots = tmax
+        st.sparse = sp.sparse
+        if sp.sparse:
+            rank, member = np.zeros((dc.L, tmax), dtype=np.int32), np.zeros((dc.L, tmax), dtype=np.int32)
+            for l, (idx, _not) in enumerate(eng._sparse_idx['dec']):
+                if int((idx < off + 1).sum()) < 2:
+                    # layers.py:572-573 sends the WHOLE sequence through the null connector while <= 1 position is kept; a token's
+                    # state would then depend on the current length and could not be cached
+                    raise NotImplementedError('KV-cache generation with sparse decoder blocks needs >= 2 kept positions before the '
+                                              'first text token (a soft prompt of >= 2 encoder outputs)')
+                if off + tmax > idx.size + _not.size:
+                    raise AssertionError('block_size + prompt exceeds max_block_size of the sparse decoder blocks')
+                text = np.zeros(off + tmax, dtype=np.int32)
+                text[idx[idx < off + tmax]] = 1
+                member[l] = text[off:]
+                rank[l] = np.cumsum(member[l]) - member[l]
+            st.slots = max(int(member.sum(axis=1).max()), 1)
+            st.rank, st.member = torch.from_numpy(rank).to(dev), torch.from_numpy(member).to(dev)
+            st.lpos = torch.zeros(dc.L, dtype=torch.int32, device=dev)
+            st.lmem = torch.zeros(dc.L, dtype=torch.int32, device=dev)
+            st.xb, st.xn, st.xnb = e(B, d, dtype=F32), e(B, d, dtype=F32), e(B, d)
+        w = st.Hkv * hd
+        st.kc = [e(B, st.slots, w) for _ in range(dc.L)]
+        st.vc = [e(B, st.slots, w) for _ in range(dc.L)]
+        st.kvn = e(B, 2 * w)
+        if sp.moe is not None:
+            m = sp.moe
+            st.U = e(B, m.E * m.P + (m.G if m.G else m.E), dtype=F32)
+            st.A = e(B, m.Kp)
+            st.gates, st.wsel = e(B, m.E, dtype=F32), e(B, m.E, dtype=F32)
+
+    def _moe_step(self, st, pfx: str, x_bf, y, act: int, residual):
+        eng, m = self.eng, self.eng.dec.fam.moe
+        mv = eng._moe_views(pfx, m)
+        ops.gemm(x_bf, mv.W1, st.U, st.B, mv.N1, mv.in_f, bias=mv.b1)
+        ops.moe_gate_fwd(st.U, mv.wg2, mv.bg2, st.A, st.gates, st.wsel, st.B, m.E, m.P, m.G, m.top_k, mv.in_f ** -0.5)
+        ops.gemm(st.A, mv.W2aug, y, st.B, mv.out_f, m.Kp, act=act, residual=residual)
+
+    def _layers_family(self, st):
+        """The decoder blocks of one decode step for the nano-mini family.  A sparse layer computes both of its paths for the new
+        token -- the block (whose K/V land in the layer's next free cache slot: a skipped token's entry is overwritten by the next
+        kept one before anything reads it) and x + null_connector(x) -- and keeps the one its position table selects; which
+        one is a device-side flag, so the captured graph is the same for every position."""
+        eng, a, dc = self.eng, self.eng.arena, self.eng.dec
+        sp = dc.fam
+        B, d, ff, H, hd, Hkv = st.B, dc.d, dc.ff, dc.H, sp.hd, st.Hkv
+        w = Hkv * hd
+        dp = eng.dp
+        if st.sparse:
+            ops.sparse_step_setup(st.counters[0:1], st.rank, st.member, st.lpos, st.lmem, dc.L, st.tmax)
+        for l in range(dc.L):
+            p = f'{dp}transformer.h.{l}'
+            xo = st.xb if st.sparse else st.x
+            pos_ptr = st.lpos[l:l + 1] if st.sparse else st.counters[0:1]
+            ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
+            if sp.mqa:
+                ops.gemm(st.ln, a.W(f'{p}.attn.q_proj.weight'), st.q, B, d, d, bias=a.P(f'{p}.attn.q_proj.bias'))
+                ops.gemm(st.ln, a.W(f'{p}.attn.kv_proj.weight'), st.kvn, B, 2 * hd, d, bias=a.P(f'{p}.attn.kv_proj.bias'))
+                qv, kn, vn, out_name = st.q, st.kvn[:, :hd], st.kvn[:, hd:], 'attn.out_proj'
+            else:
+                ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
+                qv, kn, vn, out_name = st.qkv[:, :d], st.qkv[:, d:2 * d], st.qkv[:, 2 * d:], 'attn.c_proj'
+            ops.gq_decode_attention(qv, kn, vn, st.kc[l], st.vc[l], st.slots * w, w, st.ao, pos_ptr, 0, st.slots, B, H, Hkv, hd)
+            ops.gemm(st.ao, a.W(f'{p}.{out_name}.weight'), xo, B, d, d, bias=a.P(f'{p}.{out_name}.bias'), residual=st.x)
+            if l in st.cross_kv:
+                kv, S = st.cross_kv[l]
+                win, bin_ = a.W(f'{p}.cross_attn.in_proj_weight'), a.P(f'{p}.cross_attn.in_proj_bias')
+                ops.layernorm_fwd(xo, a.P(f'{p}.ln_3.weight'), a.P(f'{p}.ln_3.bias'), st.ln, None, None, B, d)
+                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d])
+                ops.gq_decode_attention(st.q, None, None, kv, kv.view(-1)[d:], S * 2 * d, 2 * d, st.ao, None, S, S, B, H, H, hd)
+                ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), xo, B, d, d, bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=xo)
+            ops.layernorm_fwd(xo, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
+            if sp.moe is not None:
+                self._moe_step(st, f'{p}.mlp.c_fc', st.ln, st.h, 1, None)
+                self._moe_step(st, f'{p}.mlp.c_proj', st.h, xo, 0, xo)
+            else:
+                ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
+                ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), xo, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=xo)
+            if st.sparse:
+                ops.cast_f32_bf16(st.x, st.xnb)
+                ops.gemm(st.xnb, a.W(f'{p}.null_connector.weight'), st.xn, B, d, d, bias=a.P(f'{p}.null_connector.bias'), residual=st.x)
+                ops.select_rows(st.lmem[l:l + 1], st.xb, st.xn, st.x, B * d)
 
     def _cross_layers(self):
         cfg = self.model.config
@@ -100,7 +195,9 @@ class GreedyDecoder:
         dp = eng.dp
         ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(f'{dp}transformer.wte.weight'), a.P(f'{dp}transformer.wpe.weight'),
                        st.x, B, d, st.off, dc.V)
-        for l in range(dc.L):
+        if dc.fam is not None:
+            self._layers_family(st)
+        for l in range(dc.L if dc.fam is None else 0):
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
@@ -175,6 +272,11 @@ class GreedyDecoder:
                 p = f'{eng.dp}transformer.h.{l}.cross_attn'
                 ops.gemm(mem, a.W(f'{p}.in_proj_weight')[dc.d:], kv.view(B * S, 2 * dc.d), B * S, 2 * dc.d, dc.d,
                          bias=a.P(f'{p}.in_proj_bias')[dc.d:])
+        if dc.fam is not None and dc.fam.moe is not None:       # the packed expert output weights follow the current parameters
+            for l in range(dc.L):
+                for part in ('c_fc', 'c_proj'):
+                    mv = eng._moe_views(f'{eng.dp}transformer.h.{l}.mlp.{part}', dc.fam.moe)
+                    ops.moe_pack_w2(mv.l2w, mv.l2b, mv.W2aug, mv.out_f, dc.fam.moe.E, dc.fam.moe.P)
         if sampling is not None:
             seed = sampling.seed if sampling.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
             lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF

@@ -65,6 +65,9 @@ SIGNATURES = {
     'i2t_moe_gate_bwd': [P, P, I, P, I, P, P, P, P, I, P, P, P, I, I, I, I, I, F],
     'i2t_moe_pack_w2': [P, P, P, P, I, I, I, I],
     'i2t_moe_unpack_dw2': [P, P, P, P, I, I, I, I],
+    'i2t_gq_decode_attention': [P, P, I, P, P, I, P, P, L, I, P, I, P, I, I, I, I, I, I],
+    'i2t_sparse_step_setup': [P, P, P, P, P, P, I, I],
+    'i2t_select_rows': [P, P, P, P, P, L],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

@@ -207,6 +207,26 @@ def moe_unpack_dw2(dW, gw, gb, out, E, P):
     _l.check(_lib().i2t_moe_unpack_dw2(_stream(), _p(dW), _p(gw), _p(gb), out, E, P, dW.stride(0)), 'i2t_moe_unpack_dw2')
 
 
+def gq_decode_attention(q, k_new, v_new, kcache, vcache, cache_bs, cache_rs, out, pos_ptr, n_keys_fixed, max_keys, B, H, Hkv, hd):
+    """Decode-step attention of the family (include/i2t.h::i2t_gq_decode_attention); q / k_new / v_new / out are row-major 2-D views."""
+    _need_cuda(q, kcache, vcache, out)
+    kv_rs = k_new.stride(0) if k_new is not None else 0
+    _l.check(_lib().i2t_gq_decode_attention(_stream(), _p(q), q.stride(0), _p(k_new), _p(v_new), kv_rs, _p(kcache), _p(vcache), cache_bs,
+                                            cache_rs, _p(out), out.stride(0), _p(pos_ptr), n_keys_fixed, max_keys, B, H, Hkv, hd),
+             'i2t_gq_decode_attention')
+    return out
+
+
+def sparse_step_setup(pos_ptr, rank, member, lpos, lmem, L, tmax):
+    _need_cuda(pos_ptr, rank, member, lpos, lmem)
+    _l.check(_lib().i2t_sparse_step_setup(_stream(), _p(pos_ptr), _p(rank), _p(member), _p(lpos), _p(lmem), L, tmax), 'i2t_sparse_step_setup')
+
+
+def select_rows(flag, a, b, out, n):
+    _need_cuda(flag, a, b, out)
+    _l.check(_lib().i2t_select_rows(_stream(), _p(flag), _p(a), _p(b), _p(out), n), 'i2t_select_rows')
+
+
 def xattn_kv_fused(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, drop=None, cu_q=None, total_q=0):
     """Fused cross-attention forward (include/i2t.h::i2t_xattn_kv_fused): kv = mem . w_kv^T + bias written once, attention of every
     (image, head) out of the projection's accumulators.  q / o: [B, Tq, >= 64 H] views or packed [rows, >= 64 H] with cu_q."""

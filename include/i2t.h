@@ -349,6 +349,20 @@ int i2t_moe_gate_bwd(void* stream, const void* dA, int Kp, const float* U, int l
 int i2t_moe_pack_w2(void* stream, const void* l2w, const float* l2b, void* W, int out, int E, int P, int Kp);
 int i2t_moe_unpack_dw2(void* stream, const float* dW, float* gw, float* gb, int out, int E, int P, int Kp);
 
+/* Decode step of the family (static KV cache under hipGraph, see i2t_decode_attention): the new query row q [B][H hd] against the
+ * cached keys 0 .. *pos_ptr of its key/value head (Hkv heads of width hd in the cache rows); k_new / v_new [B][>= Hkv hd] are this
+ * token's key / value, written to cache slot *pos_ptr and attended to; null k_new / v_new: a fixed memory of n_keys_fixed keys
+ * (cross-attention).  max_keys bounds *pos_ptr + 1 (<= 1024). */
+int i2t_gq_decode_attention(void* stream, const void* q, int q_rs, const void* k_new, const void* v_new, int kv_rs, void* kcache,
+                            void* vcache, long cache_bs, int cache_rs, void* out, int out_rs, const int* pos_ptr,
+                            int n_keys_fixed, int max_keys, int B, int H, int Hkv, int hd);
+/* Sparse blocks in the decode step: a layer's cache holds only its kept positions, so the token at text position *pos_ptr uses
+ * slot rank[l][pos] (= kept positions before it) and runs the block only when member[l][pos]; both tables int [L][tmax] on the
+ * device.  setup writes lpos[l] / lmem[l] for the current position; i2t_select_rows picks the block's or the null connector's
+ * output (out = *flag ? a : b, fp32 [n]). */
+int i2t_sparse_step_setup(void* stream, const int* pos_ptr, const int* rank, const int* member, int* lpos, int* lmem, int L, int tmax);
+int i2t_select_rows(void* stream, const int* flag, const float* a, const float* b, float* out, long n);
+
 /* hipGraph capture around any sequence of the calls above (replaces the Python loop of
  * vision_encoder_decoder.py:143-180 with one replayed launch per token) */
 int i2t_graph_capture_begin(void* stream);

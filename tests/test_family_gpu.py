@@ -257,3 +257,93 @@ def test_nano_mini_full_size_forward_and_loss():
             worst = max(worst, abs(float(p.grad.norm()) - ref) / ref)
     REPORT['nano_mini.worst_gradnorm_rel_err'] = worst
     assert worst <= 0.35
+
+
+def _decode_vs_forward(tag, m, images, gold, steps):
+    """KV-cache decode step (sparse slot tables, grouped decode attention, MoE step) == the full forward, teacher-forced"""
+    from image2text_amd.decoding import GreedyDecoder
+    V = m.config.decoder_config.vocab_size
+    with torch.no_grad():
+        full = m(images=images, ids=torch.from_numpy(gold[:, :-1]).to(dev())).logits.float()
+    dec = GreedyDecoder(m)
+    worst = 0.0
+    for t in steps:
+        dec.generate(images, torch.from_numpy(gold[:, :t + 1]).to(dev()), 1, use_graph=(t % 2 == 0))
+        lg = dec._state.logits[:, :V].float()
+        err = (lg - full[:, t]).abs()
+        tol = logits_tol(full[:, t].cpu().numpy())
+        worst = max(worst, float(err.max()) / tol)
+        assert float(err.quantile(0.99)) <= tol, (tag, t, float(err.quantile(0.99)), tol)
+        assert float(err.max()) <= 4 * tol, (tag, t, float(err.max()), tol)          # (a routing near-tie may differ between the two paths)
+    REPORT[f'{tag}.decode_vs_forward_worst_over_tol'] = worst
+
+
+def test_mini_greedy_decode():
+    from test_model_gpu import assert_greedy_matches
+    f = load_golden('mini_decode.npz')
+    cfg = mini_config()
+    m, _ = build(cfg)
+    images = torch.from_numpy(f['images']).to(dev())
+    _decode_vs_forward('mini', m, images, f['ids'], (0, 1, 2, 3, 5, 8, 12, 16, 19))
+    # the reference's greedy tokens wherever its top-1 margin is clear of the bf16 logit noise (untrained model: logits ~ +-1)
+    r = assert_greedy_matches(m, images, f['ids'], f['margins'], 1, eps=0.08)
+    REPORT['mini.greedy'] = {'low_margin_restarts': r, 'steps_with_margin_ge_eps': int((f['margins'] >= 0.08).sum()), 'steps': int(f['margins'].size)}
+    prompt = torch.from_numpy(f['prompt']).to(dev())
+    a = m.generate(images, prompt, max_new_tokens=20, temperature=1.0, top_k=1)
+    b = m.generate(images, prompt, max_new_tokens=20, temperature=1.0, top_k=1)
+    assert a.shape == (4, 21) and torch.equal(a, b)
+    s = m.generate(images, prompt, max_new_tokens=8, temperature=0.7, nucleus_p=0.6)          # eval_model's call shape (trainer.py:41-56)
+    assert s.shape == (4, 9) and int(s.min()) >= 0 and int(s.max()) < cfg.decoder_config.vocab_size
+
+
+@pytest.mark.parametrize('name', ['mq_only', 'moe_only', 'sparse_only', 'mh128', 'heads16', 'all_cross', 'top2_dec'])
+def test_variant_decode_matches_forward(name):
+    f = load_golden('mini_decode.npz')
+    m, _ = build(variant_config(name))
+    _decode_vs_forward(f'variant.{name}', m, torch.from_numpy(f['images']).to(dev()), f['ids'], (0, 1, 4, 9, 15, 19))
+
+
+def test_mini_train_step_with_dropout_matches_oracle_on_the_same_masks_and_routing():
+    """dropout 0.1 / attn_dropout 0.1 in both towers of the mini model: the oracle is fed the step's exact masks (DropPlans rebuilt on
+    the host; sparse blocks index their sites over the gathered rows) and the device's expert choices"""
+    from oracle import reference_model as orc
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    torch.manual_seed(20241004)
+    f = load_golden('mini_forward.npz')
+    cfg = mini_config(dropout=0.1)
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    sharpen_gates_(det_init_(w.model, seed=0))
+    sd = {k: v.detach().clone() for k, v in w.model.state_dict().items()}
+    w = w.to(dev()).train()
+    w.pack_rows = False
+    images, labels = torch.from_numpy(f['images']), torch.from_numpy(f['labels'])
+    eng = w.model._engine
+    eng.moe_trace = {}
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    trace = dict(eng.moe_trace)
+    eng.moe_trace = None
+    loss.backward()
+    plans = (eng.enc_drop, eng.dec_drop)
+    assert plans[0] is not None and plans[1] is not None
+    forced = device_choices(trace, top_k_fn(cfg))
+    io = {'forced': forced, 'record': {}}
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items() if k != 'decoder.lm_head.weight'}
+    osd['decoder.lm_head.weight'] = osd['decoder.transformer.wte.weight']
+    oloss = orc.lm_step_text_segment(osd, cfg, images, labels, tok, plans, moe_io=io)
+    oloss.backward()
+    check_choices('mini_dropout', forced, io['record'])
+    REPORT['mini_dropout.train_loss'] = {'got': float(loss.detach()), 'ref': float(oloss)}
+    assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * float(oloss)
+    fails = []
+    for name, p in w.model.named_parameters():
+        g = osd[name].grad
+        try:
+            grad_close(f'mini_dropout.{name}', p.grad, (g if g is not None else torch.zeros_like(osd[name])).numpy(), rel=0.1, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    with torch.no_grad():
+        clean = orc.lm_step_text_segment(sd, cfg, images, labels, tok)
+    assert abs(float(clean) - float(oloss)) > 1e-6
