@@ -220,15 +220,19 @@ __global__ __launch_bounds__(256) void moe_gate_bwd_kernel(const bf16_t* __restr
             part[(size_t)blockIdx.x * NG + i] = (acc_s[0][i] + acc_s[1][i]) + (acc_s[2][i] + acc_s[3][i]);
 }
 
-// dwg2 [E][G] += sum_b part[b][e G + k]; dbg2 [E] += sum_b part[b][E G + e]  (fixed order: run-to-run identical)
-__global__ void moe_gate_reduce_kernel(const float* __restrict__ part, int nb, int NG, int EG, float* __restrict__ dwg2,
-                                       float* __restrict__ dbg2) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NG) return;
+// dwg2 [E][G] += sum_b part[b][e G + k]; dbg2 [E] += sum_b part[b][E G + e]: one workgroup per output, a fixed summation tree
+// (thread t adds rows t, t + 256, ..; then the block reduction) -- run-to-run identical
+__global__ __launch_bounds__(256) void moe_gate_reduce_kernel(const float* __restrict__ part, int nb, int NG, int EG, float* __restrict__ dwg2,
+                                                              float* __restrict__ dbg2) {
+    __shared__ float red[16];
+    const int i = blockIdx.x;
     float a = 0.f;
-    for (int b = 0; b < nb; ++b) a += part[(size_t)b * NG + i];
-    if (i < EG) dwg2[i] += a;
-    else if (dbg2) dbg2[i - EG] += a;
+    for (int b = threadIdx.x; b < nb; b += 256) a += part[(size_t)b * NG + i];
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) {
+        if (i < EG) dwg2[i] += a;
+        else if (dbg2) dbg2[i - EG] += a;
+    }
 }
 
 // W2aug bf16 [out][Kp] from the stacked expert parameters: l2w bf16 [E][out][P], l2b f32 [E][out]
@@ -434,7 +438,8 @@ extern "C" int i2t_moe_gate_fwd(void* stream, const float* U, int ldu, const flo
     return I2T_OK;
 }
 
-extern "C" int i2t_moe_gate_bwd_blocks(int M) { return M >= 256 * 16 ? 256 : (M + 15) / 16; }
+// enough waves to hide the per-row latency chain (loads -> shuffles): 8 rows per workgroup (2 per wave) up to 4096 workgroups
+extern "C" int i2t_moe_gate_bwd_blocks(int M) { return M >= 4096 * 8 ? 4096 : (M + 7) / 8; }
 
 extern "C" int i2t_moe_gate_bwd(void* stream, const void* dA, int Kp, const float* U, int ldu, const float* gates, const float* wsel,
                                 const float* wg2, void* D1, int ldd, float* dwg2, float* dbg2, float* part_ws, int M, int E, int P, int G,
@@ -449,7 +454,7 @@ extern "C" int i2t_moe_gate_bwd(void* stream, const void* dA, int Kp, const floa
     hipLaunchKernelGGL(moe_gate_bwd_kernel, dim3(nb), dim3(256), 0, st, (const bf16_t*)dA, U, gates, wsel, wg2, (bf16_t*)D1, ldd, part_ws, s, rpb);
     if (G) {
         const int NG = E * G + E;
-        hipLaunchKernelGGL(moe_gate_reduce_kernel, dim3((NG + 255) / 256), dim3(256), 0, st, part_ws, nb, NG, E * G, dwg2, dbg2);
+        hipLaunchKernelGGL(moe_gate_reduce_kernel, dim3(NG), dim3(256), 0, st, part_ws, nb, NG, E * G, dwg2, dbg2);
     }
     I2T_CHECK_LAUNCH("i2t_moe_gate_bwd");
     return I2T_OK;

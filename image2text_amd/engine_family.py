@@ -129,8 +129,8 @@ class FamilyBlocks:
         E, P, G, Kp = sp.E, sp.P, sp.G, sp.Kp
         dA = self._empty(M, Kp, dtype=BF16)
         ops.gemm(dy_bf, mv.W2aug, dA, M, Kp, mv.out_f, b_kmajor=True)
-        dW2 = self._empty(mv.out_f, Kp)
-        ops.gemm(dy_bf, sv.A, dW2, mv.out_f, Kp, M, a_kmajor=True, b_kmajor=True)
+        dW2 = torch.zeros(mv.out_f, Kp, dtype=F32, device=self.arena.device)      # accumulate form: the split-K path (K = M rows)
+        ops.gemm(dy_bf, sv.A, dW2, mv.out_f, Kp, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         ops.moe_unpack_dw2(dW2, mv.gl2w, mv.gl2b, mv.out_f, E, P)
         N1p = _round_up(mv.N1, 8)
         D1 = self._empty(M, N1p, dtype=BF16)
