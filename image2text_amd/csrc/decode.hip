@@ -14,9 +14,13 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const int64_t* __restri
     long id = ids[(size_t)b * ids_ld + t];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const f32x4* e = reinterpret_cast<const f32x4*>(wte + (size_t)id * d);
-    const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
     f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)b * d);
-    for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c] + p[c];
+    if (wpe) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
+        for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c] + p[c];
+    } else {
+        for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c];
+    }
 }
 
 // kcache[b][pos][:] = qkv[b][d:2d], vcache[b][pos][:] = qkv[b][2d:3d]
@@ -249,7 +253,7 @@ __global__ void advance_kernel(int* counters, int n, int delta) {
 
 extern "C" int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
                               const float* wpe, float* x, int B, int d, int pos_offset, int vocab) {
-    I2T_REQUIRE(ids && len_ptr && wte && wpe && x && B > 0 && d % 4 == 0, "i2t_embed_step: bad args");
+    I2T_REQUIRE(ids && len_ptr && wte && x && B > 0 && d % 4 == 0, "i2t_embed_step: bad args");
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, ids_ld, len_ptr, wte, wpe, x, d,
                        pos_offset, vocab);
     I2T_CHECK_LAUNCH("i2t_embed_step");

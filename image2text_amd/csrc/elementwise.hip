@@ -16,9 +16,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         long id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const f32x4* e = reinterpret_cast<const f32x4*>(wte + (size_t)id * d);
-        const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
         f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)row * d);
-        for (int c = threadIdx.x; c < d4; c += 256) o[c] = e[c] + p[c];
+        if (wpe) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(wpe + (size_t)(t + pos_offset) * d);
+            for (int c = threadIdx.x; c < d4; c += 256) o[c] = e[c] + p[c];
+        } else {                                    // token embedding only (the position term is a per-position MLP, grouped.hip)
+            for (int c = threadIdx.x; c < d4; c += 256) o[c] = e[c];
+        }
     }
 }
 
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_packed_kernel(const int* __
 
 extern "C" int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte, const float* wpe, float* x, int B, int T,
                              int d, int pos_offset, int vocab, const int* pos) {
-    I2T_REQUIRE(ids && wte && wpe && x && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_fwd: bad args");
+    I2T_REQUIRE(ids && wte && x && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_fwd: bad args");
     const int rows = B * T;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, ids, wte, wpe, x,
                        T, d, pos_offset, vocab, rows, pos);

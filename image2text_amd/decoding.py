@@ -82,6 +82,8 @@ class GreedyDecoder:
         st.cross_kv = {l: (e(B, S, 2 * d), S) for l in self._cross_layers()}
         if dc.fam is not None:
             self._build_family(st, e)
+        if dc.advpos:
+            st.pos_h = [e(B, g) for g in (self.model.config.decoder_config.advanced_pos_emb_gate_sizes or ())]
         st.ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
         st.graphs = {}                      # None -> prefill step, 'greedy' / Sampling.key() -> full step
         st.seed = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -193,8 +195,19 @@ class GreedyDecoder:
         B, d, ff, H = st.B, dc.d, dc.ff, dc.H
         pos_ptr, len_ptr = st.counters[0:1], st.counters[1:2]
         dp = eng.dp
-        ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(f'{dp}transformer.wte.weight'), a.P(f'{dp}transformer.wpe.weight'),
-                       st.x, B, d, st.off, dc.V)
+        ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(f'{dp}transformer.wte.weight'),
+                       None if dc.advpos else a.P(f'{dp}transformer.wpe.weight'), st.x, B, d, st.off, dc.V)
+        if dc.advpos:           # x = MLP_p(e) + e with p = off + pos read on the device: the same captured launches serve every position
+            pv = eng._pos_views()
+            ops.cast_f32_bf16(st.x, st.ln)
+            h = st.ln
+            for i, L in enumerate(pv.layers):
+                last = i == len(pv.layers) - 1
+                out = st.x if last else st.pos_h[i]
+                ops.grouped_gemm(0, h, L.W[:L.N * L.K].view(L.N, L.K), out, L.N, L.K, b_group_stride=pv.stride, bias=L.b,
+                                 bias_group_stride=pv.stride, act=0 if last else 1, residual=st.x if last else None, n_groups=1, max_rows=B,
+                                 group_ptr=pos_ptr, group0=st.off)
+                h = out
         if dc.fam is not None:
             self._layers_family(st)
         for l in range(dc.L if dc.fam is None else 0):

@@ -237,6 +237,7 @@ class HotPath(FamilyBlocks):
         self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer)
         self._sparse_idx = {'enc': self._sparse_sets(model, self.ep, ecfg.n_layer) if self.enc.fam and self.enc.fam.sparse else None,
                             'dec': self._sparse_sets(model, self.dp, dcfg.n_layer) if self.dec.fam and self.dec.fam.sparse else None}
+        self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
         self._moe_cache, self._sub_cache = {}, {}
         self.moe_trace = None           # tests set a dict: site -> (gate values, routing weights) of every MoELinear forward
         gates = list(ecfg.feature_extractor_gate_sizes or [])
@@ -668,18 +669,23 @@ class HotPath(FamilyBlocks):
             raise AssertionError(f'Cannot forward sequence of length {T + pos_offset}, block size is only {dc.block}')
         d, M = dc.d, (vl.total if vl is not None else B * T)
         x = self._empty(M, d)
-        wpe = a.P(f'{self.dp}transformer.wpe.weight')
+        wpe = None if dc.advpos else a.P(f'{self.dp}transformer.wpe.weight')
         # (dropout_without_save: a forward that is never differentiated but runs in training mode -- the momentum twin)
         plan = self.dec_drop if (save or dropout_without_save) else None
         emb_drop = plan.get(0, 'emb') if plan is not None else None
+        pos_ctx = None
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()
             if vl is not None:
                 ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, M, 1, d, pos_offset, dc.V, pos=vl.pos)
             else:
                 ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
+            if dc.advpos:
+                x, pos_ctx = self.posmlp_fwd(x, B, T, pos_offset, vl, save)
             if emb_drop is not None:
                 ops.dropout_apply(x, M, d, emb_drop)
+        elif dc.advpos:
+            x, pos_ctx = self.posmlp_fwd(embeds.to(device=a.device, dtype=F32).contiguous().view(M, d), B, T, pos_offset, vl, save)
         else:
             ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
             ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
@@ -697,7 +703,7 @@ class HotPath(FamilyBlocks):
         hb = self._empty(M, d, dtype=BF16)
         ops.cast_f32_bf16(hid, hb)
         ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset, vl=vl, M=M,
-                              emb_drop=emb_drop if ids is not None else None) if save else None
+                              emb_drop=emb_drop if ids is not None else None, pos_ctx=pos_ctx) if save else None
         return hid, hb, ctx
 
     def logits_f32(self, hb: torch.Tensor, M: int):
@@ -739,10 +745,15 @@ class HotPath(FamilyBlocks):
         if ctx.ids is not None:
             if ctx.emb_drop is not None:
                 ops.dropout_apply(dx, M, d, ctx.emb_drop)
+            dwpe = None if dc.advpos else a.G(f'{self.dp}transformer.wpe.weight')
+            if dc.advpos:
+                dx = self.posmlp_bwd(ctx.pos_ctx, dx)
             if ctx.vl is not None:
-                ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
+                ops.embed_bwd(ctx.ids, dx, a.G(wte), dwpe, M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
             else:
-                ops.embed_bwd(ctx.ids, dx, a.G(wte), a.G(f'{self.dp}transformer.wpe.weight'), B, T, d, ctx.pos_offset, dc.V)
+                ops.embed_bwd(ctx.ids, dx, a.G(wte), dwpe, B, T, d, ctx.pos_offset, dc.V)
             return None
+        if dc.advpos:
+            return self.posmlp_bwd(ctx.pos_ctx, dx)
         ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)
-        return dx      # gradient w.r.t. the embeddings fed in
+        return dx

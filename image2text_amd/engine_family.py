@@ -145,6 +145,106 @@ class FamilyBlocks:
             ops.gemm(D1, mv.W1, dx_out, M, mv.in_f, mv.N1, b_kmajor=True, lda=N1p, **dx_kw)
         return dx_out
 
+    # ------------------------------------------------------------------------------------------------ per-position MLP (wpe)
+    def _pos_views(self):
+        """AdvancedPositionalBiasMLP parameters (layers.py:617-638) as (base view of position 0, constant stride between positions)
+        per layer: consecutive positions' MLPs are laid out identically, one after the other, in the arena."""
+        a = self.arena
+        key = ('pos', a.p32.data_ptr())
+        pv = self._moe_cache.get(key)
+        if pv is not None:
+            return pv
+        pfx = f'{self.dp}transformer.wpe.models'
+        layers, i = [], 0
+        while f'{pfx}.0.model.{i}.weight' in a.entries:
+            ow, _, shp = a.entries[f'{pfx}.0.model.{i}.weight']
+            ob = a.entries[f'{pfx}.0.model.{i}.bias'][0]
+            layers.append(SimpleNamespace(N=shp[0], K=shp[1], W=a.pbf[ow:], gW=a.g32[ow:], b=a.p32[ob:], gb=a.g32[ob:]))
+            i += 2
+        n_pos = self.dec.block
+        stride = a.entries[f'{pfx}.1.model.0.weight'][0] - a.entries[f'{pfx}.0.model.0.weight'][0] if n_pos > 1 else 0
+        for t in (1, n_pos - 1):                              # the layout this relies on, checked once
+            for j, L in enumerate(layers):
+                if n_pos > 1:
+                    assert a.entries[f'{pfx}.{t}.model.{2 * j}.weight'][0] - a.entries[f'{pfx}.0.model.{2 * j}.weight'][0] == t * stride
+                    assert a.entries[f'{pfx}.{t}.model.{2 * j}.bias'][0] - a.entries[f'{pfx}.0.model.{2 * j}.bias'][0] == t * stride
+        pv = SimpleNamespace(layers=layers, stride=stride)
+        self._moe_cache[key] = pv
+        return pv
+
+    def _pos_plan(self, B: int, T: int, vl):
+        """Position-major row order of a batch: rows of position 0 first, then position 1, ...  -> (row index list, segment table)."""
+        key = ('posplan', B, T) if vl is None else None
+        if key is not None and key in self._sub_cache:
+            return self._sub_cache[key]
+        dev = self.arena.device
+        if vl is None:
+            rows = (np.arange(T, dtype=np.int64)[:, None] + np.arange(B, dtype=np.int64)[None] * T).ravel()
+            seg = np.arange(T + 1, dtype=np.int64) * B
+            max_rows = B
+        else:
+            lens = np.asarray(vl.lens_host, dtype=np.int64)
+            cu = np.zeros(B + 1, dtype=np.int64)
+            cu[1:] = np.cumsum(lens)
+            order = np.argsort(-lens, kind='stable')                      # sequences by decreasing length: position t holds the first n_t
+            n_t = (lens[None, :] > np.arange(T)[:, None]).sum(axis=1)       # sequences that reach position t
+            seg = np.zeros(T + 1, dtype=np.int64)
+            seg[1:] = np.cumsum(n_t)
+            rows = _expand_rows(np.arange(T, dtype=np.int64), cu[order], n_t).astype(np.int64) if int(n_t.sum()) else np.zeros(0, dtype=np.int64)
+            max_rows = int(n_t.max()) if T else 0
+        plan = SimpleNamespace(rows=torch.from_numpy(rows.astype(np.int32)).to(dev), seg=torch.from_numpy(seg.astype(np.int32)).to(dev),
+                               max_rows=max(max_rows, 1), G=T, M=int(rows.size))
+        if key is not None:
+            self._sub_cache[key] = plan
+        return plan
+
+    def posmlp_fwd(self, x_emb, B: int, T: int, pos_offset: int, vl, save: bool):
+        """x[row] = MLP_p(e[row]) + e[row] with p = pos_offset + position of the row (decoder.py:231-232).  x_emb fp32 [M, d]."""
+        pv = self._pos_views()
+        plan = self._pos_plan(B, T, vl)
+        M, d = plan.M, self.dec.d
+        e32, ebf = self._empty(M, d), self._empty(M, d, dtype=BF16)
+        ops.gather_rows(x_emb, plan.rows, M, d, out_f32=e32, out_bf16=ebf)
+        h, hs, pres = ebf, [ebf], []
+        kw = dict(seg=plan.seg, n_groups=plan.G, max_rows=plan.max_rows, group0=pos_offset, b_group_stride=pv.stride, bias_group_stride=pv.stride)
+        for i, L in enumerate(pv.layers):
+            last = i == len(pv.layers) - 1
+            out = self._empty(M, L.N, dtype=F32 if last else BF16)
+            pre = self._empty(M, L.N, dtype=BF16) if (save and not last) else None
+            ops.grouped_gemm(0, h, L.W[:L.N * L.K].view(L.N, L.K), out, L.N, L.K, bias=L.b, act=0 if last else 1, aux_out=pre,
+                             residual=e32 if last else None, **kw)
+            if not last:
+                hs.append(out)
+                pres.append(pre)
+            h = out
+        x = self._empty(M, d)
+        ops.scatter_rows(h, plan.rows, x, M, d)
+        return x, (SimpleNamespace(plan=plan, hs=hs, pres=pres, pos_offset=pos_offset) if save else None)
+
+    def posmlp_bwd(self, sv, dx):
+        """dx fp32 [M, d] (packed order): accumulates the gradients of every position's MLP, returns d/d(embedding) fp32 [M, d]."""
+        pv, plan = self._pos_views(), sv.plan
+        M, d = plan.M, self.dec.d
+        dy32, g = self._empty(M, d), self._empty(M, d, dtype=BF16)
+        ops.gather_rows(dx, plan.rows, M, d, out_f32=dy32, out_bf16=g)
+        kw = dict(seg=plan.seg, n_groups=plan.G, max_rows=plan.max_rows, group0=sv.pos_offset)
+        de = None
+        for i in reversed(range(len(pv.layers))):
+            L = pv.layers[i]
+            ops.grouped_gemm(2, g, sv.hs[i], L.gW[:L.N * L.K].view(L.N, L.K), L.N, L.K, c_group_stride=pv.stride, accumulate=True, **kw)
+            ops.grouped_colsum(g, plan.seg, plan.G, L.gb, pv.stride, sv.pos_offset, L.N)
+            W = L.W[:L.N * L.K].view(L.N, L.K)
+            if i > 0:
+                nxt = self._empty(M, L.K, dtype=BF16)
+                ops.grouped_gemm(1, g, W, nxt, L.N, L.K, b_group_stride=pv.stride, act=2, aux_in=sv.pres[i - 1], **kw)
+                g = nxt
+            else:
+                de = self._empty(M, d)
+                ops.grouped_gemm(1, g, W, de, L.N, L.K, b_group_stride=pv.stride, residual=dy32, **kw)
+        out = self._empty(M, d)
+        ops.scatter_rows(de, plan.rows, out, M, d)
+        return out
+
     # ------------------------------------------------------------------------------------------------ one block
     def fam_block_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl):
         a = self.arena

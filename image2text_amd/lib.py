@@ -68,6 +68,8 @@ SIGNATURES = {
     'i2t_gq_decode_attention': [P, P, I, P, P, I, P, P, L, I, P, I, P, I, I, I, I, I, I],
     'i2t_sparse_step_setup': [P, P, P, P, P, P, I, I],
     'i2t_select_rows': [P, P, P, P, P, L],
+    'i2t_grouped_gemm': [P, I, P, I, P, I, L, P, I, L, I, P, L, I, P, P, I, P, I, I, P, I, I, P, I, I, I],
+    'i2t_grouped_colsum': [P, P, I, P, I, P, L, I, I],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

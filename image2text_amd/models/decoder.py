@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ..configs.models import HuggingfaceDecoderConfig, TransformerDecoderConfig
-from .layers import LayerNorm, TransformerBlock, init_gpt_weights_
+from .layers import AdvancedPositionalBiasMLP, LayerNorm, TransformerBlock, init_gpt_weights_
 from .utils import mutate_transformer_config
 
 
@@ -58,15 +58,19 @@ class TransformerDecoder(Decoder):
     def __init__(self, config: TransformerDecoderConfig, space_for_prompt: int):
         super().__init__()
         if config.use_advanced_pos_emb:
-            raise NotImplementedError('use_advanced_pos_emb (per-position MLP) is outside the HIP hot path')
+            gs = tuple(config.advanced_pos_emb_gate_sizes or ())
+            d_ = config.transformer_config.attn_config.n_embd
+            if any(g % 32 for g in gs) or d_ % 32:
+                raise NotImplementedError('advanced_pos_emb_gate_sizes / n_embd must be multiples of 32 (MFMA k-step of the grouped GEMM)')
         self.config = config
-        self.use_advanced_pos_emb = False
+        self.use_advanced_pos_emb = config.use_advanced_pos_emb
         self.enable_gradient_checkpointing = config.enable_gradient_checkpointing
         self.skip_alternate_cross_attn = config.skip_alternate_cross_attn
         d = config.transformer_config.attn_config.n_embd
         self.transformer = nn.ModuleDict(dict(
             wte=nn.Embedding(config.vocab_size, d),
-            wpe=nn.Embedding(config.block_size, d),
+            wpe=AdvancedPositionalBiasMLP(config.block_size, d, d, config.advanced_pos_emb_gate_sizes, add_residual_connection=True)
+            if config.use_advanced_pos_emb else nn.Embedding(config.block_size, d),
             drop=nn.Dropout(config.transformer_config.attn_config.dropout),
             h=nn.ModuleList([
                 TransformerBlock(mutate_transformer_config(config.transformer_config, depth, config.skip_alternate_cross_attn),

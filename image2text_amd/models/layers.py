@@ -93,19 +93,33 @@ class SelfAttention:
 
 
 class MLP(_Container):
-    """Linear [GELU(tanh) Linear]* -- Sequential slots 0,2,4,... hold the Linears (reference layers.py:222-255); here only as
-    the expert gate of MoELinear (no residual connector)."""
+    """Linear [GELU(tanh) Linear]* -- Sequential slots 0,2,4,... hold the Linears (reference layers.py:222-255): the expert gate of
+    MoELinear (no residual connector) and the per-position MLPs of AdvancedPositionalBiasMLP (identity residual connector)."""
 
-    def __init__(self, in_features: int, out_features: int, gate_sizes: Optional[Tuple[int, ...]] = None, bias: bool = True):
+    def __init__(self, in_features: int, out_features: int, gate_sizes: Optional[Tuple[int, ...]] = None, bias: bool = True,
+                 add_residual_connection: bool = False):
         super().__init__()
         blocks, prev = [], in_features
         for width in (gate_sizes or []):
             blocks += [nn.Linear(prev, width, bias=bias), nn.GELU(approximate='tanh')]
             prev = width
         blocks.append(nn.Linear(prev, out_features, bias=bias))
-        self.add_residual_connection = False
+        self.add_residual_connection = add_residual_connection
         self.model = nn.Sequential(*blocks)
+        if add_residual_connection and in_features != out_features:
+            raise NotImplementedError('MLP residual connector with in_features != out_features is outside the HIP hot path')
         self.residual_connector = nn.Identity()
+
+
+class AdvancedPositionalBiasMLP(_Container):
+    """One MLP (with identity residual) per position: x_p = MLP_p(e_p) + e_p (reference layers.py:617-638); the decoder's ``wpe``
+    when ``use_advanced_pos_emb`` is set."""
+
+    def __init__(self, context_width: int, in_features: int, out_features: int, gate_sizes: Optional[Tuple[int, ...]] = None,
+                 add_residual_connection: bool = True):
+        super().__init__()
+        self.models = nn.ModuleList([MLP(in_features, out_features, gate_sizes, bias=True, add_residual_connection=add_residual_connection)
+                                     for _ in range(context_width)])
 
 
 class _MoEUnit(_Container):

@@ -227,6 +227,25 @@ def select_rows(flag, a, b, out, n):
     _l.check(_lib().i2t_select_rows(_stream(), _p(flag), _p(a), _p(b), _p(out), n), 'i2t_select_rows')
 
 
+def grouped_gemm(mode, a, b, c, N, K, *, b_group_stride=0, c_group_stride=0, bias=None, bias_group_stride=0, act=0, aux_in=None,
+                 aux_out=None, residual=None, accumulate=False, seg=None, n_groups=1, max_rows=0, group_ptr=None, group0=0):
+    """One GEMM per group (position) in one launch; see include/i2t.h::i2t_grouped_gemm for the three modes."""
+    _need_cuda(a, b, c)
+    assert a.dtype == BF16 and b.dtype == BF16 and c.dtype in (BF16, F32)
+    aux = aux_in if aux_in is not None else aux_out
+    _l.check(_lib().i2t_grouped_gemm(_stream(), mode, _p(a), a.stride(0), _p(b), b.stride(0), b_group_stride, _p(c), c.stride(0),
+                                     c_group_stride, int(c.dtype == F32), _p(bias), bias_group_stride, int(act), _p(aux_in), _p(aux_out),
+                                     aux.stride(0) if aux is not None else 0, _p(residual), residual.stride(0) if residual is not None else 0,
+                                     int(accumulate), _p(seg), n_groups, max_rows, _p(group_ptr), group0, N, K), 'i2t_grouped_gemm')
+    return c
+
+
+def grouped_colsum(x, seg, n_groups, out, out_group_stride, group0, N):
+    _need_cuda(x, seg, out)
+    _l.check(_lib().i2t_grouped_colsum(_stream(), _p(x), x.stride(0), _p(seg), n_groups, _p(out), out_group_stride, group0, N),
+             'i2t_grouped_colsum')
+
+
 def xattn_kv_fused(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, drop=None, cu_q=None, total_q=0):
     """Fused cross-attention forward (include/i2t.h::i2t_xattn_kv_fused): kv = mem . w_kv^T + bias written once, attention of every
     (image, head) out of the projection's accumulators.  q / o: [B, Tq, >= 64 H] views or packed [rows, >= 64 H] with cu_q."""

@@ -101,7 +101,8 @@ def _family_config(*, img: int, num_patches: int, conv_gates, conv_out: int, ker
                    enc_layers: int, dec_layers: int, block_size: int, vocab: int, dropout: float, experts: int, proj: int, gate_sizes,
                    enc_ff: float, dec_ff: float, enc_top_k: int, dec_top_k: int, sparsity: float, sparse: bool = True,
                    attn_type=SelfAttentionType.MULTI_QUERY, moe: bool = True, use_cross_attn: bool = True,
-                   use_soft_prompting: bool = True, skip_alternate_cross_attn: bool = True) -> VisionEncoderDecoderConfig:
+                   use_soft_prompting: bool = True, skip_alternate_cross_attn: bool = True,
+                   advanced_pos_emb_gate_sizes=None) -> VisionEncoderDecoderConfig:
     """The nano-mini topology (reference training_configs/gpu/nano-mini.yaml:17-78): multi-query attention, MoE rotators,
     sparse token subsets with max_block_size = patches + n_cls (encoder) / block_size + n_cls (decoder)."""
     P2 = num_patches ** 2
@@ -126,7 +127,8 @@ def _family_config(*, img: int, num_patches: int, conv_gates, conv_out: int, ker
     dec = TransformerDecoderConfig(
         transformer_config=tf(True, dec_ff, dec_top_k, True, True, block_size + n_cls),
         n_layer=dec_layers, block_size=block_size, vocab_size=vocab, enable_gradient_checkpointing=False,
-        skip_alternate_cross_attn=skip_alternate_cross_attn)
+        skip_alternate_cross_attn=skip_alternate_cross_attn, use_advanced_pos_emb=advanced_pos_emb_gate_sizes is not None,
+        advanced_pos_emb_gate_sizes=tuple(advanced_pos_emb_gate_sizes) if advanced_pos_emb_gate_sizes else None)
     return VisionEncoderDecoderConfig(vision_encoder_config=enc, decoder_config=dec, use_cross_attn=use_cross_attn,
                                       use_soft_prompting=use_soft_prompting, no_repeat_n_grams=(2, 3, 4, 5))
 
@@ -225,7 +227,7 @@ def det_init_(module: torch.nn.Module, seed: int = 0, style: str = 'stress') -> 
         elif p.dim() == 4:                         # conv kernels: keep activations O(1)
             fan_in = p.shape[1] * p.shape[2] * p.shape[3]
             x = x / (fan_in ** 0.5)
-        elif '.wte.' in name or '.wpe.' in name or name.startswith('lm_head') or '.lm_head.' in name:
+        elif ('.wte.' in name or '.wpe.' in name or name.startswith('lm_head') or '.lm_head.' in name) and '.wpe.models.' not in name:
             x = 0.02 * x                           # embeddings / tied head: reference decoder.py:206-212 scale
         elif p.dim() == 2:
             x = 0.7 * x / (p.shape[1] ** 0.5)      # linear maps: O(1) activations, non-flat attention softmax

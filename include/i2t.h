@@ -363,6 +363,23 @@ int i2t_gq_decode_attention(void* stream, const void* q, int q_rs, const void* k
 int i2t_sparse_step_setup(void* stream, const int* pos_ptr, const int* rank, const int* member, int* lpos, int* lmem, int L, int tmax);
 int i2t_select_rows(void* stream, const int* flag, const float* a, const float* b, float* out, long n);
 
+/* Grouped small GEMMs for AdvancedPositionalBiasMLP (reference models/layers.py:617-638, decoder.py:231-232: every position owns a
+ * private MLP, so one layer of the module is one GEMM per position).  Group g = position; its rows are rows [seg[g], seg[g+1]) of
+ * the row-major operands (position-major order; seg = device int[n_groups + 1]; max_rows = the largest group), its weights
+ * W_g = B + (g + group0) * b_group_stride (bf16 [N][K]), bias b_g = bias + (g + group0) * bias_group_stride (f32 [N]).
+ *   mode 0: C[rows][N] = act(A[rows][K] . W_g^T + b_g) (+ residual)   act = I2T_ACT_GELU keeps the pre-activation in aux_out (bf16)
+ *   mode 1: C[rows][K] = (A[rows][N] . W_g) * gelu'(aux_in) (+ residual)          (act = I2T_ACT_DGELU, or none)
+ *   mode 2: C_g[N][K] (+)= A_g[rows][N]^T . B_g[rows][K]   with C_g = C + (g + group0) * c_group_stride (f32; B = the layer input rows)
+ * group_ptr (device int, modes 0 / 1 with n_groups = 1, seg null): every one of the max_rows rows uses group *group_ptr + group0
+ * (the decode step under hipGraph replay).  N, K multiples of 32.
+ * i2t_grouped_colsum: out[(g + group0) * out_group_stride + n] += sum over the rows of group g of X[row][n]  (bias gradients). */
+int i2t_grouped_gemm(void* stream, int mode, const void* A, int lda, const void* B, int ldb, long b_group_stride, void* C, int ldc,
+                     long c_group_stride, int c_is_f32, const float* bias, long bias_group_stride, int act, const void* aux_in,
+                     void* aux_out, int ld_aux, const float* residual, int ldr, int accumulate, const int* seg, int n_groups,
+                     int max_rows, const int* group_ptr, int group0, int N, int K);
+int i2t_grouped_colsum(void* stream, const void* X, int ld, const int* seg, int n_groups, float* out, long out_group_stride,
+                       int group0, int N);
+
 /* hipGraph capture around any sequence of the calls above (replaces the Python loop of
  * vision_encoder_decoder.py:143-180 with one replayed launch per token) */
 int i2t_graph_capture_begin(void* stream);

@@ -339,7 +339,13 @@ def gpt_decoder(sd: SD, cfg, idx=None, inputs_embeds=None, cross_attn_embeds=Non
         inputs_embeds = sd['transformer.wte.weight'][idx]
     t = inputs_embeds.size(1)
     assert t <= cfg.block_size, f'Cannot forward sequence of length {t}, block size is only {cfg.block_size}'
-    x = inputs_embeds + sd['transformer.wpe.weight'][pos_offset:pos_offset + t]
+    if 'transformer.wpe.models.0.model.0.weight' in sd:
+        # decoder.py:231-232 + layers.py:617-638 AdvancedPositionalBiasMLP: position p has its OWN MLP (Linear [GELU Linear]*, biased)
+        # with an identity residual connector: x_p = MLP_p(e_p) + e_p
+        x = torch.stack([gate_mlp(sd, f'transformer.wpe.models.{pos_offset + p}', inputs_embeds[..., p, :]) + inputs_embeds[..., p, :]
+                         for p in range(t)], dim=-2)
+    else:
+        x = inputs_embeds + sd['transformer.wpe.weight'][pos_offset:pos_offset + t]
     x = _planned(plan.get(0, 'emb'), x) if plan is not None else _drop(x, ac.dropout, training)
     for depth in range(cfg.n_layer):
         mem = cross_attn_embeds if (depth % 2 == 0 or not cfg.skip_alternate_cross_attn) else None

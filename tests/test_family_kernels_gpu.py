@@ -255,3 +255,63 @@ def test_moe_linear_two_gemm_form(ops, M, inf, outf, E, P, G, top_k):
         check('dwg2', dwg2, wg2r.grad, 4e-2 * float(wg2r.grad.abs().max()), 4e-2)
         check('dbg2', dbg2, bg2r.grad, 4e-2 * float(bg2r.grad.abs().max()), 4e-2)
     check('dx', dx, xr.grad, 4e-2 * float(xr.grad.abs().max()), 4e-2)
+
+
+@pytest.mark.parametrize('G,N,K,lens', [(5, 32, 256, [7, 0, 64, 130, 1]), (3, 256, 32, [65, 64, 3]), (4, 128, 64, [10, 20, 30, 40]),
+                                        (2, 1024, 32, [300, 5])])
+def test_grouped_gemm_three_modes(ops, G, N, K, lens):
+    """i2t_grouped_gemm (csrc/grouped.hip): forward with bias / GELU / residual, dX with the GELU derivative, dW accumulation and the
+    grouped bias gradient against per-group fp64 products"""
+    group0, n_pos = 2, G + 3
+    seg_h = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    M = int(seg_h[-1])
+    seg = torch.from_numpy(seg_h).to(dev())
+    stride = N * K + 24                                   # weights of consecutive positions a constant stride apart (with a gap)
+    Wall = rnd(n_pos * stride, scale=K ** -0.5, dtype=BF16, seed=470)
+    ball = rnd(n_pos * stride, scale=0.3, seed=471)
+    X = rnd(M, K, dtype=BF16, seed=472)
+    res = rnd(M, N, seed=473)
+    Wg = lambda g: Wall[(g + group0) * stride:(g + group0) * stride + N * K].view(N, K)
+    bg = lambda g: ball[(g + group0) * stride:(g + group0) * stride + N]
+    W0, b0 = Wall[:N * K].view(N, K), ball
+    # mode 0: gelu + pre-activation
+    Y, pre = torch.full((M, N), float('nan'), dtype=BF16, device=dev()), torch.full((M, N), float('nan'), dtype=BF16, device=dev())
+    ops.grouped_gemm(0, X, W0, Y, N, K, b_group_stride=stride, bias=b0, bias_group_stride=stride, act=1, aux_out=pre, seg=seg, n_groups=G,
+                     max_rows=max(lens), group0=group0)
+    Yf = torch.full((M, N), float('nan'), device=dev())
+    ops.grouped_gemm(0, X, W0, Yf, N, K, b_group_stride=stride, bias=b0, bias_group_stride=stride, residual=res, seg=seg, n_groups=G,
+                     max_rows=max(lens), group0=group0)
+    dY = rnd(M, N, dtype=BF16, seed=474)
+    dX = torch.full((M, K), float('nan'), dtype=BF16, device=dev())
+    aux = rnd(M, K, dtype=BF16, seed=475)
+    ops.grouped_gemm(1, dY, W0, dX, N, K, b_group_stride=stride, act=2, aux_in=aux, seg=seg, n_groups=G, max_rows=max(lens), group0=group0)
+    dW = rnd(n_pos * stride, seed=476)
+    dW_before = dW.clone()
+    ops.grouped_gemm(2, dY, X, dW[:N * K].view(N, K), N, K, c_group_stride=stride, accumulate=True, seg=seg, n_groups=G, max_rows=max(lens),
+                     group0=group0)
+    db = torch.zeros(n_pos * stride, device=dev())
+    ops.grouped_colsum(dY, seg, G, db, stride, group0, N)
+    from test_kernels_gpu import gelu_grad
+    for g in range(G):
+        lo, hi = int(seg_h[g]), int(seg_h[g + 1])
+        if hi == lo:
+            continue
+        z = X[lo:hi].double() @ Wg(g).double().t() + bg(g).double()
+        check(f'pre g{g}', pre[lo:hi], z, 2e-2, 1e-2)
+        check(f'gelu g{g}', Y[lo:hi], F.gelu(z, approximate='tanh'), 2e-2, 1e-2)
+        check(f'f32+res g{g}', Yf[lo:hi], z + res[lo:hi].double(), 1e-3, 1e-3)
+        want_dx = (dY[lo:hi].double() @ Wg(g).double()) * gelu_grad(aux[lo:hi].double())
+        check(f'dx g{g}', dX[lo:hi], want_dx, 3e-2, 2e-2)
+        o = (g + group0) * stride
+        check(f'dW g{g}', dW[o:o + N * K].view(N, K), dW_before[o:o + N * K].view(N, K).double() + dY[lo:hi].double().t() @ X[lo:hi].double(),
+              2e-3 * (hi - lo) ** 0.5, 2e-3)
+        check(f'db g{g}', db[o:o + N], dY[lo:hi].double().sum(0), 1e-3, 1e-3)
+    # untouched: other positions' weights gradients and the gaps
+    o0, o1 = group0 * stride, (group0 + G) * stride
+    assert torch.equal(dW[:o0], dW_before[:o0]) and torch.equal(dW[o1:], dW_before[o1:])
+    # device-side group index (the decode step): every row uses group *ptr + group0
+    ptr = torch.tensor([1], dtype=torch.int32, device=dev())
+    Yd = torch.empty(9, N, dtype=BF16, device=dev())
+    ops.grouped_gemm(0, X[:9].contiguous(), W0, Yd, N, K, b_group_stride=stride, bias=b0, bias_group_stride=stride, act=1, n_groups=1, max_rows=9,
+                     group_ptr=ptr, group0=group0)
+    check('decode group', Yd, F.gelu(X[:9].double() @ Wg(1).double().t() + bg(1).double(), approximate='tanh'), 2e-2, 1e-2)

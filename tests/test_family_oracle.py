@@ -19,6 +19,7 @@ VARIANTS = {
     'no_gate_hidden': dict(gate_sizes=None),
     'heads16': dict(d=64, heads=4, proj=8, gate_sizes=None, enc_ff=2.5, dec_ff=2.5, dec_top_k=2),
     'all_cross': dict(skip_alternate_cross_attn=False),
+    'advpos': dict(advanced_pos_emb_gate_sizes=(32, 64, 32)),
 }
 
 
@@ -161,3 +162,24 @@ def test_nano_mini_full_size():
         flips += int(diff.sum())
         total += diff.size
     assert flips <= 1e-3 * total
+
+
+def test_advanced_positional_mlp_gradients():
+    """AdvancedPositionalBiasMLP (layers.py:617-638): gradients of the per-position MLPs of a few text positions"""
+    f = load_golden('mini_variants.npz')
+    cfg = variant_config('advpos')
+    w = family_weights(cfg)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in w.items() if k != 'decoder.lm_head.weight'}
+    sd['decoder.lm_head.weight'] = sd['decoder.transformer.wte.weight']
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    loss = orc.lm_step(sd, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['labels']), tok, training=True)
+    loss.backward()
+    keys = [k for k in f if k.startswith('advpos.grad.')]
+    assert len(keys) == 4 * 8            # positions 8, 9, 20, 31 (prompt 8 + text 0, 1, 12, 23); position 32 is past the sequence
+    for k in keys:
+        name = k[len('advpos.grad.'):]
+        close(sd[name].grad, f[k], 1e-6 + 1e-3 * float(np.abs(f[k]).max()))
+    # and the text-segment form (position offset = prompt length) gives the same loss
+    with torch.no_grad():
+        l2 = orc.lm_step_text_segment(w, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['labels']), tok)
+    assert abs(l2.item() - float(f['advpos.loss'])) <= 2e-5
