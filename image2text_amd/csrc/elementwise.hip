@@ -606,6 +606,18 @@ extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, voi
     return I2T_OK;
 }
 
+extern "C" int i2t_sumsq(void* stream, const float* g, long n, float* ws, int accumulate) {
+    I2T_REQUIRE(g && ws && n > 0 && ALIGNED16(g), "i2t_sumsq: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
+        if (e != hipSuccess) { i2t_set_error("i2t_sumsq: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
+    }
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2, 1024)), dim3(256), 0, s, g, n >> 2, n, ws);
+    I2T_CHECK_LAUNCH("i2t_sumsq");
+    return I2T_OK;
+}
+
 extern "C" int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                               const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
                               float beta2, float eps, int step, float grad_scale) {

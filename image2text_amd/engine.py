@@ -285,7 +285,7 @@ class HotPath(FamilyBlocks):
             self._moe_cache.clear()
             self._sub_cache.clear()
         self.arena.refresh_shadow()
-        self.enc_drop = self.dec_drop = None
+        self.enc_drop = self.dec_drop = self.dec_drop_prompt = None
         if training:
             # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run, and
             # a later torch.manual_seed restarts the sequence) and from the data-parallel rank: replicas seeded identically
@@ -300,6 +300,7 @@ class HotPath(FamilyBlocks):
                                          compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
             if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
                 self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout)
+                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout)
         return self.arena
 
     @property
@@ -661,7 +662,7 @@ class HotPath(FamilyBlocks):
         return mem
 
     def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0, vl=None,
-                       dropout_without_save: bool = False):
+                       dropout_without_save: bool = False, drop_plan=None):
         """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [M,d], hidden bf16, ctx), M = B*T, or
         M = vl.total for packed variable-length rows (vl = namespace(cu, pos, total): ids is then the packed 1-D id list)."""
         a, dc = self.arena, self.dec
@@ -671,7 +672,8 @@ class HotPath(FamilyBlocks):
         x = self._empty(M, d)
         wpe = None if dc.advpos else a.P(f'{self.dp}transformer.wpe.weight')
         # (dropout_without_save: a forward that is never differentiated but runs in training mode -- the momentum twin)
-        plan = self.dec_drop if (save or dropout_without_save) else None
+        # (drop_plan: a second differentiated segment of the same step -- the prompt rows of the contrastive loss -- draws its own masks)
+        plan = (drop_plan if drop_plan is not None else self.dec_drop) if (save or dropout_without_save) else None
         emb_drop = plan.get(0, 'emb') if plan is not None else None
         pos_ctx = None
         if ids is not None:
@@ -684,11 +686,14 @@ class HotPath(FamilyBlocks):
                 x, pos_ctx = self.posmlp_fwd(x, B, T, pos_offset, vl, save)
             if emb_drop is not None:
                 ops.dropout_apply(x, M, d, emb_drop)
-        elif dc.advpos:
-            x, pos_ctx = self.posmlp_fwd(embeds.to(device=a.device, dtype=F32).contiguous().view(M, d), B, T, pos_offset, vl, save)
         else:
-            ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
-            ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
+            if dc.advpos:
+                x, pos_ctx = self.posmlp_fwd(embeds.to(device=a.device, dtype=F32).contiguous().view(M, d), B, T, pos_offset, vl, save)
+            else:
+                ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
+                ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
+            if emb_drop is not None:                          # decoder.py:233/238: the embedding dropout covers the prompt rows too
+                ops.dropout_apply(x, M, d, emb_drop)
         saves, cur = [], x
         for l in range(dc.L):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
@@ -703,7 +708,7 @@ class HotPath(FamilyBlocks):
         hb = self._empty(M, d, dtype=BF16)
         ops.cast_f32_bf16(hid, hb)
         ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset, vl=vl, M=M,
-                              emb_drop=emb_drop if ids is not None else None, pos_ctx=pos_ctx) if save else None
+                              emb_drop=emb_drop, pos_ctx=pos_ctx) if save else None
         return hid, hb, ctx
 
     def logits_f32(self, hb: torch.Tensor, M: int):
@@ -723,8 +728,44 @@ class HotPath(FamilyBlocks):
         ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), buf, M, self.dec.V, self.dec.d)
         return buf
 
+    @staticmethod
+    def _lockstep(*gens):
+        """Run backward generators side by side.  Each yields (key, its sum(g^2) part) at a gradient-normaliser site (keys
+        descend); generators stopped at the SAME key belong to one tensor in the reference (the prompt rows and the text rows of a
+        decoder block) and are sent the sum of their parts, everything else gets its own part back.  Returns their return values."""
+        state, results = {}, [None] * len(gens)
+        for i, g in enumerate(gens):
+            try:
+                state[i] = next(g)
+            except StopIteration as stop:
+                results[i] = stop.value
+        while state:
+            top = max(k for k, _ in state.values())
+            group = [i for i, (k, _) in state.items() if k == top]
+            joint = state[group[0]][1]
+            for i in group[1:]:
+                joint = joint + state[i][1]                    # 1-float device tensors: no host sync
+            for i in group:
+                try:
+                    state[i] = gens[i].send(joint)
+                except StopIteration as stop:
+                    results[i] = stop.value
+                    del state[i]
+        return results
+
     def decode_backward(self, ctx, dlogits_bf: Optional[torch.Tensor], dhid: Optional[torch.Tensor], dmem):
-        """dlogits_bf: bf16 [M, Vp] (pads zero) or None; dhid: fp32 [M, d] or None; dmem: fp32 [B*S, d] accumulator."""
+        """dlogits_bf: bf16 [M, Vp] (pads zero) or None; dhid: fp32 [M, d] or None; dmem: fp32 [B*S, d] accumulator.  Returns the
+        gradient w.r.t. ``embeds`` for an embeds-driven segment (None when the segment was driven by token ids)."""
+        return self._lockstep(self._decode_backward_steps(ctx, dlogits_bf, dhid, dmem, paired=False))[0]
+
+    def decode_backward_pair(self, ctx_a, dlogits_a, dhid_a, ctx_b, dlogits_b, dhid_b, dmem):
+        """Backward of two segments of ONE decoder sequence (text rows a, prompt rows b: reference vision_encoder_decoder.py:84-113)
+        whose block outputs the reference normalises as one tensor (layers.py:606-607): the two run layer by layer in lock step and
+        share every normaliser's sum.  Returns (None | d embeds_a, None | d embeds_b)."""
+        return self._lockstep(self._decode_backward_steps(ctx_a, dlogits_a, dhid_a, dmem, paired=True),
+                              self._decode_backward_steps(ctx_b, dlogits_b, dhid_b, dmem, paired=True))
+
+    def _decode_backward_steps(self, ctx, dlogits_bf, dhid, dmem, paired: bool):
         a, dc = self.arena, self.dec
         B, T, d, M = ctx.B, ctx.T, dc.d, ctx.M
         wte = f'{self.dp}transformer.wte.weight'
@@ -739,12 +780,19 @@ class HotPath(FamilyBlocks):
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
         if dc.fam is not None:
             for l in reversed(range(dc.L)):
-                dx = self.fam_layer_bwd(f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, B, T, ctx.S, dmem, ctx.vl)
+                dx = yield from self.fam_layer_bwd_steps(l, f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, B, T, ctx.S, dmem, ctx.vl)
+        elif paired:        # the un-fused form of _blocks_bwd: the normaliser's sum comes from outside
+            dxb = self._empty(M, d, dtype=BF16)
+            for l in reversed(range(dc.L)):
+                joint = yield l, ops.sumsq(dx, self._empty(1))
+                ops.grad_normalize(dx, joint, dxb, bf16_drop=ctx.saves[l].dr['mlp'], presummed=True)
+                self.block_bwd(f'{self.dp}transformer.h.{l}', ctx.saves[l], dx, dxb, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem,
+                               emit_last_bf16=False, vl=ctx.vl)
         else:
             self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl)
+        if ctx.emb_drop is not None:
+            ops.dropout_apply(dx, M, d, ctx.emb_drop)
         if ctx.ids is not None:
-            if ctx.emb_drop is not None:
-                ops.dropout_apply(dx, M, d, ctx.emb_drop)
             dwpe = None if dc.advpos else a.G(f'{self.dp}transformer.wpe.weight')
             if dc.advpos:
                 dx = self.posmlp_bwd(ctx.pos_ctx, dx)

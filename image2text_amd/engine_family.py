@@ -309,8 +309,9 @@ class FamilyBlocks:
         sv.x2, sv.ln2, sv.m2, sv.r2 = x2, ln2, m2, r2
         return x3, (sv if save else None)
 
-    def fam_block_bwd(self, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
-        """dx fp32 [M, d]: gradient w.r.t. the block output on entry (un-normalised), w.r.t. the block input on return."""
+    def fam_block_bwd(self, pfx: str, sp, sv, dx, B, T, S, dmem, vl, ws=None):
+        """dx fp32 [M, d]: gradient w.r.t. the block output on entry (un-normalised), w.r.t. the block input on return.
+        ws: 1 float holding sum(g^2) of the WHOLE tensor the reference normalises here (None: dx is that tensor)."""
         a = self.arena
         d, H, hd = sp.d, sp.H, sp.hd
         M = vl.total if vl is not None else B * T
@@ -320,7 +321,7 @@ class FamilyBlocks:
         bias = lambda n: n if a.G(n) is not None and n in a.params else None
         # normalize_gradients at the block output (layers.py:606-607); the bf16 copy feeds the MLP branch -> carries its dropout mask
         dxb = self._empty(M, d, dtype=BF16)
-        ops.grad_normalize(dx, self._empty(1), dxb, bf16_drop=dr['mlp'])
+        ops.grad_normalize(dx, self._empty(1) if ws is None else ws, dxb, bf16_drop=dr['mlp'], presummed=ws is not None)
         dln = self._empty(M, d, dtype=BF16)
         if sp.moe is not None:
             ff = sv.fc.pre.shape[1]
@@ -464,10 +465,13 @@ class FamilyBlocks:
             ops.scatter_rows(yn, sub.rows_out, out, sub.n_out, d)
         return out, (SimpleNamespace(only_null=False, block=bsv, xnb=xnb, sub=sub) if save else None)
 
-    def fam_layer_bwd(self, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
-        """Returns the gradient w.r.t. the layer input (dx itself for a dense layer, a new buffer for a sparse one)."""
+    def fam_layer_bwd_steps(self, key, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
+        """Generator form of the layer backward: yields (key, sum(g^2) of this segment's part of the block-output gradient) right
+        before the gradient normaliser and is sent back the sum to normalise with (engine.HotPath._lockstep); returns the gradient
+        w.r.t. the layer input (dx itself for a dense layer, a new buffer for a sparse one)."""
         if not hasattr(sv, 'only_null'):
-            self.fam_block_bwd(pfx, sp, sv, dx, B, T, S, dmem, vl)
+            joint = yield key, ops.sumsq(dx, self._empty(1))
+            self.fam_block_bwd(pfx, sp, sv, dx, B, T, S, dmem, vl, ws=joint)
             return dx
         d, M = sp.d, dx.shape[0]
         if sv.only_null:
@@ -475,10 +479,14 @@ class FamilyBlocks:
         sub = sv.sub
         dys = self._empty(sub.n_in, d)
         ops.gather_rows(dx, sub.rows_in, sub.n_in, d, out_f32=dys)
-        self.fam_block_bwd(pfx, sp, sv.block, dys, B, sub.T_in, S, dmem, sub.vl_in)
+        joint = yield key, ops.sumsq(dys, self._empty(1))
+        self.fam_block_bwd(pfx, sp, sv.block, dys, B, sub.T_in, S, dmem, sub.vl_in, ws=joint)
         out = self._empty(M, d)
         ops.scatter_rows(dys, sub.rows_in, out, sub.n_in, d)
         if sub.n_out:
             dxn = self._null_bwd(pfx, sv.xnb, dx, sub.n_out, d, sub.rows_out)
             ops.scatter_rows(dxn, sub.rows_out, out, sub.n_out, d)
         return out
+
+    def fam_layer_bwd(self, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
+        return self._lockstep(self.fam_layer_bwd_steps(0, pfx, sp, sv, dx, B, T, S, dmem, vl))[0]

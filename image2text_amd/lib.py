@@ -70,6 +70,7 @@ SIGNATURES = {
     'i2t_select_rows': [P, P, P, P, P, L],
     'i2t_grouped_gemm': [P, I, P, I, P, I, L, P, I, L, I, P, L, I, P, P, I, P, I, I, P, I, I, P, I, I, I],
     'i2t_grouped_colsum': [P, P, I, P, I, P, L, I, I],
+    'i2t_sumsq': [P, P, L, P, I],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

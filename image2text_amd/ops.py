@@ -319,6 +319,13 @@ def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=Non
     return g
 
 
+def sumsq(g: torch.Tensor, ws: torch.Tensor, accumulate=False):
+    """ws[0] (+)= sum(g^2)  (include/i2t.h::i2t_sumsq)"""
+    _need_cuda(g, ws)
+    _l.check(_lib().i2t_sumsq(_stream(), _p(g), g.numel(), _p(ws), int(accumulate)), 'i2t_sumsq')
+    return ws
+
+
 def conv_fwd(x, in_gelu, w, bias, y, w_ws, B, Cin, Cout, H, W, k):
     _need_cuda(x, w, y, w_ws)
     _l.check(_lib().i2t_conv_fwd(_stream(), _p(x), int(x.dtype == F32), int(in_gelu), _p(w), _p(bias), _p(y), _p(w_ws), B, Cin,

@@ -8,7 +8,10 @@ Trainer options (configs/trainer.py:7-15):
   * ``moco_momentum`` / ``moco_alpha`` (momentum distillation, wrapper.py:30-33,46-59,134-144): a second VisionEncoderDecoder
     (``model_m``, its own flat arenas) is run on the same packed rows without gradient, its bf16 logits are the soft targets of the
     fused distillation cross-entropy, and after every train step it is moved towards the model by one EMA launch over the arenas;
-  * ``add_contrastive_loss`` is refused (NotImplementedError): it differentiates the PROMPT rows of ``hidden_state``.
+  * ``add_contrastive_loss`` (wrapper.py:98-118): the hidden rows [prompt rows | text rows] against the target embeddings of the
+    whole batch -- one GEMM whose -inf column bias masks the ignored positions, the same fused cross-entropy kernels on its
+    diagonal labels, and a backward that runs the prompt segment of the decoder (the only consumer of its gradient) into the
+    encoder output and scatter-adds the target-embedding gradient into wte.
 """
 from typing import Tuple
 
@@ -17,7 +20,7 @@ import torch.nn as nn
 
 from ..configs.models import VisionEncoderDecoderConfig
 from ..configs.trainer import TrainerWrapperConfig
-from ..engine import F32, HotPath
+from ..engine import BF16, F32, HotPath
 from ..models.vision_encoder_decoder import VisionEncoderDecoder
 from .. import ops
 
@@ -45,7 +48,7 @@ class _LMLossFunction(torch.autograd.Function):
             ids_p = ids[:, :T]
             lab = labels[:, :T].contiguous().view(M)
             w = weights[:, :T].contiguous().view(M)
-        _, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids_p, pos_offset=off, vl=vl)
+        hid, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids_p, pos_offset=off, vl=vl)
         logits = eng.logits_bf16(hb, M, capacity=B * T)
         lse = torch.empty(M, dtype=F32, device=a.device)
         loss = torch.zeros(1, dtype=F32, device=a.device)
@@ -65,16 +68,22 @@ class _LMLossFunction(torch.autograd.Function):
                                M, eng.dec.V)
         else:
             ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, eng.dec.V)
-        ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, teacher, lse_t) if save else None
-        return loss[0]
+        con = None
+        loss_c = torch.zeros(1, dtype=F32, device=a.device)
+        if wrapper.add_contrastive_loss:
+            con = _contrastive_forward(wrapper, eng, enc_out, mem, hid, labels, B, T, ncls, vl, save, loss_c)
+        ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, teacher, lse_t, con) if save else None
+        return loss[0], loss_c[0]
 
     @staticmethod
-    def backward(ctx, g):
-        wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, teacher, lse_t = ctx.pack
+    def backward(ctx, g, g_c):
+        wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, teacher, lse_t, con = ctx.pack
         eng: HotPath = wrapper.model._engine
         a = eng.arena
         eng.notify_grads_ready('begin')          # e.g. the DP exchange drains whatever is still in flight on the arena
         a.begin_backward()
+        if g is None:
+            g = torch.zeros((), dtype=F32, device=a.device)
         gscale = g.reshape(1).to(F32).contiguous()              # stays on the device: no host sync
         if teacher is not None:
             ops.ce_distill_bwd(logits, eng.dec.Vp, teacher, teacher.stride(0), wrapper.alpha, lab, w, inv_t, wrapper.ignore_index, lse, lse_t,
@@ -82,13 +91,119 @@ class _LMLossFunction(torch.autograd.Function):
         else:
             ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, M, eng.dec.V)
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
-        eng.decode_backward(dctx, logits, None, dmem)
+        if con is not None and g_c is not None:
+            dhid, dph = _contrastive_backward(wrapper, eng, con, g_c, M)
+            if con.pctx is not None:      # text rows and prompt rows are ONE sequence to the blocks' gradient normalisers: lock step
+                _, dxp = eng.decode_backward_pair(dctx, logits, dhid, con.pctx, None, dph, dmem)
+                dmem.view(B, ncls, -1)[:, :con.n_p].add_(dxp.view(B, con.n_p, -1))      # d/d(inputs_embeds) of the prompt rows
+            else:
+                eng.decode_backward(dctx, logits, dhid, dmem)
+        else:
+            eng.decode_backward(dctx, logits, None, dmem)
         eng.notify_grads_ready('decoder')
         eng.encode_backward(enc_ctx, dmem)
         eng.notify_grads_ready('encoder')
         a.attach_grads()
         ctx.pack = None
         return None, None, None, None, None, None, None, None
+
+
+def _contrastive_rows(B: int, T: int, n_p: int, Lc: int, vl, dev):
+    """Row maps of the contrastive term's hidden rows (wrapper.py:99-104): position c of sequence b is prompt row c (c < n_p) or text
+    row c - n_p.  Returns (source rows in the text segment's row space, their destinations in [B * Lc], prompt sources, destinations)."""
+    import numpy as np
+    n_pc, Lt = min(n_p, Lc), max(Lc - n_p, 0)
+    b = np.arange(B, dtype=np.int64)
+    if vl is None:
+        t = np.arange(min(Lt, T), dtype=np.int64)
+        src = (b[:, None] * T + t[None]).ravel()
+        dst = (b[:, None] * Lc + n_p + t[None]).ravel()
+    else:
+        full = np.asarray(vl.lens_host, dtype=np.int64)
+        lens = np.minimum(full, Lt)
+        cu = np.zeros(B + 1, dtype=np.int64)
+        cu[1:] = np.cumsum(full)
+        seq = np.repeat(b, lens)
+        within = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+        src, dst = cu[seq] + within, seq * Lc + n_p + within
+    c = np.arange(n_pc, dtype=np.int64)
+    psrc, pdst = (b[:, None] * n_p + c[None]).ravel(), (b[:, None] * Lc + c[None]).ravel()
+    to = lambda x: torch.from_numpy(x.astype(np.int32)).to(dev)
+    return to(src), to(dst), to(psrc), to(pdst)
+
+
+def _contrastive_forward(wrapper, eng, enc_out, mem, hid, labels, B, T, ncls, vl, save, loss_out):
+    """The contrastive term (reference training/wrapper.py:98-118) on the device: hidden rows [prompt rows | text rows] of every
+    sequence against the target embeddings wte[label] of the whole batch; ignored positions are masked out as columns through a
+    -inf GEMM bias and skipped as rows.  Adds the loss into loss_out; returns what backward needs."""
+    from types import SimpleNamespace
+    a, cfg = eng.arena, wrapper.model.config
+    d, dev = eng.dec.d, a.device
+    n_p = min(ncls, eng.dec.block) if cfg.use_soft_prompting else 0
+    L = labels.shape[1]
+    Lc = min(L, n_p + T)
+    N = B * Lc
+    pctx = ph = None
+    if n_p:        # the prompt rows of hidden_state: their own causal segment (text never attends to them), differentiated here
+        ph, _, pctx = eng.decode_segment(B, n_p, mem, ncls, save, embeds=enc_out[:, :n_p].reshape(B * n_p, -1), pos_offset=0,
+                                         drop_plan=eng.dec_drop_prompt)
+    src, dst, psrc, pdst = _contrastive_rows(B, T, n_p, Lc, vl, dev)
+    Hc = torch.zeros(N, d, dtype=F32, device=dev)
+    tmp = torch.empty(max(src.numel(), psrc.numel(), 1), d, dtype=F32, device=dev)
+    if src.numel():
+        ops.gather_rows(hid, src, src.numel(), d, out_f32=tmp)
+        ops.scatter_rows(tmp, dst, Hc, src.numel(), d)
+    if psrc.numel():
+        ops.gather_rows(ph, psrc, psrc.numel(), d, out_f32=tmp)
+        ops.scatter_rows(tmp, pdst, Hc, psrc.numel(), d)
+    Hb = torch.empty(N, d, dtype=BF16, device=dev)
+    ops.cast_f32_bf16(Hc, Hb)
+    lab_c = labels[:, :Lc].contiguous().view(N)
+    keep = lab_c != wrapper.ignore_index
+    ids0 = torch.where(keep, lab_c, torch.zeros_like(lab_c))
+    E = torch.empty(N, d, dtype=F32, device=dev)
+    ops.embed_fwd(ids0, a.P(f'{eng.dp}transformer.wte.weight'), None, E, N, 1, d, 0, eng.dec.V)
+    Eb = torch.empty(N, d, dtype=BF16, device=dev)
+    ops.cast_f32_bf16(E, Eb)
+    Np = (N + 7) // 8 * 8
+    colbias = torch.zeros(Np, dtype=F32, device=dev)
+    colbias[:N].masked_fill_(~keep, float('-inf'))
+    P = torch.zeros(N, Np, dtype=BF16, device=dev)
+    ops.gemm(Hb, Eb, P, N, N, d, bias=colbias)
+    w_c = wrapper.get_weights(labels[:, :Lc]).contiguous().view(N)
+    diag = torch.where(keep, torch.arange(N, device=dev), torch.full_like(lab_c, wrapper.ignore_index))
+    lse = torch.empty(N, dtype=F32, device=dev)
+    inv_t = 1.0 / wrapper.contrastive_temperature
+    ops.ce_fwd(P, Np, diag, w_c, inv_t, wrapper.ignore_index, lse, loss_out, N, N)
+    if not save:
+        return None
+    return SimpleNamespace(P=P, Np=Np, N=N, diag=diag, w=w_c, lse=lse, inv_t=inv_t, Hb=Hb, Eb=Eb, ids0=ids0, pctx=pctx, n_p=n_p, B=B,
+                           rows=(src, dst, psrc, pdst))
+
+
+def _contrastive_backward(wrapper, eng, con, g_c, M):
+    """Gradient of the contrastive term onto the target embeddings (accumulated into wte's gradient) and onto the hidden rows:
+    returns (d text hidden fp32 [M, d], d prompt hidden fp32 [B n_p, d] | None)."""
+    a = eng.arena
+    d, dev, N = eng.dec.d, a.device, con.N
+    ops.ce_bwd(con.P, con.Np, con.diag, con.w, con.inv_t, wrapper.ignore_index, con.lse, g_c.reshape(1).to(F32).contiguous(), N, N)
+    dH = torch.empty(N, d, dtype=F32, device=dev)
+    ops.gemm(con.P, con.Eb, dH, N, d, N, b_kmajor=True)
+    dE = torch.zeros(N, d, dtype=F32, device=dev)
+    ops.gemm(con.P, con.Hb, dE, N, d, N, a_kmajor=True, b_kmajor=True, accumulate=True)
+    ops.embed_bwd(con.ids0, dE, a.G(f'{eng.dp}transformer.wte.weight'), None, N, 1, d, 0, eng.dec.V)
+    src, dst, psrc, pdst = con.rows
+    tmp = torch.empty(max(src.numel(), psrc.numel(), 1), d, dtype=F32, device=dev)
+    dhid = torch.zeros(M, d, dtype=F32, device=dev)
+    if src.numel():
+        ops.gather_rows(dH, dst, src.numel(), d, out_f32=tmp)
+        ops.scatter_rows(tmp, src, dhid, src.numel(), d)
+    dph = None
+    if con.pctx is not None:
+        dph = torch.zeros(con.B * con.n_p, d, dtype=F32, device=dev)
+        ops.gather_rows(dH, pdst, psrc.numel(), d, out_f32=tmp)
+        ops.scatter_rows(tmp, psrc, dph, psrc.numel(), d)
+    return dhid, dph
 
 
 class ModelTrainerWrapper(nn.Module):
@@ -98,8 +213,8 @@ class ModelTrainerWrapper(nn.Module):
                  ignore_index: int = -100):
         super().__init__()
         tc = trainer_config
-        if tc.add_contrastive_loss:
-            raise NotImplementedError('contrastive loss is outside the HIP hot path (it differentiates the prompt rows of hidden_state)')
+        self.add_contrastive_loss = tc.add_contrastive_loss
+        self.contrastive_temperature = tc.training_contrastive_temperature
         self.model = VisionEncoderDecoder(config=model_config)
         self.is_momentum = tc.moco_momentum is not None and tc.moco_alpha is not None
         self.model_m = VisionEncoderDecoder(config=model_config) if self.is_momentum else None
@@ -205,8 +320,12 @@ class ModelTrainerWrapper(nn.Module):
         weights = self.get_weights(labels[:, :T])
         save = torch.is_grad_enabled()
         distill = self.is_momentum and is_train
-        loss = _LMLossFunction.apply(self.model._grad_hook(dev), self, images, ids, labels, weights, save, distill)
+        loss, loss_c = _LMLossFunction.apply(self.model._grad_hook(dev), self, images, ids, labels, weights, save, distill)
         step = 'train' if is_train else 'val'
+        metrics = {f'{step}_loss_lm': loss.detach()}
+        if self.add_contrastive_loss:                          # wrapper.py:206-209
+            metrics[f'{step}_loss_contrastive'] = loss_c.detach()
+            loss = loss + loss_c
         if is_train:
             self._momentum_update()
-        return loss, {f'{step}_loss_lm': loss.detach()}
+        return loss, metrics

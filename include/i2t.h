@@ -202,6 +202,10 @@ int i2t_lm_inputs(void* stream, const int64_t* labels, int64_t* ids, int B, int 
 int i2t_grad_normalize(void* stream, float* g, long n, float* ws, void* g_bf16,
                        unsigned drop_key, unsigned drop_thr, float drop_scale,      /* dropout on the bf16 copy, as i2t_layernorm_bwd */
                        int presummed, float* clear_after);
+/* ws[0] (+)= sum(g^2): the first half of i2t_grad_normalize on its own.  Two gradient tensors that the reference normalises as ONE
+ * (the prompt rows and the text rows of the decoder when a loss differentiates both) sum their parts and normalise with
+ * i2t_grad_normalize(..., presummed = 1). */
+int i2t_sumsq(void* stream, const float* g, long n, float* ws, int accumulate);
 /* presummed bit 0: *ws already holds sum(g^2) (accumulated by the producer through i2t_layernorm_bwd's sumsq_out) and the
  * reduction pass is skipped; bit 1 (2): g itself is left as it is and only the normalised bf16 copy is written -- the first
  * i2t_layernorm_bwd that accumulates onto g applies the factor (its dx_pre_sumsq = ws), 6 instead of 10 bytes per element;

@@ -462,17 +462,40 @@ def shifted_inputs(labels, bos: int, eos: int, ignore_index=-100):
     return ids, msk
 
 
+def contrastive_loss(hidden_state, labels, wte, ignore_index=-100, temperature=1.0, weight_fn='constant', eos_token_id=None,
+                     eos_token_weight=None):
+    """wrapper.py:98-118: row i of hidden_state (flattened over batch and position; with a soft prompt the first n_cls positions
+    are the PROMPT rows) must pick out the target embedding wte[label_i] among the embeddings of every labelled position of the
+    batch; ignored positions are masked out as columns and carry zero weight as rows (their infinite loss is replaced by 0)."""
+    labels = labels[..., :hidden_state.size(-2)]
+    hidden_state = hidden_state[..., :labels.size(-1), :]
+    w = loss_weights(labels, ignore_index, weight_fn, eos_token_id, eos_token_weight)
+    keep = labels != ignore_index
+    target = wte[torch.where(keep, labels, torch.zeros_like(labels))]
+    pred = hidden_state.reshape(-1, hidden_state.size(-1)) @ target.reshape(-1, target.size(-1)).t()
+    pred = torch.where(keep.reshape(1, -1), pred, torch.full_like(pred, NEG_INF))
+    losses = F.cross_entropy(pred / temperature, torch.arange(pred.size(0)), reduction='none')
+    losses = torch.where(losses.isinf(), torch.zeros_like(losses), losses)
+    return (losses * w.reshape(-1)).sum()
+
+
 def lm_step(sd: SD, cfg, images, labels, tokenizer, training: bool, ignore_index=-100, temperature=1.0,
-            weight_fn='constant', eos_token_weight=None, moe_io=None):
-    """ModelTrainerWrapper.train_step / val_step for the default trainer config -> scalar loss."""
+            weight_fn='constant', eos_token_weight=None, moe_io=None, contrastive_temperature=None, return_parts=False):
+    """ModelTrainerWrapper.train_step / val_step -> scalar loss: weighted cross-entropy, plus the contrastive term when
+    contrastive_temperature is given (trainer option add_contrastive_loss, wrapper.py:206-209)."""
     ids, msk = shifted_inputs(labels, tokenizer.bos_token_id, tokenizer.eos_token_id, ignore_index)
-    _, logits, _ = forward(sd, cfg, images, ids, msk, training=training, moe_io=moe_io)
-    labels = labels[..., :logits.size(-2)]
-    logits = logits[..., :labels.size(-1), :]
-    w = loss_weights(labels, ignore_index, weight_fn, tokenizer.eos_token_id, eos_token_weight)
-    ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)) / temperature, labels.reshape(-1),
+    _, logits, hidden = forward(sd, cfg, images, ids, msk, training=training, moe_io=moe_io)
+    lab = labels[..., :logits.size(-2)]
+    logits = logits[..., :lab.size(-1), :]
+    w = loss_weights(lab, ignore_index, weight_fn, tokenizer.eos_token_id, eos_token_weight)
+    ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)) / temperature, lab.reshape(-1),
                          ignore_index=ignore_index, reduction='none')
-    return (ce * w.reshape(-1)).sum()
+    loss = (ce * w.reshape(-1)).sum()
+    if contrastive_temperature is None:
+        return loss
+    lc = contrastive_loss(hidden, labels, sd['decoder.transformer.wte.weight'], ignore_index, contrastive_temperature, weight_fn,
+                          tokenizer.eos_token_id, eos_token_weight)
+    return (loss + lc, loss, lc) if return_parts else loss + lc
 
 
 # --------------------------------------------------------------------------------------------------------------

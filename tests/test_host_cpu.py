@@ -99,11 +99,11 @@ def test_no_cpu_path_fails_loudly():
         w.model.decoder.transformer.h[0](torch.zeros(1, 4, 128))                  # blocks are parameter containers
 
 
-def test_unsupported_trainer_options_are_refused():
+def test_trainer_options_are_wired_or_refused():
     from image2text_amd.training.wrapper import ModelTrainerWrapper
     cfg = tiny_config()
-    with pytest.raises(NotImplementedError):
-        ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(add_contrastive_loss=True))
+    wc = ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(add_contrastive_loss=True, training_contrastive_temperature=0.7))
+    assert wc.add_contrastive_loss and wc.contrastive_temperature == 0.7          # wrapper.py:35,42
     with pytest.raises(ValueError):                         # MLM corruption needs a mask token (trainer.py:124-125 adds one)
         ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(mask_fraction=0.15))
     # momentum distillation builds the twin and starts it from the model's weights (wrapper.py:30-33,46-50)

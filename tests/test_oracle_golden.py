@@ -242,3 +242,31 @@ def test_trainer_extras_moco_and_mlm():
     assert np.array_equal(ids.numpy(), m['ids'])
     assert np.array_equal(orc.lm_inputs(torch.from_numpy(m['labels']), V - 1, V - 1).numpy(),
                           orc.shifted_inputs(torch.from_numpy(m['labels']), V - 1, V - 1)[0].numpy())
+
+
+@pytest.mark.parametrize('tag,kw', [('prompt', {}), ('cross_only', dict(use_soft_prompting=False))])
+def test_contrastive_loss_and_every_gradient(tag, kw):
+    """add_contrastive_loss (wrapper.py:98-118,206-209): both loss terms and the gradient of every parameter vs the reference"""
+    from conftest import load_golden
+    g = load_golden('tiny_contrastive.npz')
+    cfg = tiny_config(**kw)
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    m = det_init_(VisionEncoderDecoder(cfg), seed=0)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if k != 'decoder.lm_head.weight'}
+    sd['decoder.lm_head.weight'] = sd['decoder.transformer.wte.weight']
+    images, labels = torch.from_numpy(g['images']), torch.from_numpy(g['labels'])
+    loss, lm, lc = orc.lm_step(sd, cfg, images, labels, tok, training=True, contrastive_temperature=0.7, return_parts=True)
+    loss.backward()
+    assert abs(lm.item() - float(g[f'{tag}.loss_lm'])) <= 2e-5 and abs(lc.item() - float(g[f'{tag}.loss_contrastive'])) <= 2e-5
+    assert abs(loss.item() - float(g[f'{tag}.loss'])) <= 3e-5
+    for k, v in sd.items():
+        if k == 'decoder.lm_head.weight':
+            continue
+        want = g[f'{tag}.grad.{k}']
+        err = np.abs(v.grad.numpy() - want).max()
+        assert err <= 1e-6 + 1e-3 * np.abs(want).max(), (k, err)
+    with torch.no_grad():
+        _, _, vc = orc.lm_step({k: v.detach() for k, v in sd.items()}, cfg, images, labels, tok, training=False, contrastive_temperature=0.7,
+                               return_parts=True)
+    assert abs(vc.item() - float(g[f'{tag}.val_loss_contrastive'])) <= 2e-5

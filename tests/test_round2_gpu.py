@@ -10,6 +10,7 @@ import torch
 
 from conftest import load_golden
 from image2text_amd.synth import det_init_, fake_tokenizer, nano224_config, synthetic_batch, tiny_config
+from test_model_gpu import grad_close
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
@@ -471,3 +472,39 @@ def test_mlm_train_step_runs_and_val_is_clean():
     assert abs(losses['clean'][0] - losses['clean'][1]) < 1e-4 * losses['clean'][0]
     assert abs(losses['mlm'][0] - losses['clean'][0]) > 1e-3 and abs(losses['mlm'][0] - losses['mlm'][1]) > 1e-4
     assert abs(losses['mlm'][2] - losses['clean'][2]) < 1e-4 * losses['clean'][2]
+
+
+@pytest.mark.parametrize('tag,kw', [('prompt', {}), ('cross_only', dict(use_soft_prompting=False))])
+@pytest.mark.parametrize('packed', [False, True])
+def test_contrastive_loss_and_every_gradient(tag, kw, packed):
+    """add_contrastive_loss (reference training/wrapper.py:98-118, temperature 0.7): both loss terms and the gradient of every parameter
+    against the reference's fixture (tests/golden/tiny_contrastive.npz) -- with a soft prompt the term differentiates the prompt rows
+    of hidden_state (their own decoder segment) -- dense and with packed caption rows; validation reports the term too."""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    g = load_golden('tiny_contrastive.npz')
+    cfg = tiny_config(**kw)
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(cfg.decoder_config.vocab_size),
+                            TrainerWrapperConfig(add_contrastive_loss=True, training_contrastive_temperature=0.7), ignore_index=-100)
+    det_init_(w.model, seed=0)
+    w = w.to(dev()).train()
+    w.pack_rows = packed
+    images, labels = torch.from_numpy(g['images']).to(dev()), torch.from_numpy(g['labels']).to(dev())
+    loss, metrics = w.train_step(images, labels)
+    loss.backward()
+    for key, got in (('loss', loss), ('loss_lm', metrics['train_loss_lm']), ('loss_contrastive', metrics['train_loss_contrastive'])):
+        ref = float(g[f'{tag}.{key}'])
+        REPORT[f'contrastive.{tag}.{packed}.{key}'] = {'got': float(got.detach()), 'ref': ref}
+        assert abs(float(got.detach()) - ref) <= 1e-2 * max(1.0, ref), (key, float(got.detach()), ref)
+    fails = []
+    for name, p in w.model.named_parameters():
+        try:
+            grad_close(f'contrastive.{tag}.{name}', p.grad, g[f'{tag}.grad.{name}'], rel=6e-2, cos=0.995)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    w.eval()
+    with torch.no_grad():
+        vloss, vm = w.val_step(images, labels)
+    assert abs(float(vloss) - float(g[f'{tag}.val_loss'])) <= 1e-2 * float(g[f'{tag}.val_loss'])
+    assert abs(float(vm['val_loss_contrastive']) - float(g[f'{tag}.val_loss_contrastive'])) <= 1e-2 * float(g[f'{tag}.val_loss_contrastive'])

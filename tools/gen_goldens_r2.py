@@ -217,12 +217,43 @@ def gen_trainer_extras():
     print('mlm corrupted positions', int((seen['ids'][:, 1:] != torch.where(labels != -100, labels, torch.full_like(labels, V - 1))[:, :-1]).sum()))
 
 
+def gen_contrastive():
+    """tiny_contrastive.npz: train_step with add_contrastive_loss (training_contrastive_temperature 0.7) on the tiny model with soft
+    prompt + cross-attention, and on its cross-attention-only variant (no prompt rows in hidden_state): the two loss terms and the
+    gradient of every parameter (the contrastive term differentiates the PROMPT rows of hidden_state and the target embeddings)."""
+    from image2text_amd.synth import det_init_, fake_tokenizer, synthetic_batch, tiny_config
+    from configs.trainer import TrainerWrapperConfig as RefTrainerCfg
+    from training.wrapper import ModelTrainerWrapper as RefWrapper
+    out = {}
+    for tag, kw in (('prompt', {}), ('cross_only', dict(use_soft_prompting=False))):
+        cfg = tiny_config(dropout=0.0, **kw)
+        V = cfg.decoder_config.vocab_size
+        tok = fake_tokenizer(V)
+        images, labels = synthetic_batch(4, 32, 16, V, seed=5)
+        w = RefWrapper(to_ref_config(cfg), tok, RefTrainerCfg(add_contrastive_loss=True, training_contrastive_temperature=0.7), ignore_index=-100)
+        det_init_(w.model, seed=0)
+        w.train()
+        loss, metrics = w.train_step(images, labels)
+        loss.backward()
+        out.update({'images': images.numpy(), 'labels': labels.numpy(), f'{tag}.loss': np.float32(loss.item()),
+                    f'{tag}.loss_lm': np.float32(metrics['train_loss_lm'].item()),
+                    f'{tag}.loss_contrastive': np.float32(metrics['train_loss_contrastive'].item())})
+        for n, p in w.model.named_parameters():
+            out[f'{tag}.grad.{n}'] = p.grad.numpy().copy()
+        w.eval()
+        with torch.no_grad():
+            vloss, vm = w.val_step(images, labels)
+        out[f'{tag}.val_loss'], out[f'{tag}.val_loss_contrastive'] = np.float32(vloss.item()), np.float32(vm['val_loss_contrastive'].item())
+        print(tag, 'loss', loss.item(), 'lm', metrics['train_loss_lm'].item(), 'contrastive', metrics['train_loss_contrastive'].item())
+    np.savez_compressed(os.path.join(OUT, 'tiny_contrastive.npz'), **out)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    want = sys.argv[1:] or ['snradam', 'greedy64', 'trunc', 'sampling', 'trainer_extras']
+    want = sys.argv[1:] or ['snradam', 'greedy64', 'trunc', 'sampling', 'trainer_extras', 'contrastive']
     for name in want:
         t0 = time.time()
         globals()[f'gen_{name}']()
