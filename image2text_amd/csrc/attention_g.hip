@@ -70,6 +70,8 @@ struct GTile {
 struct GShape {
     int H, G, hd;             // query heads, query heads per kv head, true head width
     int TqMax, TkMax, causal;
+    int split;                // forward only, > 0: rows >= split do not see keys < split (a non-causal decoder's text rows never attend
+                              // the soft-prompt columns while the prompt rows see everything: vision_encoder_decoder.py:93-99,106-113)
     float scale;              // 1 / sqrt(hd)
     unsigned drop_key, drop_thr;
     float drop_scale;
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(AttnPtr Q, AttnPtr K, At
         }
         if (!wave_on) continue;
         const int nkj = min(4, (last_key - kt * 64) / 16 + 1);
-        const bool full = kt * 64 + 63 < Tk && (!causal || kt * 64 + 63 <= q0 + shift);
+        const bool full = kt * 64 + 63 < Tk && (!causal || kt * 64 + 63 <= q0 + shift) &&
+                          (sh.split == 0 || kt * 64 >= sh.split || q0 + 15 < sh.split);
         f32x4 s[4];
         float mx = -INFINITY;
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void gattn_fwd_kernel(AttnPtr Q, AttnPtr K, At
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 64 + kj * 16 + 4 * g + r;
-                        if (!(key <= qlim && key < Tk)) a[r] = -INFINITY;
+                        if (!(key <= qlim && key < Tk) || (sh.split && qrow >= sh.split && key < sh.split)) a[r] = -INFINITY;
                     }
                 }
                 mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
@@ -524,13 +527,14 @@ int g_check(const char* who, int B, int H, int Hkv, int hd, int Tq, int Tk, int 
 extern "C" int i2t_gq_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs, const void* v,
                                     long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse, int B, int H, int Hkv, int hd, int Tq,
                                     int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale, const int* cu_q,
-                                    const int* cu_k, int total_q) {
+                                    const int* cu_k, int total_q, int split) {
+    I2T_REQUIRE(split == 0 || (!causal && !cu_q && !cu_k && Tq == Tk && split < Tq), "i2t_gq_attention_fwd: split needs dense non-causal self-attention");
     if (int rc = g_check("i2t_gq_attention_fwd", B, H, Hkv, hd, Tq, Tk, causal, drop_thr, cu_q, total_q)) return rc;
     I2T_REQUIRE(g_strides_ok(q, q_bs, q_rs, H * hd) && g_strides_ok(k, k_bs, k_rs, Hkv * hd) && g_strides_ok(v, v_bs, v_rs, Hkv * hd) &&
                     g_strides_ok(o, o_bs, o_rs, H * hd),
                 "i2t_gq_attention_fwd: operands must be 16-byte aligned with strides that are multiples of 8 and cover every head");
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
-    const GShape sh{H, H / Hkv, hd, Tq, Tk, causal, 1.0f / sqrtf((float)hd), drop_key, drop_thr, drop_scale};
+    const GShape sh{H, H / Hkv, hd, Tq, Tk, causal, split, 1.0f / sqrtf((float)hd), drop_key, drop_thr, drop_scale};
     GATTN_DISPATCH(gattn_fwd_kernel, hd, drop_thr, dim3(((Tq + 63) / 64) * H * B), dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o,
                    o_bs, o_rs, lse, sh, VarLen{cu_q, cu_k, total_q, B});
     I2T_CHECK_LAUNCH("i2t_gq_attention_fwd");
@@ -553,7 +557,7 @@ extern "C" int i2t_gq_attention_bwd(void* stream, const void* q, long q_bs, int 
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs}, Ow{(const bf16_t*)o, o_bs, o_rs};
     const VarLen vl{cu_q, cu_k, total_q, B};
-    const GShape sh{H, H / Hkv, hd, Tq, Tk, causal, 1.0f / sqrtf((float)hd), drop_key, drop_thr, drop_scale};
+    const GShape sh{H, H / Hkv, hd, Tq, Tk, causal, 0, 1.0f / sqrtf((float)hd), drop_key, drop_thr, drop_scale};
     const GOutDrop od{out_drop_key, out_drop_thr, out_drop_scale};
     GATTN_DISPATCH(gattn_bwd_dq_kernel, hd, drop_thr, dim3(((Tq + 63) / 64) * H * B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
                    (bf16_t*)dq, dq_bs, dq_rs, sh, vl, od);

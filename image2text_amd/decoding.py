@@ -332,6 +332,48 @@ class GreedyDecoder:
         return out
 
 
+@torch.no_grad()
+def generate_by_recompute(model, images, prompt_ids: torch.Tensor, max_new_tokens: int, sampling: Optional[Sampling] = None):
+    """generate() for a NON-causal decoder, as the reference runs it (vision_encoder_decoder.py:143-180): the whole text segment is
+    re-evaluated for every new token (with bidirectional attention a new token changes the state of all earlier ones, so there is
+    nothing to cache); the encoder runs once, and the token choice -- n-gram ban + argmax or the sampling step -- stays on the device."""
+    eng: HotPath = model._engine
+    a = eng.prepare(False)
+    dc, cfg = eng.dec, model.config
+    dev = a.device
+    B, P = prompt_ids.shape
+    total = P + max_new_tokens
+    enc_out, _ = eng.encode(images, False)
+    ncls = enc_out.shape[1]
+    mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
+    off = ncls if cfg.use_soft_prompting else 0
+    blk = dc.block - off
+    ids = torch.zeros(B, total, dtype=torch.long, device=dev)
+    ids[:, :P] = prompt_ids.to(dev)
+    counters = torch.tensor([P - 1, P], dtype=torch.int32, device=dev)
+    ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
+    logits = torch.zeros(B, dc.Vp, dtype=F32, device=dev)
+    margin = torch.zeros(B, dtype=F32, device=dev)
+    seed = torch.zeros(2, dtype=torch.int32, device=dev)
+    if sampling is not None:
+        sd = sampling.seed if sampling.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        lo, hi = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        seed.copy_(torch.tensor([lo - (1 << 32) if lo >= (1 << 31) else lo, hi - (1 << 32) if hi >= (1 << 31) else hi], dtype=torch.int32))
+    for t in range(P, total):
+        cond = ids[:, :t] if t <= blk else ids[:, t - blk:t]                     # the reference crops the conditioning to the block
+        Tc = cond.shape[1]
+        _, hb, _ = eng.decode_segment(B, Tc, mem, ncls, False, ids=cond.contiguous(), pos_offset=off)
+        last = hb.view(B, Tc, dc.d)[:, -1].contiguous()
+        ops.gemm(last, a.W(f'{eng.dp}transformer.wte.weight'), logits, B, dc.V, dc.d)
+        if sampling is None:
+            ops.ngram_ban_argmax(logits, dc.Vp, ids, total, counters[1:2], ngrams, ngrams.numel(), B, dc.V, margin)
+        else:
+            ops.sample_token(logits, dc.Vp, ids, total, counters[1:2], ngrams, ngrams.numel(), B, dc.V, sampling.temperature,
+                             sampling.top_k, sampling.nucleus_p, seed)
+        ops.advance(counters, 1)
+    return ids
+
+
 class ConcurrentGreedyDecoder:
     """Several independent caption batches decoded at the same time, one HIP stream + one captured graph each.
 

@@ -234,7 +234,7 @@ class HotPath(FamilyBlocks):
                                    dropout=dac.dropout, attn_dropout=dac.attn_dropout)
         # the nano-mini block family (multi-query / MoE / sparse / head widths other than 64): engine_family.FamilyBlocks
         self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
-        self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer)
+        self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer, force=not dcfg.transformer_config.is_causal)
         self._sparse_idx = {'enc': self._sparse_sets(model, self.ep, ecfg.n_layer) if self.enc.fam and self.enc.fam.sparse else None,
                             'dec': self._sparse_sets(model, self.dp, dcfg.n_layer) if self.dec.fam and self.dec.fam.sparse else None}
         self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
@@ -662,12 +662,14 @@ class HotPath(FamilyBlocks):
         return mem
 
     def decode_segment(self, B: int, T: int, mem_bf, S: int, save: bool, ids=None, embeds=None, pos_offset: int = 0, vl=None,
-                       dropout_without_save: bool = False, drop_plan=None):
+                       dropout_without_save: bool = False, drop_plan=None, split: int = 0):
         """One causal segment through the decoder blocks + ln_f.  Returns (hidden fp32 [M,d], hidden bf16, ctx), M = B*T, or
         M = vl.total for packed variable-length rows (vl = namespace(cu, pos, total): ids is then the packed 1-D id list)."""
         a, dc = self.arena, self.dec
         if T + pos_offset > dc.block:
             raise AssertionError(f'Cannot forward sequence of length {T + pos_offset}, block size is only {dc.block}')
+        if split and (save or vl is not None or dc.fam is None):
+            raise I2TError('split visibility is a forward-only feature of the grouped attention kernels on dense rows')
         d, M = dc.d, (vl.total if vl is not None else B * T)
         x = self._empty(M, d)
         wpe = None if dc.advpos else a.P(f'{self.dp}transformer.wpe.weight')
@@ -699,7 +701,7 @@ class HotPath(FamilyBlocks):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
             if dc.fam is not None:
                 cur, sv = self.fam_layer_fwd(f'{self.dp}transformer.h.{l}', dc.fam, cur, B, T, m, S, save, plan, l, vl,
-                                             self.sparse_subset('dec', l, B, T, pos_offset, vl))
+                                             self.sparse_subset('dec', l, B, T, pos_offset, vl), split)
             else:
                 cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l, vl)
             saves.append(sv)

@@ -33,9 +33,10 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def family_spec(tcfg, n_layer: int):
-    """Static description of one tower's blocks (None for the dense multi-head path)."""
-    if not tcfg.is_family:
+def family_spec(tcfg, n_layer: int, force: bool = False):
+    """Static description of one tower's blocks (None for the dense multi-head path).  force: a block the dense path could run is
+    still described here (a non-causal decoder: its [prompt | text] forward needs the split visibility of the grouped kernels)."""
+    if not (tcfg.is_family or force):
         return None
     ac = tcfg.attn_config
     rc = tcfg.rotator_config
@@ -246,7 +247,7 @@ class FamilyBlocks:
         return out
 
     # ------------------------------------------------------------------------------------------------ one block
-    def fam_block_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl):
+    def fam_block_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, split: int = 0):
         a = self.arena
         d, H, hd = sp.d, sp.H, sp.hd
         M = vl.total if vl is not None else B * T
@@ -272,7 +273,8 @@ class FamilyBlocks:
             qq, kk, vv, Hkv, out_name = q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], H, 'attn.c_proj'
             sv.qkv = qkv
         ao, lse = self._empty(M, d, dtype=BF16), self._empty(H * M)
-        ops.gq_attention_fwd(qq, kk, vv, v3(ao, d), lse, B, H, Hkv, hd, T, T, sp.causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M)
+        ops.gq_attention_fwd(qq, kk, vv, v3(ao, d), lse, B, H, Hkv, hd, T, T, sp.causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M,
+                             split=split)
         x1 = self._empty(M, d)
         ops.gemm(ao, a.W(f'{pfx}.{out_name}.weight'), x1, M, d, d, bias=a.P(f'{pfx}.{out_name}.bias'), residual=x, drop=dr['resid'])
         sv.ln1, sv.m1, sv.r1, sv.ao, sv.lse, sv.x1, sv.out_name, sv.Hkv = ln1, m1, r1, ao, lse, x1, out_name, Hkv
@@ -398,6 +400,7 @@ class FamilyBlocks:
             sub.all_null = True
         else:
             not_t = not_all[(not_all < t_full) & (not_all >= off)] - off
+            sub.idx_t = idx_t
             if vl is None:
                 base = (np.arange(B, dtype=np.int64) * T)[:, None]
                 rows_in, rows_out = (base + idx_t[None]).ravel(), (base + not_t[None]).ravel()
@@ -447,16 +450,19 @@ class FamilyBlocks:
         self._linear_bwd(dyb, n, d, d, xb, f'{pfx}.null_connector.weight', nb if nb in a.params else None, dx_out=dxn, residual=dyn)
         return dxn
 
-    def fam_layer_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, sub):
+    def fam_layer_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, sub, split: int = 0):
+        """split > 0 (forward only): the rows are [prompt | text] of a non-causal decoder, text rows must not see prompt keys."""
         if sub is None:
-            return self.fam_block_fwd(pfx, sp, x, B, T, mem_bf, S, save, plan, layer, vl)
+            return self.fam_block_fwd(pfx, sp, x, B, T, mem_bf, S, save, plan, layer, vl, split)
+        if split and not sub.all_null:
+            split = int((sub.idx_t < split).sum())          # the prompt positions kept by this layer come first in the subset
         d, M = sp.d, x.shape[0]
         if sub.all_null or sub.n_in == 0:
             y, xb = self._null_fwd(pfx, x, M, d, None)
             return y, (SimpleNamespace(only_null=True, xb=xb) if save else None)
         xs = self._empty(sub.n_in, d)
         ops.gather_rows(x, sub.rows_in, sub.n_in, d, out_f32=xs)
-        ys, bsv = self.fam_block_fwd(pfx, sp, xs, B, sub.T_in, mem_bf, S, save, plan, layer, sub.vl_in)
+        ys, bsv = self.fam_block_fwd(pfx, sp, xs, B, sub.T_in, mem_bf, S, save, plan, layer, sub.vl_in, split)
         out = self._empty(M, d)
         ops.scatter_rows(ys, sub.rows_in, out, sub.n_in, d)
         xnb = None

@@ -54,7 +54,7 @@ SIGNATURES = {
     'i2t_sample_token': [P, P, I, P, I, P, P, I, I, I, F, I, F, P, P, I],
     'i2t_embed_step': [P, P, I, P, P, P, P, I, I, I, I],
     'i2t_advance': [P, P, I, I],
-    'i2t_gq_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, I, I, U, U, F, P, P, I],
+    'i2t_gq_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, I, I, U, U, F, P, P, I, I],
     'i2t_gq_attention_bwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I, I, I, U, U, F, P, P, I,
                              U, U, F],
     'i2t_row_sections_dropout': [P, P, I, L, I, I, U, U, F],

@@ -166,8 +166,17 @@ class VisionEncoderDecoder(nn.Module):
                 B, ncls = enc_out.shape[0], enc_out.shape[1]
                 n_p = min(ncls, eng.dec.block)
                 mem = eng._mem_bf16(enc_out) if self.use_cross_attn else None
-                ph, _, _ = eng.decode_segment(B, n_p, mem, ncls, False, embeds=enc_out[:, :n_p].reshape(B * n_p, -1), pos_offset=0)
-            hid = torch.cat((ph.view(B, n_p, -1), hid), dim=1)
+                if eng.dec.causal:
+                    ph, _, _ = eng.decode_segment(B, n_p, mem, ncls, False, embeds=enc_out[:, :n_p].reshape(B * n_p, -1), pos_offset=0)
+                else:
+                    # a NON-causal decoder: the prompt rows see every column, text included (:93-95), so they need the whole
+                    # sequence in one pass; text rows still never see the prompt (split visibility of the grouped kernels)
+                    Tt = hid.shape[1]
+                    emb = torch.cat((enc_out[:, :n_p], self.decoder.get_inputs_embeds(ids[:, :Tt])), dim=1)
+                    full, _, _ = eng.decode_segment(B, n_p + Tt, mem, ncls, False, embeds=emb.reshape(B * (n_p + Tt), -1), pos_offset=0,
+                                                    split=n_p)
+                    ph = full.view(B, n_p + Tt, -1)[:, :n_p]
+            hid = torch.cat((ph.reshape(B, n_p, -1), hid), dim=1)
         return VisionEncoderDecoderModelOutput(encoder_output=enc_out, logits=logits, hidden_state=hid)
 
     @torch.no_grad()
@@ -180,7 +189,10 @@ class VisionEncoderDecoder(nn.Module):
         assert max_new_tokens <= blk_size - prompt_ids.size(-1)
         dev = next(self.parameters()).device
         prompt_ids = prompt_ids.to(dev)
-        from ..decoding import GreedyDecoder, Sampling
+        from ..decoding import GreedyDecoder, Sampling, generate_by_recompute
+        if not self._engine.dec.causal:      # bidirectional attention: every new token changes the state of the earlier ones
+            return generate_by_recompute(self, images, prompt_ids, max_new_tokens,
+                                         None if (top_k == 1 and nucleus_p is None) else Sampling(temperature, top_k, nucleus_p))
         if self._greedy is None:
             object.__setattr__(self, '_greedy', GreedyDecoder(self))
         if top_k == 1 and nucleus_p is None:

@@ -134,12 +134,12 @@ def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causa
              'i2t_attention_bwd')
 
 
-def gq_attention_fwd(q, k, v, o, lse, B, H, Hkv, hd, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0):
+def gq_attention_fwd(q, k, v, o, lse, B, H, Hkv, hd, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0, split=0):
     """Grouped-query attention (include/i2t.h::i2t_gq_attention_fwd): H query heads of width hd on Hkv shared key/value heads."""
     _need_cuda(q, k, v, o, lse)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o)
     _l.check(_lib().i2t_gq_attention_fwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(lse), B, H, Hkv, hd,
-                                         Tq, Tk, int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q)), 'i2t_gq_attention_fwd')
+                                         Tq, Tk, int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q), int(split)), 'i2t_gq_attention_fwd')
     return o
 
 

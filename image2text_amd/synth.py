@@ -152,6 +152,22 @@ def mini_config(dropout: float = 0.0, **overrides) -> VisionEncoderDecoderConfig
     return _family_config(**kw)
 
 
+def reference_unit_test_config() -> VisionEncoderDecoderConfig:
+    """The configuration of the reference's only unit test (models/vision_encoder_decoder_test.py:21-88): multi-query attention with
+    16-wide heads, MoE rotators without a gate hidden layer (top-2 of 4 experts of rank 8, ff 2.5), 4x4 convolutions, 32x32 = 1024
+    flat patches of 512 + 24 CLS, and a NON-causal decoder with cross-attention and a soft prompt."""
+    def tf(causal, cross):
+        return TransformerConfig(
+            rotator_config=MoEConfig(num_experts=4, proj_features=8, gate_sizes=None, ff_mult_factor=2.5, top_k=2),
+            attn_config=SelfAttentionConfig(attn_type=SelfAttentionType.MULTI_QUERY, n_embd=64, n_head=4),
+            is_causal=causal, is_cross_attn=cross)
+    enc = VisionTransformerEncoderConfig(
+        transformer_config=tf(False, False), enable_gradient_checkpointing=True, input=ImageInputSpec(n_channels=3, width=128, height=128),
+        n_layer=2, n_cls=24, num_patches=32, n_channels=32, feature_extractor_gate_sizes=(8, 16), feature_extractor_kernel_size=(4, 4))
+    dec = TransformerDecoderConfig(transformer_config=tf(False, True), n_layer=2, block_size=256, vocab_size=1024)
+    return VisionEncoderDecoderConfig(vision_encoder_config=enc, decoder_config=dec, use_cross_attn=True, use_soft_prompting=True)
+
+
 def fake_tokenizer(vocab_size: int, eos: Optional[int] = None):
     """The four attributes ModelTrainerWrapper reads from a tokenizer (reference training/wrapper.py:88,157,173,188)."""
     eos = vocab_size - 1 if eos is None else eos

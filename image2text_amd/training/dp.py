@@ -75,12 +75,17 @@ class DataParallelGrads:
             raise RuntimeError('no parameter arena yet: run one forward/backward first')
         return arena
 
-    def _split(self, arena) -> int:
-        """First arena offset that belongs to the decoder (parameters are laid out encoder first)."""
-        for name, (off, _, _) in arena.entries.items():
-            if name.startswith('decoder.'):
-                return off
-        return arena.total
+    def _split(self, arena):
+        """[lo, hi): the arena range that holds the decoder's parameters (named_parameters lays the towers out one after the other;
+        which one comes first depends on the module's registration order, so both ends are looked up)."""
+        offs = [(off, off + ((n + 7) // 8) * 8) for name, (off, n, _) in arena.entries.items() if name.startswith('decoder.')]
+        if not offs:
+            return arena.total, arena.total
+        lo, hi = min(o for o, _ in offs), max(e for _, e in offs)
+        inside = sum(e - o for o, e in offs)
+        if inside != hi - lo:
+            raise RuntimeError('decoder parameters are not contiguous in the arena: the overlapped gradient exchange needs them to be')
+        return lo, min(hi, arena.total)
 
     def _reduce(self, t: torch.Tensor, async_op: bool):
         backend = dist.get_backend(self.group)
@@ -110,24 +115,25 @@ class DataParallelGrads:
         if which != 'decoder' or not self._sync:
             return
         arena = self._arena()
-        cut = self._split(arena)
-        if cut >= arena.total:
+        lo, hi = self._split(arena)
+        if hi <= lo:
             return
         if arena.g32.is_cuda and dist.get_backend(self.group) == 'nccl' and RCCL_CUS > 0:
             from .. import ops
             ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
             self._reserved = True
-        work, need_div = self._reduce(arena.g32[cut:], async_op=True)
-        self._pending.append((work, arena.g32[cut:], need_div))
-        self._reduced_upto = cut
+        work, need_div = self._reduce(arena.g32[lo:hi], async_op=True)
+        self._pending.append((work, arena.g32[lo:hi], need_div))
+        self._reduced_upto = (lo, hi)
 
     def all_reduce_mean(self):
         """Finish the exchange: after this every rank holds mean-over-ranks gradients in its arena / p.grad."""
         arena = self._arena()
-        hi = arena.total if self._reduced_upto is None else self._reduced_upto
-        if hi > 0:
-            work, need_div = self._reduce(arena.g32[:hi], async_op=True)
-            self._pending.append((work, arena.g32[:hi], need_div))
+        lo, hi = self._reduced_upto if self._reduced_upto is not None else (0, 0)
+        for a, b in ((0, lo), (hi, arena.total)):        # everything the 'decoder' hook has not already put on the wire
+            if b > a:
+                work, need_div = self._reduce(arena.g32[a:b], async_op=True)
+                self._pending.append((work, arena.g32[a:b], need_div))
         self._drain()
 
     def broadcast_parameters(self, src: int = 0):

@@ -38,7 +38,7 @@ class _LMLossFunction(torch.autograd.Function):
         mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
         off = ncls if cfg.use_soft_prompting else 0
         T = min(L, eng.dec.block - off)
-        vl = wrapper._pack_rows(labels[:, :T], B, T) if wrapper.pack_rows else None
+        vl = wrapper._pack_rows(labels[:, :T], B, T) if (wrapper.pack_rows and eng.dec.causal) else None      # (dead rows are dead under a causal mask only)
         if vl is not None:      # rows past each caption's last label are dead (causal + zero loss weight): not computed
             M = vl.total
             ids_p = ids[:, :T][vl.mask]
@@ -215,6 +215,9 @@ class ModelTrainerWrapper(nn.Module):
         tc = trainer_config
         self.add_contrastive_loss = tc.add_contrastive_loss
         self.contrastive_temperature = tc.training_contrastive_temperature
+        if tc.add_contrastive_loss and model_config.use_soft_prompting and not model_config.decoder_config.transformer_config.is_causal:
+            raise NotImplementedError('contrastive loss with a non-causal decoder and a soft prompt: the prompt rows then attend to the '
+                                      'text rows, which the two-segment backward does not cover')
         self.model = VisionEncoderDecoder(config=model_config)
         self.is_momentum = tc.moco_momentum is not None and tc.moco_alpha is not None
         self.model_m = VisionEncoderDecoder(config=model_config) if self.is_momentum else None

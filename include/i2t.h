@@ -318,7 +318,10 @@ int i2t_gq_attention_fwd(void* stream, const void* q, long q_bs, int q_rs, const
                          const void* v, long v_bs, int v_rs, void* o, long o_bs, int o_rs, float* lse,
                          int B, int H, int Hkv, int hd, int Tq, int Tk, int causal,
                          unsigned drop_key, unsigned drop_thr, float drop_scale,
-                         const int* cu_q, const int* cu_k, int total_q);
+                         const int* cu_q, const int* cu_k, int total_q, int split);
+/* split (forward only, dense non-causal self-attention; 0 = off): query rows >= split do not see keys < split -- the mask of a
+ * NON-causal decoder over [soft prompt | text] (reference models/vision_encoder_decoder.py:93-99,106-113: prompt rows see every
+ * column, text rows never see the prompt columns). */
 int i2t_gq_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
                          const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
                          const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,

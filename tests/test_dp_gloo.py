@@ -110,20 +110,27 @@ def _overlap_worker(rank, world, port, out_dir):
     assert len(eng.grad_ready_hooks) == 1
     notify = lambda which: [h(which) for h in eng.grad_ready_hooks]
 
-    def backward(grads):                             # what _LMLossFunction.backward does to the arena, with oracle gradients
-        notify('begin')
+    def backward(grads):                             # what _LMLossFunction.backward does to the arena, with oracle gradients:
+        notify('begin')                              # the decoder's gradients are final at 'decoder', the encoder's only afterwards
         for name, gr in grads.items():
-            arena.G(name).add_(gr)
+            if name.startswith('decoder.'):
+                arena.G(name).add_(gr)
         notify('decoder')
+        for work, _, _ in dp._pending:               # a collective may finish at any time -- here: at once, so an exchange that
+            work.wait()                              # (wrongly) covered the encoder's slice this early would miss its gradients
+        for name, gr in grads.items():
+            if not name.startswith('decoder.'):
+                arena.G(name).add_(gr)
         notify('encoder')
 
     g = load_golden('tiny_train_init.npz')
     images, labels = torch.from_numpy(g['images']), torch.from_numpy(g['labels'])
     # priming backward with garbage gradients, never followed by all_reduce_mean
     backward({name: torch.full(shape, float(rank + 1)) for name, (_, _, shape) in arena.entries.items()})
-    arena.g32.zero_()                                # optimizer.zero_grad()
-    dp.broadcast_parameters(0)
+    dp.broadcast_parameters(0)                       # drains the exchange the priming backward left in flight ...
     assert dp._reduced_upto is None and not dp._pending
+    arena.g32.zero_()                                # ... before the gradients are cleared (ParamArena.begin_backward does that after the
+    #                                                  'begin' hook's drain; zeroing first would race the collective still writing)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     # accumulation window: this rank's micro-batches are samples [2r] and [2r+1]
     micro = [_shard_grads(cfg, sd0, images[2 * rank + i:2 * rank + i + 1], labels[2 * rank + i:2 * rank + i + 1]) for i in range(2)]

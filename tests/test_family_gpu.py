@@ -403,3 +403,53 @@ def test_advanced_positional_mlp_train_step_every_gradient(packed):
             fails.append(str(e))
     assert n_pos == 40 * 8
     assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:8])
+
+
+def test_reference_unit_test_runs_and_matches_the_reference():
+    """The reference's only unit test (models/vision_encoder_decoder_test.py) at its own sizes -- 96 images of 128 x 128, 192 ids, a
+    random boolean mask, generate with a nucleus -- then the same model on the fixture the reference produced
+    (tests/golden/unit_test_config.npz): logits, the full hidden_state (prompt rows of the non-causal decoder see the text rows),
+    greedy tokens by re-evaluation."""
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.synth import reference_unit_test_config
+    cfg = reference_unit_test_config()
+    torch.manual_seed(0)
+    model = VisionEncoderDecoder(cfg).to(dev())
+    inp = torch.randint(0, 256, (96, 3, 128, 128)).float()
+    ids = torch.randint(0, 1024, (96, 192,))
+    attn_mask = torch.randint(0, 2, (192, 192), dtype=torch.bool)
+    outs = model(images=inp.to(dev()), ids=ids.to(dev()), attn_msk=attn_mask.to(dev()))
+    assert (96, 24, 64) == tuple(outs.encoder_output.shape)
+    assert (96, 192, 1024) == tuple(outs.logits.shape)
+    assert (96, 24 + 192, 64) == tuple(outs.hidden_state.shape)
+    assert torch.isfinite(outs.logits).all() and torch.isfinite(outs.hidden_state).all()
+    generated_ids = model.generate(inp[:2].to(dev()), ids[:2].to(dev()), max_new_tokens=16, temperature=1.0, nucleus_p=0.5)
+    assert (2, 192 + 16) == tuple(generated_ids.shape)
+    assert torch.equal(generated_ids[:, :192].cpu(), ids[:2])
+    # numbers: the reference's fixture on the same (det_init_ + sharpened gate) weights
+    f = load_golden('unit_test_config.npz')
+    m, sd = build(cfg)
+    images, fids = torch.from_numpy(f['images']).to(dev()), torch.from_numpy(f['ids']).to(dev())
+    eng = m._engine
+    eng.moe_trace = {}
+    with torch.no_grad():
+        out = m(images=images, ids=fids, attn_msk=torch.from_numpy(f['attn_msk']).to(dev()))
+    eng.moe_trace = None
+    for key, got in (('encoder_output', out.encoder_output), ('logits', out.logits), ('hidden_state', out.hidden_state)):
+        err = np.abs(got.float().cpu().numpy() - f[key])
+        tol = 1.5e-2 * max(1.0, float(np.abs(f[key]).max()))
+        REPORT[f'unit_test_config.{key}'] = {'max': float(err.max()), 'q99': float(np.quantile(err, 0.99)), 'tol': tol}
+        assert float(np.quantile(err, 0.99)) <= tol, (key, float(np.quantile(err, 0.99)), tol)
+        assert float(err.max()) <= 6 * tol, (key, float(err.max()))          # (a routing near-tie moves single tokens further)
+    gen = m.generate(images, fids[:, :5], max_new_tokens=6, temperature=1.0, top_k=1).cpu().numpy()
+    agree = disagree_clear = 0
+    for b in range(gen.shape[0]):
+        for t in range(6):
+            if not np.array_equal(gen[b, :5 + t], f['greedy_ids'][b, :5 + t]):
+                break                                   # a different earlier token: the conditioning differs from here on
+            if gen[b, 5 + t] == f['greedy_ids'][b, 5 + t]:
+                agree += 1
+            elif f['greedy_margins'][b, t] >= 0.05:
+                disagree_clear += 1
+    REPORT['unit_test_config.greedy'] = {'agree': agree, 'clear_disagreements': disagree_clear}
+    assert disagree_clear == 0 and agree >= 3

@@ -183,3 +183,23 @@ def test_advanced_positional_mlp_gradients():
     with torch.no_grad():
         l2 = orc.lm_step_text_segment(w, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['labels']), tok)
     assert abs(l2.item() - float(f['advpos.loss'])) <= 2e-5
+
+
+def test_reference_unit_test_config_non_causal_decoder():
+    """the model of the reference's own unit test (vision_encoder_decoder_test.py): non-causal decoder with a soft prompt -- the
+    prompt rows of hidden_state attend to the text rows, the text rows never to the prompt"""
+    from image2text_amd.synth import reference_unit_test_config
+    f = load_golden('unit_test_config.npz')
+    cfg = reference_unit_test_config()
+    sd = family_weights(cfg)
+    io = {'record': {}}
+    with torch.no_grad():
+        enc, logits, hidden = orc.forward(sd, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['ids']),
+                                          torch.from_numpy(f['attn_msk']), moe_io=io)
+    close(enc, f['encoder_output'])
+    close(logits, f['logits'])
+    close(hidden, f['hidden_state'])
+    for s, (_, idx) in io['record'].items():
+        assert np.array_equal(idx.numpy(), f[f'moe.{s}.idx']), s
+    ids = orc.generate_greedy(sd, cfg, torch.from_numpy(f['images']), torch.from_numpy(f['ids'][:, :5]), 6)
+    assert np.array_equal(ids.numpy(), f['greedy_ids'])
