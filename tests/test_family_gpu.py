@@ -27,7 +27,7 @@ def write_family_report():
     yield
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/parity_report_family.json', 'w') as fh:
-        json.dump({k: v for k, v in REPORT.items() if k.startswith(('mini', 'variant', 'nano_mini'))}, fh, indent=1, sort_keys=True)
+        json.dump({k: v for k, v in REPORT.items() if k.startswith(('mini', 'variant', 'nano_mini', 'unit_test', 'advpos'))}, fh, indent=1, sort_keys=True)
 
 
 def build(cfg, train=False):
