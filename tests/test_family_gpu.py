@@ -453,3 +453,63 @@ def test_reference_unit_test_runs_and_matches_the_reference():
                 disagree_clear += 1
     REPORT['unit_test_config.greedy'] = {'agree': agree, 'clear_disagreements': disagree_clear}
     assert disagree_clear == 0 and agree >= 3
+
+
+@pytest.mark.parametrize('extra', [{}, dict(advanced_pos_emb_gate_sizes=(32, 64, 32))])
+def test_family_training_memorises_a_small_caption_set(extra):
+    """End-to-end sanity of the family's train path over many steps (MoE routing that changes as the gates learn, the packed W2aug
+    re-built from the updated parameters every step, sparse blocks with packed ragged rows, dropout, the fused AdamW over an arena
+    with pad entries): 8 fixed (image, caption) pairs must be memorised, and the trained model must then write those captions."""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.optim import FusedAdamW
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    torch.manual_seed(11)
+    cfg = mini_config(dropout=0.05, **extra)
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    det_init_(w.model, seed=3, style='reference')
+    w = w.to(dev()).train()
+    images, labels = synthetic_batch(8, 32, 16, cfg.decoder_config.vocab_size, seed=21)
+    images, labels = images.to(dev()), labels.to(dev())
+    opt = FusedAdamW(w.model.parameters(), w.model, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    pads = [n for n in w.model._engine.arena.entries if n not in w.model._engine.arena.params] if w.model._engine.arena is not None else []
+    losses = []
+    for _ in range(300):
+        loss, _ = w.train_step(images, labels)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    REPORT[f'mini.memorise.{"advpos" if extra else "plain"}'] = {'first': losses[0], 'last': losses[-1]}
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.2 * losses[0], (losses[0], losses[-1])
+    a = w.model._engine.arena
+    pads = [n for n in a.entries if n not in a.params]
+    assert len(pads) == 4 and all(float(a.P(n).abs().max()) == 0.0 for n in pads), 'the pad entries behind bias-free gates must stay zero'
+    w.eval()
+    with torch.no_grad():
+        vl, _ = w.val_step(images, labels)
+        assert float(vl) < 0.25 * losses[0]
+        # teacher-forced: the trained model predicts its captions
+        ids = torch.cat((torch.full((8, 1), tok.bos_token_id, dtype=torch.long, device=dev()),
+                         torch.where(labels != -100, labels, torch.full_like(labels, tok.eos_token_id))), dim=1)[:, :16]
+        logits = w.model(images=images, ids=ids).logits
+        live = labels != -100
+        acc = float(((logits.argmax(-1) == labels) & live).sum()) / float(live.sum())
+        REPORT[f'mini.memorise.{"advpos" if extra else "plain"}.teacher_forced_accuracy'] = acc
+        assert acc > 0.8, acc
+        # the KV-cache generation of the TRAINED model == greedy decoding by repeated full forwards (the reference's loop)
+        prompt = torch.full((8, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = w.model.generate(images, prompt, max_new_tokens=10, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(10):
+            lg = w.model(images=images, ids=cur).logits[:, -1].float()
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 0.05
+            same_prefix = (gen[:, :cur.shape[1]] == cur).all(dim=1)
+            ok = gen[:, cur.shape[1]] == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True)), dim=1)
+    REPORT[f'mini.memorise.{"advpos" if extra else "plain"}.generate_vs_forward'] = {'agree': agree, 'of': total}
+    assert total >= 40 and agree == total, (agree, total)

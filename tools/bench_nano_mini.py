@@ -100,14 +100,19 @@ def main():
         out['step_split_ms'] = {n: {'launches': v[0], 'ms': round(v[1], 2)} for n, v in sorted(fams.items(), key=lambda kv: -kv[1][1])[:14]}
         out['step_split_total_ms'] = round(tot, 1)
         out['step_split_wall_ms'] = round(wall * 1e3, 1)
-    if args.gemm_breakdown:
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from bench import GemmTimer
-        with GemmTimer(ops) as gt:
-            step()
+    # GEMM family of one step (HIP events around every i2t_gemm_bf16 call): FLOP rate against the bf16 MFMA peak and algorithmic
+    # bytes against the HBM peak -- most of this model's GEMMs have N or K around 100 (experts, K/V head) and sit on the HBM roof
+    from bench import GemmTimer
+    with GemmTimer(ops) as gt:
+        step()
+        gs = gt.summary()
+        if args.gemm_breakdown:
             for line in gt.breakdown()[:45]:
                 print(line, file=sys.stderr)
-            print(gt.summary(), file=sys.stderr)
+    tbs = gs['bytes_per_launch'] * gs['launches'] / (gs['total_ms'] * 1e-3) / 1e12
+    out['gemm_family'] = {'launches': gs['launches'], 'ms_per_step': round(gs['total_ms'], 2), 'tflops': round(gs['tflops'], 1),
+                          'frac_of_2500_tflops': round(gs['tflops'] / 2500.0, 3), 'algorithmic_tb_per_s': round(tbs, 2),
+                          'frac_of_8_tb_per_s': round(tbs / 8.0, 3)}
     # greedy decode
     wrapper.eval()
     Bd = args.decode_batch
