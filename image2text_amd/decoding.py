@@ -255,6 +255,9 @@ class GreedyDecoder:
         """-> ids (B, P + max_new_tokens) [, margins (B, N) greedy only] [, dists (B, N, V) sampling only: the filtered,
         renormalised distribution every token was drawn from]."""
         eng = self.eng
+        if not eng.dec.causal:      # nothing to cache under bidirectional attention: the reference's re-evaluation loop
+            assert not return_margins and not return_dists, 'margins / distributions are recorded on the KV-cache path only'
+            return generate_by_recompute(self.model, images, prompt_ids, max_new_tokens, sampling)
         a = eng.prepare(False)
         dc = eng.dec
         B, P = prompt_ids.shape

@@ -239,7 +239,7 @@ class HotPath(FamilyBlocks):
                             'dec': self._sparse_sets(model, self.dp, dcfg.n_layer) if self.dec.fam and self.dec.fam.sparse else None}
         self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
         self._moe_cache, self._sub_cache = {}, {}
-        self.moe_trace = None           # tests set a dict: site -> (gate values, routing weights) of every MoELinear forward
+        self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
         gates = list(ecfg.feature_extractor_gate_sizes or [])
         chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
         self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]

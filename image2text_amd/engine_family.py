@@ -119,8 +119,8 @@ class FamilyBlocks:
         y = self._empty(M, mv.out_f, dtype=BF16 if act else F32)
         pre = self._empty(M, mv.out_f, dtype=BF16) if (act and save) else None
         ops.gemm(A, mv.W2aug, y, M, mv.out_f, sp.Kp, act=act, aux_out=pre, residual=residual, drop=drop)
-        if self.moe_trace is not None:                                       # tests: the routing decision of every site
-            self.moe_trace[pfx] = (gates, wsel)
+        if self.moe_trace is not None:                                       # tests: the routing decisions of every site, in call order
+            self.moe_trace.setdefault(pfx, []).append((gates, wsel))
         return y, (SimpleNamespace(x=x_bf, U=U, A=A, gates=gates, wsel=wsel, pre=pre) if save else None)
 
     def moe_bwd(self, pfx: str, sp, sv, dy_bf, M: int, dx_out, **dx_kw):

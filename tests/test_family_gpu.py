@@ -38,10 +38,11 @@ def build(cfg, train=False):
     return (m.train() if train else m.eval()), sd
 
 
-def device_choices(trace, top_k_of):
-    """engine.moe_trace -> {site: LongTensor [N, top_k] (expert indices, by descending weight)}"""
+def device_choices(trace, top_k_of, call=0):
+    """engine.moe_trace -> {site: LongTensor [N, top_k] (expert indices, by descending weight)} of the call-th forward of each site"""
     out = {}
-    for site, (_gates, wsel) in trace.items():
+    for site, calls in trace.items():
+        _gates, wsel = calls[min(call, len(calls) - 1)]
         k = top_k_of(site)
         out[site] = torch.topk(wsel.detach().float().cpu(), k, dim=-1).indices
     return out
@@ -220,9 +221,10 @@ def test_nano_mini_full_size_forward_and_loss():
     assert tuple(out.logits.shape) == (2, 48, cfg.decoder_config.vocab_size) and tuple(out.encoder_output.shape) == (2, 64, 1024)
     # routing vs the reference (encoder sites: same rows in the same order)
     flips = total = 0
-    for site, (_g, wsel) in trace.items():
+    for site, calls in trace.items():
         if not site.startswith('encoder.'):
             continue
+        _g, wsel = calls[0]
         want, margin = torch.from_numpy(g[f'moe.{site}.idx'].astype(np.int64)), g[f'moe.{site}.margin']
         got = torch.topk(wsel.float().cpu(), want.shape[1], dim=-1).indices
         diff = (got.sort(1).values != want.sort(1).values).any(1).numpy()
@@ -513,3 +515,52 @@ def test_family_training_memorises_a_small_caption_set(extra):
             cur = torch.cat((cur, lg.argmax(-1, keepdim=True)), dim=1)
     REPORT[f'mini.memorise.{"advpos" if extra else "plain"}.generate_vs_forward'] = {'agree': agree, 'of': total}
     assert total >= 40 and agree == total, (agree, total)
+
+
+def test_family_contrastive_loss_lock_step_normaliser():
+    """add_contrastive_loss on the mini family model: the prompt rows and the text rows run as two decoder segments whose sparse
+    blocks gather DIFFERENT row subsets, yet every block's gradient normaliser must use the joint norm over both (one tensor in
+    the reference).  Loss terms and every gradient against the oracle's full-sequence evaluation (same expert choices checked)."""
+    from oracle import reference_model as orc
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    f = load_golden('mini_forward.npz')
+    cfg = mini_config()
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(add_contrastive_loss=True, training_contrastive_temperature=0.7), ignore_index=-100)
+    sharpen_gates_(det_init_(w.model, seed=0))
+    sd = {k: v.detach().clone() for k, v in w.model.state_dict().items()}
+    w = w.to(dev()).train()
+    w.pack_rows = False                         # dense (b, t) rows, so that the device's routing can be laid out as the oracle's rows
+    images, labels = torch.from_numpy(f['images']), torch.from_numpy(f['labels'])
+    eng = w.model._engine
+    eng.moe_trace = {}
+    loss, metrics = w.train_step(images.to(dev()), labels.to(dev()))
+    trace = dict(eng.moe_trace)
+    eng.moe_trace = None
+    loss.backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items() if k != 'decoder.lm_head.weight'}
+    osd['decoder.lm_head.weight'] = osd['decoder.transformer.wte.weight']
+    # the device's routing, laid out as the oracle's full-sequence rows: per sequence [kept prompt rows | kept text rows]
+    B, n_p = images.shape[0], cfg.vision_encoder_config.n_cls
+    text, prompt = device_choices(trace, top_k_fn(cfg), 0), device_choices(trace, top_k_fn(cfg), 1)
+    forced = {s: c for s, c in text.items() if s.startswith('encoder.')}
+    for s in (k for k in text if k.startswith('decoder.')):
+        pr, tx = prompt[s].view(B, -1, prompt[s].shape[-1]), text[s].view(B, -1, text[s].shape[-1])
+        assert pr.shape[1] == n_p                               # every prompt position is kept by every sparse decoder layer
+        forced[s] = torch.cat((pr, tx), dim=1).reshape(-1, pr.shape[-1])
+    io = {'forced': forced, 'record': {}}
+    ol, olm, oc = orc.lm_step(osd, cfg, images, labels, tok, training=True, contrastive_temperature=0.7, return_parts=True, moe_io=io)
+    ol.backward()
+    check_choices('mini.contrastive', forced, io['record'])
+    REPORT['mini.contrastive'] = {'lm': [float(metrics['train_loss_lm']), float(olm)], 'contrastive': [float(metrics['train_loss_contrastive']), float(oc)]}
+    assert abs(float(metrics['train_loss_lm']) - float(olm)) <= 1e-2 * max(1.0, float(olm))
+    assert abs(float(metrics['train_loss_contrastive']) - float(oc)) <= 1e-2 * max(1.0, float(oc))
+    fails = []
+    for name, p in w.model.named_parameters():
+        g = osd[name].grad
+        try:
+            grad_close(f'mini.contrastive.{name}', p.grad, (g if g is not None else torch.zeros_like(osd[name])).numpy(), rel=0.1, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:8])
