@@ -153,7 +153,7 @@ class DecodeAttnTimer:
         self.self_calls, self.n_layers = 0, n_layers
 
     def __enter__(self):
-        def timed(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0):
+        def timed(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0, **kw):
             if pos is not None:                   # self-attention: keys 0 .. step (the step's own key was just appended)
                 keys = self.self_calls // self.n_layers + 1
                 self.self_calls += 1
@@ -161,7 +161,7 @@ class DecodeAttnTimer:
                 keys = n_keys_fixed
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-            r = self.orig(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm)
+            r = self.orig(q, q_rs, kc, vc, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm, **kw)
             e1.record(torch.cuda.current_stream())
             self.records.append((e0, e1, B * H * 64 * 2 * (2 * keys + 2)))
             return r

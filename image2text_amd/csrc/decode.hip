@@ -46,19 +46,25 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 constexpr int DEC_MAX_KEYS = 1024;
 // append_dm > 0: q points at a packed [q | k | v] row of width 3*append_dm; the new token's k/v (this head's 64
 // columns) are written into the cache at *pos by this workgroup and attended to from LDS (fused kv_append).
-__global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __restrict__ q, int q_rs,
-                                                              bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
-                                                              long cache_bs, int cache_rs, bf16_t* __restrict__ o, int o_rs,
-                                                              const int* __restrict__ pos_ptr, int n_keys_fixed,
-                                                              int append_dm) {
-    __shared__ float qs[64], kn[64], vn[64];
-    __shared__ float ps[DEC_MAX_KEYS];
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+template <int WPB>         // waves (= heads) per workgroup: 49 152 one-wave workgroups per launch were dispatch-rate bound
+__global__ __launch_bounds__(64 * WPB) void decode_attention_kernel(const bf16_t* __restrict__ q, int q_rs,
+                                                                    bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                                    long cache_bs, int cache_rs, long cache_hs, bf16_t* __restrict__ o,
+                                                                    int o_rs, const int* __restrict__ pos_ptr, int n_keys_fixed,
+                                                                    int append_dm) {
+    __shared__ float qs_[WPB][64], kn_[WPB][64], vn_[WPB][64];
+    __shared__ float ps_[WPB][DEC_MAX_KEYS];
+    const int wv = threadIdx.x >> 6;
+    float* qs = qs_[wv];
+    float* kn = kn_[wv];
+    float* vn = vn_[wv];
+    float* ps = ps_[wv];
+    const int h = blockIdx.x * WPB + wv, b = blockIdx.y, lane = threadIdx.x & 63;
     const int n = pos_ptr ? (*pos_ptr + 1) : n_keys_fixed;
     const bf16_t* qrow = q + (size_t)b * q_rs + h * 64 + lane;
     qs[lane] = bf16_to_f32(qrow[0]);
-    bf16_t* kb = kc + (size_t)b * cache_bs + h * 64;
-    bf16_t* vb = vc + (size_t)b * cache_bs + h * 64;
+    bf16_t* kb = kc + (size_t)b * cache_bs + (size_t)h * cache_hs;      // cache_hs = 64: token-major rows [t][H][64];
+    bf16_t* vb = vc + (size_t)b * cache_bs + (size_t)h * cache_hs;      // cache_hs = tmax * 64 (cache_rs = 64): head-major [H][t][64]
     const int n_cached = append_dm > 0 ? n - 1 : n;          // keys read back from the cache
     if (append_dm > 0) {
         const bf16_t kv = qrow[append_dm], vv = qrow[2 * append_dm];
@@ -80,21 +86,30 @@ __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __re
         ps[n - 1] = s;
         mx = s;
     }
-    for (int k0 = 0; k0 < n_cached; k0 += 8) {
-        const int key = k0 + kg;
-        float s = 0.f;
-        if (key < n_cached) {
-            const u32x4 kk = *reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs + c * 8);
+    // 4 groups of 8 keys per trip: the four 16-byte loads are issued back to back (a one-group loop exposed the full HBM latency per
+    // 8 keys: a caption's whole cache is 4-8 such groups, so the kernel ran latency-bound at 0.6 of the HBM roof)
+    for (int k0 = 0; k0 < n_cached; k0 += 32) {
+        u32x4 kk[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += bf16lo(kk[e]) * qv[2 * e] + bf16hi(kk[e]) * qv[2 * e + 1];
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + kg;
+            kk[u] = u32x4{0u, 0u, 0u, 0u};
+            if (key < n_cached) kk[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)key * cache_rs + c * 8);
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        s *= 0.125f;
-        if (key < n_cached) {
-            if (c == 0) ps[key] = s;
-            mx = fmaxf(mx, s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + kg;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(kk[u][e]) * qv[2 * e] + bf16hi(kk[u][e]) * qv[2 * e + 1];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s *= 0.125f;
+            if (key < n_cached) {
+                if (c == 0) ps[key] = s;
+                mx = fmaxf(mx, s);
+            }
         }
     }
     mx = wave_max(mx);
@@ -110,15 +125,22 @@ __global__ __launch_bounds__(64) void decode_attention_kernel(const bf16_t* __re
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < n_cached; k0 += 8) {
-        const int key = k0 + kg;
-        if (key < n_cached) {
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)key * cache_rs + c * 8);
-            const float p = ps[key];
+    for (int k0 = 0; k0 < n_cached; k0 += 32) {
+        u32x4 vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + kg;
+            vv[u] = u32x4{0u, 0u, 0u, 0u};
+            if (key < n_cached) vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)key * cache_rs + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + kg;
+            const float p = key < n_cached ? ps[key] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += p * bf16lo(vv[e]);
-                acc[2 * e + 1] += p * bf16hi(vv[e]);
+                acc[2 * e] += p * bf16lo(vv[u][e]);
+                acc[2 * e + 1] += p * bf16hi(vv[u][e]);
             }
         }
     }
@@ -272,15 +294,20 @@ extern "C" int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kc
 }
 
 extern "C" int i2t_decode_attention(void* stream, const void* q, int q_rs, void* kcache, void* vcache,
-                                    long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
+                                    long cache_bs, int cache_rs, long cache_hs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
                                     int append_dm, int B, int H) {
+    I2T_REQUIRE(cache_hs >= 64 && cache_hs % 8 == 0, "i2t_decode_attention: head stride %ld", cache_hs);
     I2T_REQUIRE(append_dm == 0 || (pos_ptr && append_dm == 64 * H), "i2t_decode_attention: append needs pos_ptr and a packed qkv row");
     I2T_REQUIRE(q && kcache && vcache && o && B > 0 && H > 0, "i2t_decode_attention: bad args");
     I2T_REQUIRE(pos_ptr || (n_keys_fixed > 0 && n_keys_fixed <= DEC_MAX_KEYS), "i2t_decode_attention: key count out of range");
     I2T_REQUIRE(cache_rs % 8 == 0 && cache_bs % 8 == 0 && ALIGNED16(kcache) && ALIGNED16(vcache), "i2t_decode_attention: cache misaligned");
     I2T_REQUIRE(o_rs % 8 == 0 && ALIGNED16(o), "i2t_decode_attention: output rows must be 16-byte aligned");
-    hipLaunchKernelGGL(decode_attention_kernel, dim3(H, B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
-                       (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed, append_dm);
+    if (H % 4 == 0)
+        hipLaunchKernelGGL(decode_attention_kernel<4>, dim3(H / 4, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
+                           (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, cache_hs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed, append_dm);
+    else
+        hipLaunchKernelGGL(decode_attention_kernel<1>, dim3(H, B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q, q_rs,
+                           (bf16_t*)kcache, (bf16_t*)vcache, cache_bs, cache_rs, cache_hs, (bf16_t*)o, o_rs, pos_ptr, n_keys_fixed, append_dm);
     I2T_CHECK_LAUNCH("i2t_decode_attention");
     return I2T_OK;
 }

@@ -214,7 +214,8 @@ class GreedyDecoder:
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
-            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, d, st.ao, d, pos_ptr, 0, B, H, append_dm=d)
+            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, 64, st.ao, d, pos_ptr, 0, B, H, append_dm=d,
+                                 cache_hs=st.tmax * 64)           # head-major self-attention cache [B][H][tmax][64]
             ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
             if l in st.cross_kv:
                 kv, S = st.cross_kv[l]

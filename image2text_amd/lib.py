@@ -48,7 +48,7 @@ SIGNATURES = {
     'i2t_sum_over_batch': [P, P, L, P, I, I, I, I],
     'i2t_copy_rows': [P, P, L, P, L, I, I, I, I],
     'i2t_add_f32': [P, P, P, L],
-    'i2t_decode_attention': [P, P, I, P, P, L, I, P, I, P, I, I, I, I],
+    'i2t_decode_attention': [P, P, I, P, P, L, I, L, P, I, P, I, I, I, I],
     'i2t_kv_append': [P, P, I, P, P, L, I, P, I, I],
     'i2t_ngram_ban_argmax': [P, P, I, I, P, I, P, P, I, I, I, P],
     'i2t_sample_token': [P, P, I, P, I, P, P, I, I, I, F, I, F, P, P, I],

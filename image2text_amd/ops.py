@@ -420,8 +420,9 @@ def add_(dst, src):
     return dst
 
 
-def decode_attention(q, q_rs, kcache, vcache, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0):
-    _l.check(_lib().i2t_decode_attention(_stream(), _p(q), q_rs, _p(kcache), _p(vcache), cache_bs, cache_rs, _p(o), o_rs,
+def decode_attention(q, q_rs, kcache, vcache, cache_bs, cache_rs, o, o_rs, pos, n_keys_fixed, B, H, append_dm=0, cache_hs=64):
+    """cache_hs = 64: token-major cache rows [t][H][64]; cache_hs = tmax * 64 with cache_rs = 64: head-major [H][t][64]"""
+    _l.check(_lib().i2t_decode_attention(_stream(), _p(q), q_rs, _p(kcache), _p(vcache), cache_bs, cache_rs, cache_hs, _p(o), o_rs,
                                          _p(pos), n_keys_fixed, append_dm, B, H), 'i2t_decode_attention')
 
 

@@ -276,8 +276,11 @@ int i2t_add_f32(void* stream, float* dst, const float* src, long n);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Greedy decode step pieces (vision_encoder_decoder.py:136-182 with top_k=1, temperature=1):
- *   decode_attention: one new query token per caption against the self K/V cache (keys 0..*pos) -- cache layout
- *     [B][Tmax][d] bf16 for K and for V; also used for cross-attention with fixed n_keys (pos_ptr NULL);
+ *   decode_attention: one new query token per caption against the self K/V cache (keys 0..*pos); head h of caption b starts at
+ *     kcache + b * cache_bs + h * cache_hs and its keys are cache_rs apart: cache_hs = 64, cache_rs = d is the token-major layout
+ *     [B][Tmax][d] (what a projection GEMM writes: the cross-attention K/V, fixed n_keys, pos_ptr NULL), cache_hs = Tmax * 64,
+ *     cache_rs = 64 the head-major layout [B][H][Tmax][64] of the self-attention cache (a head's keys are one contiguous run:
+ *     the step is HBM-bound on exactly these reads);
  *     append_dm = d (0 = off): q is a packed [q|k|v] row and the new k/v are written to the cache at *pos by the same
  *     launch (fused kv_append);
  *   ngram_ban_argmax: HF NoRepeatNGramLogitsProcessor for every size in ngram_sizes (prompt included), then argmax
@@ -285,7 +288,7 @@ int i2t_add_f32(void* stream, float* dst, const float* src, long n);
  *   Positions live in device memory so that a captured hipGraph replays the same launch for every step.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_decode_attention(void* stream, const void* q, int q_rs, void* kcache, void* vcache,
-                         long cache_bs, int cache_rs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
+                         long cache_bs, int cache_rs, long cache_hs, void* o, int o_rs, const int* pos_ptr, int n_keys_fixed,
                          int append_dm, int B, int H);
 int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kcache, void* vcache, long cache_bs,
                   int cache_rs, const int* pos_ptr, int B, int d);

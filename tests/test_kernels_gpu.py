@@ -633,6 +633,19 @@ def test_decode_attention_and_kv_append(ops):
     q2 = qkv2[:, :d].float().reshape(B, 1, H, 64)
     ref, _ = ref_attention(q2, kc[:, :11].float().reshape(B, 11, H, 64), vc[:, :11].float().reshape(B, 11, H, 64), False)
     check('decode attention (fused append)', o.reshape(B, 1, H, 64), ref, 1e-2, 1 / 128)
+    # head-major cache [B][H][Tmax][64] (the self-attention cache of the decode step): same keys, same result, and the appended
+    # row lands in its head's run
+    for Hh in (2, 4):                                       # 1 and 4 heads per workgroup
+        dd = 64 * Hh
+        kt, vt = rnd(B, Tmax, dd, dtype=BF16, seed=84), rnd(B, Tmax, dd, dtype=BF16, seed=85)
+        kh = kt.view(B, Tmax, Hh, 64).permute(0, 2, 1, 3).contiguous()
+        vh = vt.view(B, Tmax, Hh, 64).permute(0, 2, 1, 3).contiguous()
+        q3 = rnd(B, 3 * dd, dtype=BF16, seed=86)
+        o_t, o_h = torch.empty(B, dd, dtype=BF16, device=dev()), torch.empty(B, dd, dtype=BF16, device=dev())
+        ops.decode_attention(q3, 3 * dd, kt, vt, Tmax * dd, dd, o_t, dd, pos, 0, B, Hh, append_dm=dd)
+        ops.decode_attention(q3, 3 * dd, kh, vh, Tmax * dd, 64, o_h, dd, pos, 0, B, Hh, append_dm=dd, cache_hs=Tmax * 64)
+        assert torch.equal(o_t, o_h)
+        assert torch.equal(kh.permute(0, 2, 1, 3).reshape(B, Tmax, dd), kt) and torch.equal(vh.permute(0, 2, 1, 3).reshape(B, Tmax, dd), vt)
 
 
 # ------------------------------------------------------------------------------------------------------ split-K / skinny paths
