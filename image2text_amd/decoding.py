@@ -210,7 +210,25 @@ class GreedyDecoder:
                 h = out
         if dc.fam is not None:
             self._layers_family(st)
-        for l in range(dc.L if dc.fam is None else 0):
+        else:
+            self._layers_dense(st)
+        if with_head:
+            ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
+            ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
+            if sampling is None:
+                ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
+            else:
+                ops.sample_token(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V,
+                                 sampling.temperature, sampling.top_k, sampling.nucleus_p, st.seed, dist_out=st.dist)
+        ops.advance(st.counters, 1)                            # pos and len together
+
+    def _layers_dense(self, st):
+        """The decoder blocks of one decode step for the dense multi-head model (64-wide heads, GELU-MLP)."""
+        eng, a, dc = self.eng, self.eng.arena, self.eng.dec
+        B, d, ff, H = st.B, dc.d, dc.ff, dc.H
+        pos_ptr = st.counters[0:1]
+        dp = eng.dp
+        for l in range(dc.L):
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
@@ -228,15 +246,6 @@ class GreedyDecoder:
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
             ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
-        if with_head:
-            ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
-            ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
-            if sampling is None:
-                ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
-            else:
-                ops.sample_token(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V,
-                                 sampling.temperature, sampling.top_k, sampling.nucleus_p, st.seed, dist_out=st.dist)
-        ops.advance(st.counters, 1)                            # pos and len together
 
     def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None):
         side = torch.cuda.Stream(device=st.arena.device)

@@ -139,3 +139,28 @@ def test_family_spec_and_refusals():
         family_spec(bad.decoder_config.transformer_config, 2)
     with pytest.raises(NotImplementedError):
         family_spec(mini_config(proj=12).decoder_config.transformer_config, 2)
+
+
+def test_lockstep_driver_sums_parts_of_generators_at_the_same_key():
+    """HotPath._lockstep: backward generators that stop at the same normaliser key share the sum of their parts, a generator that
+    is alone at a key gets its own part back, keys are served in descending order, return values are collected"""
+    from image2text_amd.engine import HotPath
+    log = []
+
+    def seg(name, keys, part):
+        total = 0.0
+        for k in keys:
+            joint = yield k, torch.tensor([part])
+            log.append((name, k, float(joint)))
+            total += float(joint)
+        return name, total
+
+    out = HotPath._lockstep(seg('text', [3, 2, 1, 0], 1.0), seg('prompt', [3, 1, 0], 10.0))
+    assert out == [('text', 11.0 + 1.0 + 11.0 + 11.0), ('prompt', 33.0)]
+    assert [(n, k) for n, k, _ in log if k == 2] == [('text', 2)] and dict(((n, k), j) for n, k, j in log)[('text', 2)] == 1.0
+    assert [k for n, k, _ in log if n == 'text'] == [3, 2, 1, 0]
+    # a generator that never yields (the fused dense path) just returns
+    def plain():
+        return 'done'
+        yield
+    assert HotPath._lockstep(plain()) == ['done']

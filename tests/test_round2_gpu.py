@@ -198,7 +198,11 @@ def test_train_and_val_loops_with_accumulation(tmp_path):
     assert stop is False and opt.steps == 3
     assert [b for b, _ in seen] == list(range(6)) and all(np.isfinite(v) for _, v in seen)
     for (n, p0), (_, p1) in zip(w0.model.named_parameters(), w1.model.named_parameters()):
-        assert float((p0 - p1).abs().max()) <= 2e-5 * max(1.0, float(p0.abs().max())), n        # (dW atomics: last-bit jitter)
+        # same arithmetic, but the embedding gradient is a scatter-add (atomics: last-bit jitter) and Adam turns the sign of a
+        # gradient that is zero up to that jitter into a full +-lr step: a few such elements may differ by up to 3 steps x lr
+        diff = (p0 - p1).abs()
+        tol = 2e-5 * max(1.0, float(p0.abs().max()))
+        assert float((diff > tol).float().mean()) <= 1e-4 and float(diff.max()) <= 3.2e-3, (n, float(diff.max()))
     saved = torch.load(ck, weights_only=True)
     want = sorted(n for n, _ in w1.model.named_parameters() if 'cross_attn' in n or n.startswith('encoder.1.'))
     assert sorted(saved) == want and len(want) >= 5
