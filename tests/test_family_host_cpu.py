@@ -164,3 +164,18 @@ def test_lockstep_driver_sums_parts_of_generators_at_the_same_key():
         return 'done'
         yield
     assert HotPath._lockstep(plain()) == ['done']
+
+
+@pytest.mark.parametrize('cfg_fn', [mini_config, lambda: __import__('image2text_amd.synth', fromlist=['tiny_config']).tiny_config()])
+def test_dp_decoder_range_of_the_arena(cfg_fn):
+    """DataParallelGrads._split: the decoder's parameters (laid out FIRST by named_parameters) form one contiguous arena range that
+    ends where the encoder's begin -- also with the MoE regrouping and its pad entries"""
+    from image2text_amd.engine import ParamArena
+    from image2text_amd.training.dp import DataParallelGrads
+    m = VisionEncoderDecoder(cfg_fn())
+    arena = ParamArena(m, torch.device('cpu'))
+    lo, hi = DataParallelGrads._split(None, arena)
+    dec = [(o, n) for name, (o, n, _) in arena.entries.items() if name.startswith('decoder.')]
+    enc = [(o, n) for name, (o, n, _) in arena.entries.items() if not name.startswith('decoder.')]
+    assert lo == 0 and 0 < hi < arena.total
+    assert all(lo <= o and o + n <= hi for o, n in dec) and all(o >= hi for o, n in enc)
