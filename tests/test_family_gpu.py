@@ -474,7 +474,6 @@ def test_family_training_memorises_a_small_caption_set(extra):
     images, labels = synthetic_batch(8, 32, 16, cfg.decoder_config.vocab_size, seed=21)
     images, labels = images.to(dev()), labels.to(dev())
     opt = FusedAdamW(w.model.parameters(), w.model, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.0)
-    pads = [n for n in w.model._engine.arena.entries if n not in w.model._engine.arena.params] if w.model._engine.arena is not None else []
     losses = []
     for _ in range(300):
         loss, _ = w.train_step(images, labels)
