@@ -1293,6 +1293,13 @@ __device__ __forceinline__ void g3_epi_part(const GemmParams& p, const f32x4 (&a
     if (PRE && !p.aux_out) return;                              // (uniform) nothing to emit
     const int g = lane >> 4, li = lane & 15;
     const int m = pd.m0 + wr * 64 + 16 * i + li, nb = pd.n0 + wc * 64;
+    // per-(row, third) multiplier: a wave's 64 columns lie inside ONE third whenever N / 3 is a multiple of 64 (q / k / v of width
+    // 512, 768, ...), so the division and the hash are done once per row here instead of once per quad (4 x ~55 VALU instructions
+    // in a step that has to fit behind one MFMA block)
+    const unsigned sec = (unsigned)(p.N / 3);
+    const bool one_third = EPI == 1 && p.drop_mode == 2 && (sec & 63u) == 0;
+    float mult = 1.f;
+    if (one_third) mult = dropout_keep(p.drop_key + (unsigned)nb / sec, (unsigned)min(m, p.M - 1), p.drop_thr) ? p.drop_scale : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 v = acc[i][j];                                    // alpha = 1 (host), bias already inside
@@ -1301,8 +1308,12 @@ __device__ __forceinline__ void g3_epi_part(const GemmParams& p, const f32x4 (&a
             for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
         }
         if (EPI == 1 && p.drop_mode == 2) {
-            const unsigned third = (unsigned)(nb + 16 * j + 4 * g) / (unsigned)(p.N / 3);
-            v *= dropout_keep(p.drop_key + third, (unsigned)min(m, p.M - 1), p.drop_thr) ? p.drop_scale : 0.f;
+            if (one_third) {
+                v *= mult;
+            } else {
+                const unsigned third = (unsigned)(nb + 16 * j + 4 * g) / sec;
+                v *= dropout_keep(p.drop_key + third, (unsigned)min(m, p.M - 1), p.drop_thr) ? p.drop_scale : 0.f;
+            }
         }
         const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         const int slot8 = 4 * j + g;                            // 8-byte slot within the 128-B row
@@ -1791,10 +1802,13 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     {   // gemm3 (256 x 128 tiles, the previous tile's epilogue inside the K loop): bit-equal to the 256^2 kernel; measured on MI355X
         // (tools/bench_gemm3.py) +8.5 % at K = 512 (class 1: 865 vs 797 TF), a tie at K = 768 (993 vs 979, 963 vs 953, 1026 vs 1058)
         // and -14 % at K = 2048 (its K loop moves 1.33x the LDS bytes per MFMA and is LDS-bound); the GELU class LOSES (458 vs 704 TF:
-        // a 64-value GELU step per wave outlasts the MFMA block it is meant to hide behind).  Default: class 1 with K <= 512 only.
+        // a 64-value GELU step per wave outlasts the MFMA block it is meant to hide behind).  Default: class 1 with K <= 512 only ...
         // I2T_GEMM3 = 0 never | 1 always, epilogue after the K loop | 2 always, overlapped | unset: the default rule.
         const char* e3 = getenv("I2T_GEMM3");          // (read per call: a test flips it)
-        const int g3 = e3 ? atoi(e3) : ((g256_epilogue_class(p) == 1 && K <= 512) ? 2 : 0);
+        // ... and only without the per-row dropout multipliers and up to ~4e5 rows: at the benchmark's M = 798 720 (B = 3072) the
+        // 256^2 kernel is the faster one (1363 vs 1654 us with dropout, 1417 vs 1528 without), and with dropout gemm3 does not win
+        // at M = 266 240 either (515 vs 513 us)
+        const int g3 = e3 ? atoi(e3) : ((g256_epilogue_class(p) == 1 && K <= 512 && !p.drop_mode && (long)M <= 400000) ? 2 : 0);
         const int cls3 = g256_epilogue_class(p);
         if (g3 && splits == 1 && !a_kmajor && !b_kmajor && K % 64 == 0 && alpha == 1.0f && (N & 7) == 0 && (ldc & 7) == 0 && ALIGNED16(C) &&
             ((cls3 == 1 && K >= 5 * 64) || (cls3 == 2 && K >= 8 * 64 && (!aux_out || ((ld_aux_out & 7) == 0 && ALIGNED16(aux_out))))) &&
