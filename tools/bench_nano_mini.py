@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--decode-batch', type=int, default=1024)
     ap.add_argument('--new-tokens', type=int, default=64)
     ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM table of one step on stderr')
     ap.add_argument('--split', action='store_true', help='time every ops.* call family of one step with HIP events')
     args = ap.parse_args()
@@ -113,6 +114,9 @@ def main():
     out['gemm_family'] = {'launches': gs['launches'], 'ms_per_step': round(gs['total_ms'], 2), 'tflops': round(gs['tflops'], 1),
                           'frac_of_2500_tflops': round(gs['tflops'] / 2500.0, 3), 'algorithmic_tb_per_s': round(tbs, 2),
                           'frac_of_8_tb_per_s': round(tbs / 8.0, 3)}
+    if args.no_decode:
+        print(json.dumps(out))
+        return
     # greedy decode
     wrapper.eval()
     Bd = args.decode_batch
