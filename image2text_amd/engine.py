@@ -555,11 +555,11 @@ class HotPath(FamilyBlocks):
         emb_drop = plan.get(0, 'emb') if plan is not None else None
         if emb_drop is not None:
             ops.dropout_apply(x, B * T, d, emb_drop)
-        saves, cur_x = [], x.view(B * T, d)
+        saves, cur_x, perm = [], x.view(B * T, d), None
         for l in range(e.L - 1 if self.cls_only_last else e.L):
             if e.fam is not None:
-                cur_x, sv = self.fam_layer_fwd(f'{self.ep}transformer.h.{l}', e.fam, cur_x, B, T, None, 0, save, plan, l, None,
-                                               self.sparse_subset('enc', l, B, T, 0, None))
+                cur_x, sv, perm = self.fam_layer_fwd(f'{self.ep}transformer.h.{l}', e.fam, cur_x, perm, B, T, None, 0, save, plan, l, None,
+                                                     self.sparse_subset('enc', l, B, T, 0, None))
             else:
                 cur_x, sv = self.block_fwd(f'{self.ep}transformer.h.{l}', cur_x, B, T, d, e.H, e.ff, e.causal, None, 0, save, plan, l)
             saves.append(sv)
@@ -567,6 +567,9 @@ class HotPath(FamilyBlocks):
         if self.cls_only_last:      # the last block's patch rows are never read: compute its CLS rows only
             cls, sv = self.block_fwd_cls(f'{self.ep}transformer.h.{e.L - 1}', cur_x, B, T, d, e.H, e.ff, e.ncls, save, plan, e.L - 1)
             saves.append(sv)
+        elif perm is not None:      # the stream is stored as the last sparse layer's pieces: fetch the CLS rows through its index
+            cls = self._empty(Mc, d)
+            ops.gather_rows(cur_x, perm.view(B, T)[:, :e.ncls].reshape(-1).contiguous(), Mc, d, out_f32=cls)
         else:
             cls = self._empty(Mc, d)
             ops.copy_rows(cur_x, T * d, cls, e.ncls * d, B, e.ncls, d)
@@ -609,10 +612,10 @@ class HotPath(FamilyBlocks):
             self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, presummed_slot=1)
         elif e.fam is not None:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
-            dxf = dx.view(B * T, d)
+            dxf, dperm = dx.view(B * T, d), None
             for l in reversed(range(e.L)):
-                dxf = self.fam_layer_bwd(f'{self.ep}transformer.h.{l}', e.fam, ctx.saves[l], dxf, B, T, 0, None, None)
-            dx = dxf.view(B, T, d)
+                dxf, dperm = self.fam_layer_bwd(f'{self.ep}transformer.h.{l}', e.fam, ctx.saves[l], dxf, dperm, B, T, 0, None, None)
+            dx = self.materialize(dxf, dperm).view(B, T, d)
         else:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
             self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
@@ -696,15 +699,16 @@ class HotPath(FamilyBlocks):
                 ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
             if emb_drop is not None:                          # decoder.py:233/238: the embedding dropout covers the prompt rows too
                 ops.dropout_apply(x, M, d, emb_drop)
-        saves, cur = [], x
+        saves, cur, perm = [], x, None
         for l in range(dc.L):
             m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
             if dc.fam is not None:
-                cur, sv = self.fam_layer_fwd(f'{self.dp}transformer.h.{l}', dc.fam, cur, B, T, m, S, save, plan, l, vl,
-                                             self.sparse_subset('dec', l, B, T, pos_offset, vl), split)
+                cur, sv, perm = self.fam_layer_fwd(f'{self.dp}transformer.h.{l}', dc.fam, cur, perm, B, T, m, S, save, plan, l, vl,
+                                                   self.sparse_subset('dec', l, B, T, pos_offset, vl), split)
             else:
                 cur, sv = self.block_fwd(f'{self.dp}transformer.h.{l}', cur, B, T, d, dc.H, dc.ff, dc.causal, m, S, save, plan, l, vl)
             saves.append(sv)
+        cur = self.materialize(cur, perm)
         hid, mf, rf = self._empty(M, d), self._empty(M), self._empty(M)
         ops.layernorm_fwd(cur, a.P(f'{self.dp}transformer.ln_f.weight'), a.P(f'{self.dp}transformer.ln_f.bias'), hid, mf, rf, M, d)
         hb = self._empty(M, d, dtype=BF16)
@@ -781,8 +785,11 @@ class HotPath(FamilyBlocks):
         ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
         if dc.fam is not None:
+            dperm = None
             for l in reversed(range(dc.L)):
-                dx = yield from self.fam_layer_bwd_steps(l, f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, B, T, ctx.S, dmem, ctx.vl)
+                dx, dperm = yield from self.fam_layer_bwd_steps(l, f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, dperm, B, T, ctx.S,
+                                                                dmem, ctx.vl)
+            dx = self.materialize(dx, dperm)
         elif paired:        # the un-fused form of _blocks_bwd: the normaliser's sum comes from outside
             dxb = self._empty(M, d, dtype=BF16)
             for l in reversed(range(dc.L)):

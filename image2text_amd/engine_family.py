@@ -106,7 +106,7 @@ class FamilyBlocks:
         self._moe_cache[key] = mv
         return mv
 
-    def moe_fwd(self, pfx: str, sp, x_bf, M: int, act: int, residual, drop, save: bool):
+    def moe_fwd(self, pfx: str, sp, x_bf, M: int, act: int, residual, drop, save: bool, out=None):
         """y = MoELinear(x) [+ GELU when act == 1] [+ residual, dropout]: returns (y, saved).  y is bf16 with act, else fp32."""
         mv = self._moe_views(pfx, sp)
         E, P, G = sp.E, sp.P, sp.G
@@ -116,7 +116,7 @@ class FamilyBlocks:
         gates, wsel = self._empty(M, E), self._empty(M, E)
         ops.moe_gate_fwd(U, mv.wg2, mv.bg2, A, gates, wsel, M, E, P, G, sp.top_k, mv.in_f ** -0.5)
         ops.moe_pack_w2(mv.l2w, mv.l2b, mv.W2aug, mv.out_f, E, P)            # (parameters may have changed since the last step)
-        y = self._empty(M, mv.out_f, dtype=BF16 if act else F32)
+        y = out if out is not None else self._empty(M, mv.out_f, dtype=BF16 if act else F32)
         pre = self._empty(M, mv.out_f, dtype=BF16) if (act and save) else None
         ops.gemm(A, mv.W2aug, y, M, mv.out_f, sp.Kp, act=act, aux_out=pre, residual=residual, drop=drop)
         if self.moe_trace is not None:                                       # tests: the routing decisions of every site, in call order
@@ -247,7 +247,8 @@ class FamilyBlocks:
         return out
 
     # ------------------------------------------------------------------------------------------------ one block
-    def fam_block_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, split: int = 0):
+    def fam_block_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, split: int = 0, out=None):
+        """out: fp32 [M, d] buffer the block output is written to (a sparse layer hands in its slice of the layer output)."""
         a = self.arena
         d, H, hd = sp.d, sp.H, sp.hd
         M = vl.total if vl is not None else B * T
@@ -299,13 +300,13 @@ class FamilyBlocks:
         ops.layernorm_fwd(x2, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, M, d)
         if sp.moe is not None:
             h, sv.fc = self.moe_fwd(f'{pfx}.mlp.c_fc', sp.moe, ln2, M, 1, None, None, save)
-            x3, sv.pj = self.moe_fwd(f'{pfx}.mlp.c_proj', sp.moe, h, M, 0, x2, dr['mlp'], save)
+            x3, sv.pj = self.moe_fwd(f'{pfx}.mlp.c_proj', sp.moe, h, M, 0, x2, dr['mlp'], save, out=out)
         else:
             ff = a.entries[f'{pfx}.mlp.c_fc.weight'][2][0]
             h = self._empty(M, ff, dtype=BF16)
             pre = self._empty(M, ff, dtype=BF16) if save else None
             ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
-            x3 = self._empty(M, d)
+            x3 = out if out is not None else self._empty(M, d)
             ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2, drop=dr['mlp'])
             sv.h, sv.pre, sv.ff = h, pre, ff
         sv.x2, sv.ln2, sv.m2, sv.r2 = x2, ln2, m2, r2
@@ -417,12 +418,17 @@ class FamilyBlocks:
             sub.n_in, sub.n_out = int(rows_in.size), int(rows_out.size)
             sub.rows_in = torch.from_numpy(rows_in.astype(np.int32)).to(dev)
             sub.rows_out = torch.from_numpy(rows_out.astype(np.int32)).to(dev)
+            # the layer's output lives as [block rows | null rows] ("pieces"); perm[r] = where row r of the sequence order sits in it
+            perm = np.empty(sub.n_in + sub.n_out, dtype=np.int32)
+            perm[rows_in] = np.arange(sub.n_in, dtype=np.int32)
+            perm[rows_out] = sub.n_in + np.arange(sub.n_out, dtype=np.int32)
+            sub.perm = torch.from_numpy(perm).to(dev)
         if key is not None:
             self._sub_cache[key] = sub
         return sub
 
-    def _null_fwd(self, pfx: str, x, n: int, d: int, rows):
-        """x + null_connector(x) on the rows `rows` of x (all rows when None) -> (fp32 [n, d], bf16 copy of the inputs)"""
+    def _null_fwd(self, pfx: str, x, n: int, d: int, rows, out=None):
+        """x + null_connector(x) on the rows `rows` of x (all rows when None) -> (fp32 [n, d] (= out when given), bf16 copy of the inputs)"""
         a = self.arena
         xb = self._empty(n, d, dtype=BF16)
         if rows is None:
@@ -431,12 +437,12 @@ class FamilyBlocks:
         else:
             xn = self._empty(n, d)
             ops.gather_rows(x, rows, n, d, out_f32=xn, out_bf16=xb)
-        yn = self._empty(n, d)
+        yn = out if out is not None else self._empty(n, d)
         ops.gemm(xb, a.W(f'{pfx}.null_connector.weight'), yn, n, d, d, bias=a.P(f'{pfx}.null_connector.bias'), residual=xn)
         return yn, xb
 
-    def _null_bwd(self, pfx: str, xb, dy, n: int, d: int, rows):
-        """gradient of x + null_connector(x): parameter gradients accumulated, returns d/dx fp32 [n, d]"""
+    def _null_bwd(self, pfx: str, xb, dy, n: int, d: int, rows, out=None):
+        """gradient of x + null_connector(x): parameter gradients accumulated, returns d/dx fp32 [n, d] (= out when given)"""
         a = self.arena
         dyb = self._empty(n, d, dtype=BF16)
         if rows is None:
@@ -445,54 +451,70 @@ class FamilyBlocks:
         else:
             dyn = self._empty(n, d)
             ops.gather_rows(dy, rows, n, d, out_f32=dyn, out_bf16=dyb)
-        dxn = self._empty(n, d)
+        dxn = out if out is not None else self._empty(n, d)
         nb = f'{pfx}.null_connector.bias'
         self._linear_bwd(dyb, n, d, d, xb, f'{pfx}.null_connector.weight', nb if nb in a.params else None, dx_out=dxn, residual=dyn)
         return dxn
 
-    def fam_layer_fwd(self, pfx: str, sp, x, B, T, mem_bf, S, save: bool, plan, layer: int, vl, sub, split: int = 0):
-        """split > 0 (forward only): the rows are [prompt | text] of a non-causal decoder, text rows must not see prompt keys."""
+    @staticmethod
+    def _compose(perm, rows):
+        """rows of the sequence order -> rows of a tensor stored in `perm` order (None = sequence order)"""
+        return rows if perm is None else perm[rows.long()]
+
+    def materialize(self, x, perm):
+        """A residual stream stored as a sparse layer's pieces -> sequence order (one gather pass)."""
+        if perm is None:
+            return x
+        out = self._empty(*x.shape)
+        ops.gather_rows(x, perm, x.shape[0], x.shape[1], out_f32=out)
+        return out
+
+    def fam_layer_fwd(self, pfx: str, sp, x, xperm, B, T, mem_bf, S, save: bool, plan, layer: int, vl, sub, split: int = 0):
+        """One layer on the residual stream (x, xperm): x fp32 [M, d] holds row r of the sequence order at x[xperm[r]] (xperm None:
+        in place).  A sparse layer never scatters: its block rows and its null-connector rows are written next to each other
+        ("pieces") and the NEXT consumer gathers through the composed index, so the stream costs one gather per path and layer
+        instead of a gather and a scatter.  Returns (out, saved, out_perm).
+        split > 0 (forward only): the rows are [prompt | text] of a non-causal decoder, text rows must not see prompt keys."""
         if sub is None:
-            return self.fam_block_fwd(pfx, sp, x, B, T, mem_bf, S, save, plan, layer, vl, split)
+            x = self.materialize(x, xperm)
+            y, bsv = self.fam_block_fwd(pfx, sp, x, B, T, mem_bf, S, save, plan, layer, vl, split)
+            return y, bsv, None
         if split and not sub.all_null:
             split = int((sub.idx_t < split).sum())          # the prompt positions kept by this layer come first in the subset
         d, M = sp.d, x.shape[0]
         if sub.all_null or sub.n_in == 0:
-            y, xb = self._null_fwd(pfx, x, M, d, None)
-            return y, (SimpleNamespace(only_null=True, xb=xb) if save else None)
+            y, xb = self._null_fwd(pfx, x, M, d, xperm)
+            return y, (SimpleNamespace(only_null=True, xb=xb) if save else None), None
+        pieces = self._empty(M, d)
         xs = self._empty(sub.n_in, d)
-        ops.gather_rows(x, sub.rows_in, sub.n_in, d, out_f32=xs)
-        ys, bsv = self.fam_block_fwd(pfx, sp, xs, B, sub.T_in, mem_bf, S, save, plan, layer, sub.vl_in, split)
-        out = self._empty(M, d)
-        ops.scatter_rows(ys, sub.rows_in, out, sub.n_in, d)
+        ops.gather_rows(x, self._compose(xperm, sub.rows_in), sub.n_in, d, out_f32=xs)
+        _, bsv = self.fam_block_fwd(pfx, sp, xs, B, sub.T_in, mem_bf, S, save, plan, layer, sub.vl_in, split, out=pieces[:sub.n_in])
         xnb = None
         if sub.n_out:
-            yn, xnb = self._null_fwd(pfx, x, sub.n_out, d, sub.rows_out)
-            ops.scatter_rows(yn, sub.rows_out, out, sub.n_out, d)
-        return out, (SimpleNamespace(only_null=False, block=bsv, xnb=xnb, sub=sub) if save else None)
+            _, xnb = self._null_fwd(pfx, x, sub.n_out, d, self._compose(xperm, sub.rows_out), out=pieces[sub.n_in:])
+        return pieces, (SimpleNamespace(only_null=False, block=bsv, xnb=xnb, sub=sub) if save else None), sub.perm
 
-    def fam_layer_bwd_steps(self, key, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
-        """Generator form of the layer backward: yields (key, sum(g^2) of this segment's part of the block-output gradient) right
-        before the gradient normaliser and is sent back the sum to normalise with (engine.HotPath._lockstep); returns the gradient
-        w.r.t. the layer input (dx itself for a dense layer, a new buffer for a sparse one)."""
+    def fam_layer_bwd_steps(self, key, pfx: str, sp, sv, dx, dperm, B, T, S, dmem, vl):
+        """Generator form of the layer backward on the gradient stream (dx, dperm) (same storage convention as the forward stream):
+        yields (key, sum(g^2) of this segment's part of the block-output gradient) right before the gradient normaliser and is sent
+        back the sum to normalise with (engine.HotPath._lockstep); returns (gradient w.r.t. the layer input, its perm)."""
         if not hasattr(sv, 'only_null'):
+            dx = self.materialize(dx, dperm)
             joint = yield key, ops.sumsq(dx, self._empty(1))
             self.fam_block_bwd(pfx, sp, sv, dx, B, T, S, dmem, vl, ws=joint)
-            return dx
+            return dx, None
         d, M = sp.d, dx.shape[0]
         if sv.only_null:
-            return self._null_bwd(pfx, sv.xb, dx, M, d, None)
+            return self._null_bwd(pfx, sv.xb, dx, M, d, dperm), None
         sub = sv.sub
-        dys = self._empty(sub.n_in, d)
-        ops.gather_rows(dx, sub.rows_in, sub.n_in, d, out_f32=dys)
+        dpieces = self._empty(M, d)
+        dys = dpieces[:sub.n_in]
+        ops.gather_rows(dx, self._compose(dperm, sub.rows_in), sub.n_in, d, out_f32=dys)
         joint = yield key, ops.sumsq(dys, self._empty(1))
         self.fam_block_bwd(pfx, sp, sv.block, dys, B, sub.T_in, S, dmem, sub.vl_in, ws=joint)
-        out = self._empty(M, d)
-        ops.scatter_rows(dys, sub.rows_in, out, sub.n_in, d)
         if sub.n_out:
-            dxn = self._null_bwd(pfx, sv.xnb, dx, sub.n_out, d, sub.rows_out)
-            ops.scatter_rows(dxn, sub.rows_out, out, sub.n_out, d)
-        return out
+            self._null_bwd(pfx, sv.xnb, dx, sub.n_out, d, self._compose(dperm, sub.rows_out), out=dpieces[sub.n_in:])
+        return dpieces, sub.perm
 
-    def fam_layer_bwd(self, pfx: str, sp, sv, dx, B, T, S, dmem, vl):
-        return self._lockstep(self.fam_layer_bwd_steps(0, pfx, sp, sv, dx, B, T, S, dmem, vl))[0]
+    def fam_layer_bwd(self, pfx: str, sp, sv, dx, dperm, B, T, S, dmem, vl):
+        return self._lockstep(self.fam_layer_bwd_steps(0, pfx, sp, sv, dx, dperm, B, T, S, dmem, vl))[0]
