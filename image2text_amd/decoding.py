@@ -61,7 +61,7 @@ class GreedyDecoder:
         off = ncls if cfg.use_soft_prompting else 0
         tmax = dc.block - off
         d, ff = dc.d, dc.ff
-        st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a)
+        st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a, sparse_epoch=eng.sparse_epoch)
         e = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=dev)
         st.ids = torch.zeros(B, ids_ld, dtype=torch.long, device=dev)
         st.counters = torch.zeros(2, dtype=torch.int32, device=dev)        # [pos, len]
@@ -273,7 +273,7 @@ class GreedyDecoder:
         B, P = prompt_ids.shape
         total = P + max_new_tokens
         st = self._state
-        if st is None or st.B != B or st.arena is not a or st.ids_ld < total:
+        if st is None or st.B != B or st.arena is not a or st.ids_ld < total or st.sparse_epoch != eng.sparse_epoch:
             st = self._state = self._build(B, max(total, dc.block))
         assert total <= st.tmax, f'prompt + new tokens ({total}) exceed the text window ({st.tmax})'
         assert not (return_margins and sampling is not None) and not (return_dists and sampling is None)

@@ -235,8 +235,8 @@ class HotPath(FamilyBlocks):
         # the nano-mini block family (multi-query / MoE / sparse / head widths other than 64): engine_family.FamilyBlocks
         self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
         self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer, force=not dcfg.transformer_config.is_causal)
-        self._sparse_idx = {'enc': self._sparse_sets(model, self.ep, ecfg.n_layer) if self.enc.fam and self.enc.fam.sparse else None,
-                            'dec': self._sparse_sets(model, self.dp, dcfg.n_layer) if self.dec.fam and self.dec.fam.sparse else None}
+        self._sparse_idx, self._sparse_versions, self.sparse_epoch = {'enc': None, 'dec': None}, None, 0
+        self._refresh_sparse_sets()
         self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
         self._moe_cache, self._sub_cache = {}, {}
         self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
@@ -259,6 +259,25 @@ class HotPath(FamilyBlocks):
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
         self.grad_ready_hooks = []      # callables(which: 'begin' | 'decoder' | 'encoder'), e.g. the data-parallel exchange
+
+    def _refresh_sparse_sets(self):
+        """(Re-)read the sparse layers' position sets when their buffers changed (they are part of the state dict: a checkpoint
+        with other draws may be loaded after construction); everything derived from them is dropped."""
+        sparse = [(t, p, n) for t, p, n, f in (('enc', self.ep, self.enc.L, self.enc.fam), ('dec', self.dp, self.dec.L, self.dec.fam))
+                  if f is not None and f.sparse]
+        if not sparse:
+            return
+        bufs = dict(self.model.named_buffers())
+        # (storage address + version counter: load_state_dict bumps the version in place, .to(device) replaces the tensor)
+        versions = tuple((b.data_ptr(), b._version) for b in (bufs[f'{p}transformer.h.{l}.{k}'] for _, p, n in sparse for l in range(n)
+                                                               for k in ('input_mask_idx', 'input_mask_not_idx')))
+        if versions == self._sparse_versions:
+            return
+        self._sparse_versions = versions
+        for t, p, n in sparse:
+            self._sparse_idx[t] = self._sparse_sets(self.model, p, n)
+        self._sub_cache = {k: v for k, v in getattr(self, '_sub_cache', {}).items() if isinstance(k, tuple) and k and k[0] == 'posplan'}
+        self.sparse_epoch += 1
 
     @staticmethod
     def _sparse_sets(model, prefix: str, n_layer: int):
@@ -285,6 +304,7 @@ class HotPath(FamilyBlocks):
             self._moe_cache.clear()
             self._sub_cache.clear()
         self.arena.refresh_shadow()
+        self._refresh_sparse_sets()
         self.enc_drop = self.dec_drop = self.dec_drop_prompt = None
         if training:
             # one fresh 64-bit seed per training forward, derived from torch's seed (torch.manual_seed reproduces a run, and

@@ -563,3 +563,40 @@ def test_family_contrastive_loss_lock_step_normaliser():
         except AssertionError as e:
             fails.append(str(e))
     assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:8])
+
+
+def test_sparse_position_sets_follow_the_state_dict():
+    """The kept / skipped position sets are persistent buffers (layers.py:557-558): loading a checkpoint with other draws into a model
+    that has already run must re-plan the sparse layers (row lists, decode slot tables) -- same results as a model that was built
+    with those sets from the start"""
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    f = load_golden('mini_decode.npz')
+    cfg = mini_config()
+    m1, sd = build(cfg)
+    images = torch.from_numpy(f['images']).to(dev())
+    ids = torch.from_numpy(f['ids'][:, :12]).to(dev())
+    prompt = torch.from_numpy(f['prompt']).to(dev())
+    with torch.no_grad():
+        out1 = m1(images=images, ids=ids).logits.clone()
+        gen1 = m1.generate(images, prompt, max_new_tokens=8, temperature=1.0, top_k=1)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    n_cls = cfg.vision_encoder_config.n_cls
+    for tower, first in (('decoder', n_cls), ('encoder', 0)):
+        for l in range(2):
+            key = f'{tower}.transformer.h.{l}.input_mask_idx'
+            size = sd[key].numel() + sd[key.replace('_idx', '_not_idx')].numel()
+            gen = np.random.Generator(np.random.PCG64(seed=100 + l))
+            full = np.concatenate((np.arange(first), gen.permutation(size - first) + first))
+            k = sd[key].numel()
+            sd2[key] = torch.from_numpy(np.sort(full[:k])).long()
+            sd2[key.replace('_idx', '_not_idx')] = torch.from_numpy(np.sort(full[k:])).long()
+    m1.load_state_dict(sd2)
+    m2 = VisionEncoderDecoder(cfg)
+    m2.load_state_dict(sd2)
+    m2 = m2.to(dev()).eval()
+    with torch.no_grad():
+        a, b = m1(images=images, ids=ids).logits, m2(images=images, ids=ids).logits
+        ga = m1.generate(images, prompt, max_new_tokens=8, temperature=1.0, top_k=1)
+        gb = m2.generate(images, prompt, max_new_tokens=8, temperature=1.0, top_k=1)
+    assert torch.equal(a, b) and torch.equal(ga, gb)
+    assert float((a - out1).abs().max()) > 1e-3                   # other positions attended: other numbers
