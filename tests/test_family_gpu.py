@@ -652,3 +652,35 @@ def test_every_trainer_option_on_every_tower_mix(kind):
         vloss, vm = w.val_step(images, labels)
         gen = w.model.generate(images, torch.full((6, 1), V - 1, dtype=torch.long, device=dev()), max_new_tokens=6, temperature=0.8, top_k=20)
     assert torch.isfinite(vloss) and 'val_loss_contrastive' in vm and gen.shape == (6, 7)
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_family_edge_case_captions(B):
+    """ragged extremes through the sparse / packed planning: a caption with no label at all, a one-token caption, a full-length
+    one (and a batch of one): packed == dense, finite gradients, zero-weight rows contribute nothing"""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = mini_config()
+    V = cfg.decoder_config.vocab_size
+    tok = fake_tokenizer(V)
+    images, labels = synthetic_batch(3, 32, 24, V, seed=13)
+    labels[0, :] = -100                                  # nothing to predict
+    labels[1, 0] = V - 1
+    labels[1, 1:] = -100                                 # EOS only
+    labels[2, :] = torch.randint(0, V - 1, (24,), generator=torch.Generator().manual_seed(1))       # no EOS, every position live
+    if B == 1:
+        images, labels = images[1:2], labels[1:2]
+    res = []
+    for packed in (True, False):
+        w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+        sharpen_gates_(det_init_(w.model, seed=0))
+        w = w.to(dev()).train()
+        w.pack_rows = packed
+        loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+        loss.backward()
+        assert torch.isfinite(loss)
+        res.append((float(loss.detach()), {n: p.grad.detach().float().cpu().numpy() for n, p in w.model.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-3 * max(1.0, abs(res[1][0]))
+    for n in res[0][1]:
+        assert np.isfinite(res[0][1][n]).all(), n
+        grad_close(f'edge.{B}.{n}', torch.from_numpy(res[0][1][n]), res[1][1][n], rel=6e-2, cos=0.99)
