@@ -21,7 +21,9 @@ Reference quirks reproduced on purpose (each pinned by a golden fixture):
     decoder and unmasked in the encoder;
   * with soft prompting text rows never see prompt columns and prompt-row logits are sliced off, so the prompt rows
     and the text rows are two independent causal segments; the training path runs only the text segment
-    (positions offset by n_cls), ``forward`` also runs the prompt segment to return the full ``hidden_state``;
+    (positions offset by n_cls), ``forward`` also runs the prompt segment to return the full ``hidden_state`` -- differentiably:
+    when a loss touches those rows (a custom loss on ``hidden_state``, the contrastive term) the two segments' backward passes run
+    in lock step and share every block's gradient normaliser (``_lockstep``);
   * LayerNormND is applied twice with shared weights; "patches" are a flat chunking of the CHW conv output;
   * ``normalize_gradients`` (models/functions.py:19-24) rescales the residual-stream gradient to unit L2 norm at
     every block output, per replica.

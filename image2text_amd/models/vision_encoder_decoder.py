@@ -52,16 +52,27 @@ class _HotPathFunction(torch.autograd.Function):
         T = min(L, eng.dec.block - off)                       # the reference crops inputs to block_size (:88)
         hid, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids[:, :T], pos_offset=off)
         logits = eng.logits_f32(hb, B * T).view(B, T, -1)
+        hid = hid.view(B, T, -1)
+        # hidden_state of the reference also carries the prompt rows (it is not sliced, :133).  Under a causal decoder they are an
+        # independent causal segment (text never attends to them); differentiable like everything else: a loss on those rows
+        # back-propagates through this segment, in lock step with the text rows (shared gradient normaliser, layers.py:606-607)
+        pctx, n_p = None, 0
+        if cfg.use_soft_prompting and eng.dec.causal:
+            n_p = min(ncls, eng.dec.block)
+            ph, _, pctx = eng.decode_segment(B, n_p, mem, ncls, save, embeds=enc_out[:, :n_p].reshape(B * n_p, -1), pos_offset=0,
+                                             drop_plan=eng.dec_drop_prompt)
+            hid = torch.cat((ph.view(B, n_p, -1), hid), dim=1)
+        ctx.set_materialize_grads(False)                     # an output the loss does not use arrives as None, not as zeros
         ctx.model, ctx.enc_ctx, ctx.dctx, ctx.has_enc_in = model, enc_ctx, dctx, enc_in is not None
-        ctx.shapes = (B, T, ncls)
-        return enc_out, logits, hid.view(B, T, -1)
+        ctx.pctx, ctx.shapes = pctx, (B, T, ncls, n_p)
+        return enc_out, logits, hid
 
     @staticmethod
     def backward(ctx, d_enc, d_logits, d_hid):
         model = ctx.model
         eng: HotPath = model._engine
         a = eng.arena
-        B, T, ncls = ctx.shapes
+        B, T, ncls, n_p = ctx.shapes
         eng.notify_grads_ready('begin')          # e.g. the DP exchange drains whatever is still in flight on the arena
         a.begin_backward()
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
@@ -69,8 +80,16 @@ class _HotPathFunction(torch.autograd.Function):
         if d_logits is not None:
             dl = torch.zeros(B * T, eng.dec.Vp, dtype=BF16, device=a.device)
             dl[:, :eng.dec.V] = d_logits.reshape(B * T, -1)
-        dh = None if d_hid is None else d_hid.reshape(B * T, -1).to(F32)
-        eng.decode_backward(ctx.dctx, dl, dh, dmem)
+        dh = dph = None
+        if d_hid is not None:
+            d_hid = d_hid.to(F32)
+            dh = d_hid[:, n_p:].reshape(B * T, -1).contiguous()
+            dph = d_hid[:, :n_p].reshape(B * n_p, -1).contiguous() if ctx.pctx is not None else None
+        if dph is not None:                       # the prompt rows of hidden_state carry gradient: both segments, one normaliser
+            _, dxp = eng.decode_backward_pair(ctx.dctx, dl, dh, ctx.pctx, None, dph, dmem)
+            dmem.view(B, ncls, -1)[:, :n_p].add_(dxp.view(B, n_p, -1))
+        else:
+            eng.decode_backward(ctx.dctx, dl, dh, dmem)
         eng.notify_grads_ready('decoder')
         if d_enc is not None:
             dmem += d_enc.reshape(B * ncls, -1)
@@ -81,7 +100,7 @@ class _HotPathFunction(torch.autograd.Function):
             eng.encode_backward(ctx.enc_ctx, dmem)
             eng.notify_grads_ready('encoder')
         a.attach_grads()
-        ctx.enc_ctx = ctx.dctx = None
+        ctx.enc_ctx = ctx.dctx = ctx.pctx = None
         return None, None, None, None, d_enc_in, None
 
 
@@ -158,24 +177,19 @@ class VisionEncoderDecoder(nn.Module):
         self._check_mask(attn_msk, ids.shape[0], ids.shape[-1])
         save = torch.is_grad_enabled()
         enc_out, logits, hid = _HotPathFunction.apply(self._grad_hook(dev), self, images, ids, encoder_output, save)
-        if self.use_soft_prompting:
-            # hidden_state of the reference also carries the prompt rows (it is not sliced, :133).  They form an
-            # independent causal segment (text never attends to them); computed without autograd.
+        if self.use_soft_prompting and not self._engine.dec.causal:
+            # a NON-causal decoder: the prompt rows see every column, text included (:93-95), so they need the whole sequence in one
+            # pass; text rows still never see the prompt (split visibility of the grouped kernels).  Forward only: these rows carry
+            # no gradient.
             with torch.no_grad():
                 eng = self._engine
                 B, ncls = enc_out.shape[0], enc_out.shape[1]
                 n_p = min(ncls, eng.dec.block)
                 mem = eng._mem_bf16(enc_out) if self.use_cross_attn else None
-                if eng.dec.causal:
-                    ph, _, _ = eng.decode_segment(B, n_p, mem, ncls, False, embeds=enc_out[:, :n_p].reshape(B * n_p, -1), pos_offset=0)
-                else:
-                    # a NON-causal decoder: the prompt rows see every column, text included (:93-95), so they need the whole
-                    # sequence in one pass; text rows still never see the prompt (split visibility of the grouped kernels)
-                    Tt = hid.shape[1]
-                    emb = torch.cat((enc_out[:, :n_p], self.decoder.get_inputs_embeds(ids[:, :Tt])), dim=1)
-                    full, _, _ = eng.decode_segment(B, n_p + Tt, mem, ncls, False, embeds=emb.reshape(B * (n_p + Tt), -1), pos_offset=0,
-                                                    split=n_p)
-                    ph = full.view(B, n_p + Tt, -1)[:, :n_p]
+                Tt = hid.shape[1]
+                emb = torch.cat((enc_out[:, :n_p], self.decoder.get_inputs_embeds(ids[:, :Tt])), dim=1)
+                full, _, _ = eng.decode_segment(B, n_p + Tt, mem, ncls, False, embeds=emb.reshape(B * (n_p + Tt), -1), pos_offset=0, split=n_p)
+                ph = full.view(B, n_p + Tt, -1)[:, :n_p]
             hid = torch.cat((ph.reshape(B, n_p, -1), hid), dim=1)
         return VisionEncoderDecoderModelOutput(encoder_output=enc_out, logits=logits, hidden_state=hid)
 
