@@ -61,11 +61,14 @@ class GreedyDecoder:
         off = ncls if cfg.use_soft_prompting else 0
         tmax = dc.block - off
         d, ff = dc.d, dc.ff
-        st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a, sparse_epoch=eng.sparse_epoch)
+        # Hugging Face decoder + soft prompt (engine.decode_prefixed): the encoder outputs are the first cache positions of every caption
+        prefix = min(ncls, dc.block) if dc.prefixed else 0
+        st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a, sparse_epoch=eng.sparse_epoch, prefix=prefix,
+                             clen=tmax + prefix)
         e = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=dev)
         st.ids = torch.zeros(B, ids_ld, dtype=torch.long, device=dev)
         st.counters = torch.zeros(2, dtype=torch.int32, device=dev)        # [pos, len]
-        st.counters_init = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+        st.counters_init = torch.tensor([prefix, 1], dtype=torch.int32, device=dev)
         st.x = e(B, d, dtype=F32)
         st.ln = e(B, d)
         st.qkv = e(B, 3 * d)
@@ -76,14 +79,14 @@ class GreedyDecoder:
         st.logits = e(B, dc.Vp, dtype=F32)                      # rows padded to 8 columns: 16-byte aligned rows for the GEMM epilogue
         st.margin = e(B, dtype=F32)
         if dc.fam is None:
-            st.kc = [e(B, tmax, d) for _ in range(dc.L)]
-            st.vc = [e(B, tmax, d) for _ in range(dc.L)]
+            st.kc = [e(B, st.clen, d) for _ in range(dc.L)]
+            st.vc = [e(B, st.clen, d) for _ in range(dc.L)]
         S = ncls
         st.cross_kv = {l: (e(B, S, 2 * d), S) for l in self._cross_layers()}
         if dc.fam is not None:
             self._build_family(st, e)
         if dc.advpos:
-            st.pos_h = [e(B, g) for g in (self.model.config.decoder_config.advanced_pos_emb_gate_sizes or ())]
+            st.pos_h = [e(B, g) for g in (self.eng.dcfg.advanced_pos_emb_gate_sizes or ())]
         st.ngrams = torch.tensor(list(cfg.no_repeat_n_grams), dtype=torch.int32, device=dev)
         st.graphs = {}                      # None -> prefill step, 'greedy' / Sampling.key() -> full step
         st.seed = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -185,7 +188,7 @@ class GreedyDecoder:
     def _cross_layers(self):
         cfg = self.model.config
         return [l for l in range(self.eng.dec.L)
-                if cfg.use_cross_attn and (self.eng.dec_cross[l] or not cfg.decoder_config.skip_alternate_cross_attn)]
+                if self.eng.cross_inputs and (self.eng.dec_cross[l] or not self.eng.dcfg.skip_alternate_cross_attn)]
 
     # ------------------------------------------------------------------------------------------------ one token
     def _step(self, st, with_head: bool, sampling: Optional[Sampling] = None):
@@ -232,8 +235,8 @@ class GreedyDecoder:
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
-            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.tmax * d, 64, st.ao, d, pos_ptr, 0, B, H, append_dm=d,
-                                 cache_hs=st.tmax * 64)           # head-major self-attention cache [B][H][tmax][64]
+            ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.clen * d, 64, st.ao, d, pos_ptr, 0, B, H, append_dm=d,
+                                 cache_hs=st.clen * 64)           # head-major self-attention cache [B][H][prefix + tmax][64]
             ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
             if l in st.cross_kv:
                 kv, S = st.cross_kv[l]
@@ -298,6 +301,15 @@ class GreedyDecoder:
                 p = f'{eng.dp}transformer.h.{l}.cross_attn'
                 ops.gemm(mem, a.W(f'{p}.in_proj_weight')[dc.d:], kv.view(B * S, 2 * dc.d), B * S, 2 * dc.d, dc.d,
                          bias=a.P(f'{p}.in_proj_bias')[dc.d:])
+        if st.prefix:       # the prompt rows' keys and values (one causal pass over the encoder outputs) open every caption's cache
+            n_p = st.prefix
+            _, _, pctx = eng.decode_segment(B, n_p, eng._mem_bf16(enc_out) if eng.cross_inputs else None, S, True,
+                                            embeds=enc_out[:, :n_p].reshape(B * n_p, dc.d), pos_offset=0)
+            for l in range(dc.L):
+                qkv = pctx.saves[l].qkv.view(B, n_p, 3, dc.H, 64)
+                st.kc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 1].transpose(1, 2))
+                st.vc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 2].transpose(1, 2))
+            del pctx
         if dc.fam is not None and dc.fam.moe is not None:       # the packed expert output weights follow the current parameters
             for l in range(dc.L):
                 for part in ('c_fc', 'c_proj'):
@@ -358,7 +370,7 @@ def generate_by_recompute(model, images, prompt_ids: torch.Tensor, max_new_token
     total = P + max_new_tokens
     enc_out, _ = eng.encode(images, False)
     ncls = enc_out.shape[1]
-    mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
+    mem = eng._mem_bf16(enc_out) if eng.cross_inputs else None
     off = ncls if cfg.use_soft_prompting else 0
     blk = dc.block - off
     ids = torch.zeros(B, total, dtype=torch.long, device=dev)

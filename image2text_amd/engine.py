@@ -212,6 +212,12 @@ class ParamArena:
                 p.grad = self.G(name)
 
 
+def decoder_hot_config(model):
+    """The TransformerDecoderConfig the decoder's arithmetic follows: the model config's own, or the one a GPT2HuggingfaceDecoder
+    derived from its checkpoint (models/decoder.py)."""
+    return getattr(model.decoder, 'hot_config', None) or model.config.decoder_config
+
+
 class HotPath(FamilyBlocks):
     """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
 
@@ -219,7 +225,11 @@ class HotPath(FamilyBlocks):
         self.model = model
         self.cfg = model.config
         self.arena: Optional[ParamArena] = None
-        ecfg, dcfg = self.cfg.vision_encoder_config, self.cfg.decoder_config
+        ecfg, dcfg = self.cfg.vision_encoder_config, decoder_hot_config(model)
+        self.dcfg = dcfg
+        # the encoder output reaches the decoder's cross-attention: the model asks for it and -- Hugging Face decoders only, which
+        # drop the input otherwise (reference decoder.py:341-361) -- the decoder has the layers
+        self.cross_inputs = bool(self.cfg.use_cross_attn) and getattr(model.decoder, 'use_cross_attn', True)
         self.has_bridge = model.has_bridge
         self.ep = 'encoder.0.' if self.has_bridge else 'encoder.'
         self.dp = 'decoder.'
@@ -239,6 +249,8 @@ class HotPath(FamilyBlocks):
         self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer, force=not dcfg.transformer_config.is_causal)
         self._sparse_idx, self._sparse_versions, self.sparse_epoch = {'enc': None, 'dec': None}, None, 0
         self._refresh_sparse_sets()
+        self.dec.grad_norm = not hasattr(model.decoder, 'hot_config')     # layers.py:606-607; transformers' GPT-2 block has none
+        self.dec.prefixed = hasattr(model.decoder, 'hot_config') and bool(self.cfg.use_soft_prompting)     # see decode_prefixed
         self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
         self._moe_cache, self._sub_cache = {}, {}
         self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
@@ -531,11 +543,22 @@ class HotPath(FamilyBlocks):
         ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx_full.view(M, d), a.G(f'{pfx}.ln_1.weight'),
                           a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, sumsq_out=self._ws[1:2])
 
-    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None, presummed_slot=None):
+    def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None, presummed_slot=None,
+                    normalize: bool = True):
         """presummed_slot: index into self._ws that already holds sum(dx^2) of the incoming gradient (None: reduce it here).
-        Inside the loop every block's last LayerNorm backward leaves that sum for the block below (two alternating floats)."""
+        Inside the loop every block's last LayerNorm backward leaves that sum for the block below (two alternating floats).
+        normalize=False (Hugging Face GPT-2 blocks have no normalize_gradients): the same launches with the 'sum' pinned to the
+        value whose normaliser 1 / (sqrt(s) + 1e-6) is 1."""
         dxb = self._empty(dx.shape[0], d, dtype=BF16)
         slot, presummed = (presummed_slot, True) if presummed_slot is not None else (0, False)
+        if not normalize:
+            if getattr(self, '_unit_sq', None) is None or self._unit_sq.device != dx.device:
+                self._unit_sq = torch.full((1,), (1.0 - 1e-6) ** 2, dtype=F32, device=dx.device)
+            for l in reversed(range(len(saves))):
+                ops.grad_normalize(dx, self._unit_sq, dxb, bf16_drop=saves[l].dr['mlp'], presummed=True, keep_f32=True)
+                self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
+                               vl=vl, dx_pre=self._unit_sq)
+            return
         for l in reversed(range(len(saves))):
             cur, nxt = self._ws[slot:slot + 1], self._ws[1 - slot:2 - slot]
             # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
@@ -723,7 +746,7 @@ class HotPath(FamilyBlocks):
                 ops.dropout_apply(x, M, d, emb_drop)
         saves, cur, perm = [], x, None
         for l in range(dc.L):
-            m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.cfg.decoder_config.skip_alternate_cross_attn)) else None
+            m = mem_bf if (mem_bf is not None and (self.dec_cross[l] or not self.dcfg.skip_alternate_cross_attn)) else None
             if dc.fam is not None:
                 cur, sv, perm = self.fam_layer_fwd(f'{self.dp}transformer.h.{l}', dc.fam, cur, perm, B, T, m, S, save, plan, l, vl,
                                                    self.sparse_subset('dec', l, B, T, pos_offset, vl), split)
@@ -738,6 +761,47 @@ class HotPath(FamilyBlocks):
         ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, mf=mf, rf=rf, hb=hb, B=B, T=T, S=S, pos_offset=pos_offset, vl=vl, M=M,
                               emb_drop=emb_drop, pos_ctx=pos_ctx) if save else None
         return hid, hb, ctx
+
+    # ---- Hugging Face decoders with a soft prompt: ONE causal sequence [encoder outputs | text] (the reference passes no mask to
+    # transformers, decoder.py:349-361: text rows see the prompt rows, prompt rows see their predecessors) instead of the two
+    # independent segments the nanoGPT decoder's mask leaves (vision_encoder_decoder.py:84-113)
+    def decode_prefixed(self, B: int, T: int, enc_out, mem_bf, save: bool, ids, dropout_without_save: bool = False):
+        """ids [B, T] after the n_p = min(n_cls, block) encoder outputs.  Returns (hidden fp32 [B, n_p + T, d], bf16 hidden of the
+        text rows [B * T, d], ctx)."""
+        a, dc = self.arena, self.dec
+        ncls = enc_out.shape[1]
+        n_p = min(ncls, dc.block)
+        T = min(T, dc.block - n_p)
+        ids = ids[:, :T].to(device=a.device, dtype=torch.long).contiguous()
+        emb = self._empty(B, n_p + T, dc.d)
+        emb[:, :n_p].copy_(enc_out[:, :n_p])
+        if T:
+            tok = self._empty(B * T, dc.d)
+            ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), None, tok, B, T, dc.d, 0, dc.V)
+            emb[:, n_p:].copy_(tok.view(B, T, dc.d))
+        hid, hb, ctx = self.decode_segment(B, n_p + T, mem_bf, ncls, save, embeds=emb.view(B * (n_p + T), dc.d), pos_offset=0,
+                                           dropout_without_save=dropout_without_save)
+        hb_text = hb.view(B, n_p + T, dc.d)[:, n_p:].contiguous().view(B * T, dc.d)
+        if ctx is not None:
+            ctx.prefixed = SimpleNamespace(ids=ids, n_p=n_p, T=T, hb_text=hb_text)
+        return hid.view(B, n_p + T, dc.d), hb_text, ctx
+
+    def decode_prefixed_backward(self, ctx, dlogits_bf, dhid, dmem):
+        """dlogits_bf: bf16 [B * T, Vp] over the TEXT rows or None; dhid: fp32 [B, n_p + T, d] or None.  The prompt rows' input
+        gradient is added to dmem (they ARE the encoder outputs), the text rows' is scattered into wte."""
+        a, dc, px = self.arena, self.dec, ctx.prefixed
+        B, n_p, T, d = ctx.B, px.n_p, px.T, dc.d
+        wte = f'{self.dp}transformer.wte.weight'
+        dh = torch.zeros(B, n_p + T, d, dtype=F32, device=a.device) if dhid is None else dhid.to(F32).reshape(B, n_p + T, d).clone()
+        if dlogits_bf is not None and T:
+            ops.gemm(dlogits_bf, px.hb_text, a.G(wte), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # tied lm_head
+            dht = self._empty(B * T, d)
+            ops.gemm(dlogits_bf, a.W(wte), dht, B * T, d, dc.V, b_kmajor=True)
+            dh[:, n_p:] += dht.view(B, T, d)
+        dx = self.decode_backward(ctx, None, dh.view(B * (n_p + T), d), dmem).view(B, n_p + T, d)
+        dmem.view(B, -1, d)[:, :n_p] += dx[:, :n_p]
+        if T:
+            ops.embed_bwd(px.ids, dx[:, n_p:].contiguous().view(B * T, d), a.G(wte), None, B, T, d, 0, dc.V)
 
     def logits_f32(self, hb: torch.Tensor, M: int):
         out = self._empty(M, self.dec.V)
@@ -812,6 +876,8 @@ class HotPath(FamilyBlocks):
                 dx, dperm = yield from self.fam_layer_bwd_steps(l, f'{self.dp}transformer.h.{l}', dc.fam, ctx.saves[l], dx, dperm, B, T, ctx.S,
                                                                 dmem, ctx.vl)
             dx = self.materialize(dx, dperm)
+        elif not dc.grad_norm:
+            self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl, normalize=False)
         elif paired:        # the un-fused form of _blocks_bwd: the normaliser's sum comes from outside
             dxb = self._empty(M, d, dtype=BF16)
             for l in reversed(range(dc.L)):

@@ -4,7 +4,10 @@
 nanoGPT decoder is what the HIP hot path runs -- freshly initialised (``pretrained_model: null``) or carrying imported GPT-2
 weights (``pretrained_model: gpt2 | gpt2-medium | gpt2-large | gpt2-xl``: the same module, the weights are read from the local
 Hugging Face cache through ``GPT2LMHeadModel.from_pretrained``; there is no network in the build image, so an absent cache
-surfaces as transformers' own error).  The Hugging Face decoder family (other architectures, 4-bit, LoRA) is refused loudly.
+surfaces as transformers' own error).  ``HuggingfaceDecoderConfig`` with ``model_str: gpt2*`` (reference decoder.py:285-382,
+``GPT2HuggingfaceDecoder``) is the same arithmetic again -- Hugging Face's GPT-2 block, cross-attention included, IS the nanoGPT
+block -- so it runs on the HIP path too and keeps Hugging Face's parameter names and Conv1D layout in its state dict.  The other
+architectures of the family (Falcon / Llama-2 / Qwen2), 4-bit loading and LoRA are refused loudly.
 """
 import abc
 from typing import Optional, Tuple, Union
@@ -12,7 +15,8 @@ from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from ..configs.models import HuggingfaceDecoderConfig, MLPConfig, ModelType, TransformerDecoderConfig
+from ..configs.models import (HuggingfaceDecoderConfig, MLPConfig, ModelType, SelfAttentionConfig, SelfAttentionType,
+                              TransformerConfig, TransformerDecoderConfig)
 from .layers import AdvancedPositionalBiasMLP, LayerNorm, TransformerBlock, init_gpt_weights_
 from .utils import mutate_transformer_config
 
@@ -28,8 +32,12 @@ class Decoder(nn.Module, abc.ABC):
                 return cls._from_pretrained_gpt2(config, loose, space_for_prompt)
             return TransformerDecoder(config, space_for_prompt)
         if isinstance(config, HuggingfaceDecoderConfig):
-            raise NotImplementedError('HuggingfaceDecoder family (AutoModelForCausalLM.from_pretrained, 4-bit, LoRA) is '
-                                      'outside the HIP hot path (SURVEY.md 8(f) next #3)')
+            if config.lora_spec is not None:
+                raise NotImplementedError('LoRA adapters (peft) are outside the HIP hot path (SURVEY.md 8(f) next #3)')
+            if config.model_str.startswith('gpt2'):                    # reference decoder.py:120-121
+                return GPT2HuggingfaceDecoder(config, space_for_prompt)
+            raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: only the GPT-2 members of the family run on the HIP '
+                                      'hot path (Falcon / Llama-2 / Qwen2 blocks: SURVEY.md 8(f) next #3)')
         raise ValueError('Unknown config type!!!')
 
     @staticmethod
@@ -143,3 +151,114 @@ class TransformerDecoder(Decoder):
     @property
     def n_embd(self):
         return self.config.transformer_config.attn_config.n_embd
+
+
+class GPT2HuggingfaceDecoder(TransformerDecoder):
+    """``HuggingfaceDecoderConfig(model_str='gpt2*')`` (reference decoder.py:285-382): the checkpoint is loaded through
+    ``AutoModelForCausalLM.from_pretrained`` exactly as the reference does (cross-attention layers requested through
+    ``add_cross_attention`` and freshly initialised by transformers, embeddings resized to ``vocab_size + extra_tokens``), its weights
+    move into the hot path's own decoder (Hugging Face's GPT-2 block -- ln_1/attn, ln_cross_attn/crossattention, ln_2/mlp, tanh
+    GELU, eps 1e-5 -- is the nanoGPT block with other names) and the transformers module is dropped.
+
+    The state dict keeps the reference's names and layout (``backbone.transformer.h.N.attn.c_attn.weight`` as Conv1D ``[in, out]``,
+    ``crossattention.q_attn`` / ``c_attn`` / ``c_proj``, ``ln_cross_attn``, ``backbone.lm_head.weight``), so checkpoints travel in both
+    directions.  As in the reference the attention mask is ignored (always causal, decoder.py:349-350), ``block_size`` is the
+    checkpoint's 1024 positions and the decoder's dropout rates are the checkpoint's (``resid_pdrop`` for residual and embedding dropout, ``attn_pdrop``)."""
+
+    _CONV1D = ('attn.c_attn.weight', 'attn.c_proj.weight', 'mlp.c_fc.weight', 'mlp.c_proj.weight')
+
+    def __init__(self, config: HuggingfaceDecoderConfig, space_for_prompt: int = 0):
+        assert config.model_str.startswith('gpt2')
+        if config.load_in_4bit or config.prepare_for_kbit_training:
+            raise NotImplementedError('4-bit loading / k-bit training (bitsandbytes) is outside the HIP hot path')
+        from transformers import AutoConfig, AutoModelForCausalLM
+        kwargs = {}
+        if config.use_cross_attn:
+            hf_config = AutoConfig.from_pretrained(config.model_str)
+            if not hasattr(hf_config, 'add_cross_attention'):
+                raise ValueError("Don't know how to use cross attention with this model. Suggest you try a different config!!!")
+            hf_config.add_cross_attention = True
+            kwargs['config'] = hf_config
+        hf = AutoModelForCausalLM.from_pretrained(config.model_str, **kwargs)
+        hc = hf.config
+        hf.resize_token_embeddings(config.vocab_size + config.extra_tokens)
+        problems = [msg for bad, msg in (
+            (hc.model_type != 'gpt2', f'model_type {hc.model_type!r}'),
+            (hc.activation_function not in ('gelu_new', 'gelu_pytorch_tanh'), f'activation {hc.activation_function!r}'),
+            (abs(hc.layer_norm_epsilon - 1e-5) > 1e-12, f'layer_norm_epsilon {hc.layer_norm_epsilon}'),
+            (not hc.scale_attn_weights or hc.scale_attn_by_inverse_layer_idx, 'attention scaling other than 1/sqrt(head_dim)'),
+            (abs(hc.embd_pdrop - hc.resid_pdrop) > 1e-12, 'embd_pdrop != resid_pdrop'),
+        ) if bad]
+        if problems:
+            raise NotImplementedError('GPT-2 checkpoint outside the HIP hot path: ' + '; '.join(problems))
+        n_inner = hc.n_inner if hc.n_inner is not None else 4 * hc.n_embd
+        hot = TransformerDecoderConfig(
+            vocab_size=config.vocab_size + config.extra_tokens, n_layer=hc.n_layer, block_size=hc.n_positions,
+            enable_gradient_checkpointing=config.enable_gradient_checkpointing,
+            transformer_config=TransformerConfig(
+                rotator_config=MLPConfig(ff_mult=n_inner / hc.n_embd), is_causal=True, is_cross_attn=bool(config.use_cross_attn),
+                attn_config=SelfAttentionConfig(n_head=hc.n_head, n_embd=hc.n_embd, bias=True, dropout=hc.resid_pdrop,
+                                                attn_dropout=hc.attn_pdrop, attn_type=SelfAttentionType.MULTI_HEAD)),
+            skip_alternate_cross_attn=False)
+        super().__init__(hot, space_for_prompt)
+        self.hot_config = hot               # what the HIP engine reads in place of VisionEncoderDecoderConfig.decoder_config
+        self.config = config
+        self.hf_config = hc
+        self.use_cross_attn = config.use_cross_attn
+        self._register_state_dict_hook(self._to_hf_keys)
+        self._register_load_state_dict_pre_hook(self._from_hf_keys)
+        self.load_state_dict({'backbone.' + k: v for k, v in hf.state_dict().items()
+                              if not (k.endswith('.attn.masked_bias') or k.endswith('.attn.bias')
+                                      or k.endswith('.crossattention.masked_bias') or k.endswith('.crossattention.bias'))})
+        self.tie_weights()
+
+    # -- state dict in Hugging Face's names and layout -----------------------------------------------------------------------
+    @classmethod
+    def _to_hf_keys(cls, module, sd, prefix, local_metadata):
+        d = module.hot_config.transformer_config.attn_config.n_embd
+        for k in [k for k in sd if k.startswith(prefix)]:
+            v, name = sd.pop(k), k[len(prefix):]
+            if name.endswith(cls._CONV1D):
+                sd[prefix + 'backbone.' + name] = v.t()
+            elif '.cross_attn.' in name:
+                base = prefix + 'backbone.' + name.split('.cross_attn.')[0] + '.crossattention.'
+                leaf = name.split('.cross_attn.')[1]
+                if leaf == 'in_proj_weight':
+                    sd[base + 'q_attn.weight'], sd[base + 'c_attn.weight'] = v[:d].t(), v[d:].t()
+                elif leaf == 'in_proj_bias':
+                    sd[base + 'q_attn.bias'], sd[base + 'c_attn.bias'] = v[:d], v[d:]
+                else:                                                               # out_proj.weight / out_proj.bias
+                    sd[base + 'c_proj.' + leaf.split('.')[1]] = v.t() if leaf.endswith('weight') else v
+            else:
+                sd[prefix + 'backbone.' + name.replace('.ln_3.', '.ln_cross_attn.')] = v
+        return sd
+
+    def _from_hf_keys(self, sd, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        bb = prefix + 'backbone.'
+        cross = {}
+        for k in [k for k in sd if k.startswith(bb)]:
+            v, name = sd.pop(k), k[len(bb):]
+            if name.endswith(self._CONV1D):
+                sd[prefix + name] = v.t()
+            elif '.crossattention.' in name:
+                cross.setdefault(name.split('.crossattention.')[0], {})[name.split('.crossattention.')[1]] = v
+            else:
+                sd[prefix + name.replace('.ln_cross_attn.', '.ln_3.')] = v
+        for blk, parts in cross.items():
+            base = prefix + blk + '.cross_attn.'
+            if 'q_attn.weight' in parts and 'c_attn.weight' in parts:
+                sd[base + 'in_proj_weight'] = torch.cat([parts['q_attn.weight'].t(), parts['c_attn.weight'].t()], 0)
+            if 'q_attn.bias' in parts and 'c_attn.bias' in parts:
+                sd[base + 'in_proj_bias'] = torch.cat([parts['q_attn.bias'], parts['c_attn.bias']], 0)
+            if 'c_proj.weight' in parts:
+                sd[base + 'out_proj.weight'] = parts['c_proj.weight'].t()
+            if 'c_proj.bias' in parts:
+                sd[base + 'out_proj.bias'] = parts['c_proj.bias']
+
+    @property
+    def block_size(self):
+        return self.hf_config.n_positions               # 1024 for every GPT-2 checkpoint (reference decoder.py:377-378 hard-codes it)
+
+    @property
+    def n_embd(self):
+        return self.hf_config.n_embd

@@ -47,9 +47,15 @@ class _HotPathFunction(torch.autograd.Function):
         else:
             enc_out = enc_in.to(device=eng.arena.device, dtype=F32).contiguous()
         ncls = enc_out.shape[1]
-        mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
+        mem = eng._mem_bf16(enc_out) if eng.cross_inputs else None
         off = ncls if cfg.use_soft_prompting else 0
         T = min(L, eng.dec.block - off)                       # the reference crops inputs to block_size (:88)
+        if eng.dec.prefixed:      # Hugging Face decoder + soft prompt: one causal sequence [encoder outputs | text] (engine.decode_prefixed)
+            hid, hb, dctx = eng.decode_prefixed(B, T, enc_out, mem, save, ids)
+            ctx.set_materialize_grads(False)
+            ctx.model, ctx.enc_ctx, ctx.dctx, ctx.has_enc_in = model, enc_ctx, dctx, enc_in is not None
+            ctx.pctx, ctx.shapes = None, (B, T, ncls, hid.shape[1] - T)
+            return enc_out, eng.logits_f32(hb, B * T).view(B, T, -1), hid
         hid, hb, dctx = eng.decode_segment(B, T, mem, ncls, save, ids=ids[:, :T], pos_offset=off)
         logits = eng.logits_f32(hb, B * T).view(B, T, -1)
         hid = hid.view(B, T, -1)
@@ -81,11 +87,16 @@ class _HotPathFunction(torch.autograd.Function):
             dl = torch.zeros(B * T, eng.dec.Vp, dtype=BF16, device=a.device)
             dl[:, :eng.dec.V] = d_logits.reshape(B * T, -1)
         dh = dph = None
-        if d_hid is not None:
+        if eng.dec.prefixed:
+            eng.decode_prefixed_backward(ctx.dctx, dl, d_hid, dmem)
+            d_hid = None
+        elif d_hid is not None:
             d_hid = d_hid.to(F32)
             dh = d_hid[:, n_p:].reshape(B * T, -1).contiguous()
             dph = d_hid[:, :n_p].reshape(B * n_p, -1).contiguous() if ctx.pctx is not None else None
-        if dph is not None:                       # the prompt rows of hidden_state carry gradient: both segments, one normaliser
+        if eng.dec.prefixed:
+            pass
+        elif dph is not None:                     # the prompt rows of hidden_state carry gradient: both segments, one normaliser
             _, dxp = eng.decode_backward_pair(ctx.dctx, dl, dh, ctx.pctx, None, dph, dmem)
             dmem.view(B, ncls, -1)[:, :n_p].add_(dxp.view(B, n_p, -1))
         else:
@@ -185,7 +196,7 @@ class VisionEncoderDecoder(nn.Module):
                 eng = self._engine
                 B, ncls = enc_out.shape[0], enc_out.shape[1]
                 n_p = min(ncls, eng.dec.block)
-                mem = eng._mem_bf16(enc_out) if self.use_cross_attn else None
+                mem = eng._mem_bf16(enc_out) if eng.cross_inputs else None
                 Tt = hid.shape[1]
                 emb = torch.cat((enc_out[:, :n_p], self.decoder.get_inputs_embeds(ids[:, :Tt])), dim=1)
                 full, _, _ = eng.decode_segment(B, n_p + Tt, mem, ncls, False, embeds=emb.reshape(B * (n_p + Tt), -1), pos_offset=0, split=n_p)
@@ -238,6 +249,9 @@ def run_decoder_standalone(decoder, idx, inputs_embeds, cross_attn_embeds, attn_
     owner = _owner_of(decoder)
     assert not (idx is None and inputs_embeds is None)
     assert idx is None or inputs_embeds is None
+    if hasattr(decoder, 'hot_config'):       # Hugging Face decoders: always causal, cross inputs dropped without the layers (decoder.py:341-361)
+        attn_msk = None
+        cross_attn_embeds = cross_attn_embeds if decoder.use_cross_attn else None
     if attn_msk is not None:
         raise NotImplementedError('TransformerDecoder.forward with an explicit additive mask is not supported by the HIP kernels')
     eng: HotPath = owner._engine

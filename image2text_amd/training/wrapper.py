@@ -35,9 +35,20 @@ class _LMLossFunction(torch.autograd.Function):
         B, L = ids.shape
         enc_out, enc_ctx = eng.encode(images, save)
         ncls = enc_out.shape[1]
-        mem = eng._mem_bf16(enc_out) if cfg.use_cross_attn else None
+        mem = eng._mem_bf16(enc_out) if eng.cross_inputs else None
         off = ncls if cfg.use_soft_prompting else 0
         T = min(L, eng.dec.block - off)
+        if eng.dec.prefixed:       # Hugging Face decoder + soft prompt: one causal sequence [encoder outputs | text] (engine.decode_prefixed)
+            M = B * T
+            lab, w = labels[:, :T].contiguous().view(M), weights[:, :T].contiguous().view(M)
+            _, hb, dctx = eng.decode_prefixed(B, T, enc_out, mem, save, ids)
+            logits = eng.logits_bf16(hb, M, capacity=M)
+            lse = torch.empty(M, dtype=F32, device=a.device)
+            loss = torch.zeros(1, dtype=F32, device=a.device)
+            inv_t = 1.0 / wrapper.temperature
+            ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, eng.dec.V)
+            ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, None, None, None) if save else None
+            return loss[0], torch.zeros((), dtype=F32, device=a.device)
         vl = wrapper._pack_rows(labels[:, :T], B, T) if (wrapper.pack_rows and eng.dec.causal) else None      # (dead rows are dead under a causal mask only)
         if vl is not None:      # rows past each caption's last label are dead (causal + zero loss weight): not computed
             M = vl.total
@@ -60,7 +71,7 @@ class _LMLossFunction(torch.autograd.Function):
             em: HotPath = wrapper.model_m._engine
             em.prepare(model.training)
             enc_m, _ = em.encode(images, False)
-            mem_m = em._mem_bf16(enc_m) if cfg.use_cross_attn else None
+            mem_m = em._mem_bf16(enc_m) if em.cross_inputs else None
             _, hb_m, _ = em.decode_segment(B, T, mem_m, ncls, False, ids=ids_p, pos_offset=off, vl=vl, dropout_without_save=model.training)
             teacher = em.logits_bf16(hb_m, M, capacity=B * T)
             lse_t = torch.empty(M, dtype=F32, device=a.device)
@@ -91,7 +102,9 @@ class _LMLossFunction(torch.autograd.Function):
         else:
             ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, M, eng.dec.V)
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)
-        if con is not None and g_c is not None:
+        if eng.dec.prefixed:
+            eng.decode_prefixed_backward(dctx, logits, None, dmem)
+        elif con is not None and g_c is not None:
             dhid, dph = _contrastive_backward(wrapper, eng, con, g_c, M)
             if con.pctx is not None:      # text rows and prompt rows are ONE sequence to the blocks' gradient normalisers: lock step
                 _, dxp = eng.decode_backward_pair(dctx, logits, dhid, con.pctx, None, dph, dmem)
@@ -215,10 +228,13 @@ class ModelTrainerWrapper(nn.Module):
         tc = trainer_config
         self.add_contrastive_loss = tc.add_contrastive_loss
         self.contrastive_temperature = tc.training_contrastive_temperature
-        if tc.add_contrastive_loss and model_config.use_soft_prompting and not model_config.decoder_config.transformer_config.is_causal:
+        self.model = VisionEncoderDecoder(config=model_config)
+        if self.model._engine.dec.prefixed and (tc.add_contrastive_loss or (tc.moco_momentum is not None and tc.moco_alpha is not None)):
+            raise NotImplementedError('contrastive loss / momentum distillation with a Hugging Face decoder and a soft prompt are outside '
+                                      'the HIP hot path (one causal sequence [encoder outputs | text]: engine.decode_prefixed)')
+        if tc.add_contrastive_loss and model_config.use_soft_prompting and not self.model._engine.dec.causal:
             raise NotImplementedError('contrastive loss with a non-causal decoder and a soft prompt: the prompt rows then attend to the '
                                       'text rows, which the two-segment backward does not cover')
-        self.model = VisionEncoderDecoder(config=model_config)
         self.is_momentum = tc.moco_momentum is not None and tc.moco_alpha is not None
         self.model_m = VisionEncoderDecoder(config=model_config) if self.is_momentum else None
         self.tokenizer = tokenizer

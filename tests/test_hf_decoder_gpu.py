@@ -1,0 +1,220 @@
+"""GPT2HuggingfaceDecoder on the MI355X (reference models/decoder.py:285-382): the plugin loads a Hugging Face
+GPT-2 checkpoint from a local directory and runs it on the HIP hot path.  The checker is what the reference itself calls for this
+decoder -- transformers' GPT2LMHeadModel, evaluated on the CPU in fp32 -- composed with the CPU oracle's encoder exactly as
+vision_encoder_decoder.py:84-134 composes them (soft prompt = encoder outputs concatenated in front of the token embeddings, NO mask
+handed to transformers: one causal sequence; cross-attention on the encoder outputs when the decoder has the layers)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from image2text_amd.synth import det_init_, fake_tokenizer, synthetic_batch, tiny_config
+from test_host_cpu import _hf_decoder_config, _local_hf_gpt2
+from test_model_gpu import grad_close
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def write_report():
+    yield
+    import json
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_report_hf_decoder.json', 'w') as fh:
+        json.dump(REPORT, fh, indent=1, sort_keys=True)
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def _model_config(cross: bool, soft: bool, **hf_kw):
+    cfg = tiny_config(dec_d=128, dec_heads=2, dec_layers=2, block_size=64)
+    return cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(use_cross_attn=cross, **hf_kw), use_cross_attn=cross or not soft,
+                                      use_soft_prompting=soft))
+
+
+def _hf_twin(model, cross: bool):
+    """a transformers GPT-2 holding the plugin's weights (through the plugin's own Hugging Face-keyed state dict)"""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    hc = model.decoder.hf_config
+    hf = GPT2LMHeadModel(GPT2Config(n_layer=hc.n_layer, n_head=hc.n_head, n_embd=hc.n_embd, n_positions=hc.n_positions,
+                                    vocab_size=model._engine.dec.V, add_cross_attention=cross, resid_pdrop=0.0, embd_pdrop=0.0,
+                                    attn_pdrop=0.0)).eval()
+    hf.load_state_dict({k[len('backbone.'):]: v.detach().cpu().clone() for k, v in model.decoder.state_dict().items()}, strict=True)
+    return hf
+
+
+def _reference_forward(orc, osd, hf, cfg, images, ids, cross: bool, soft: bool):
+    """vision_encoder_decoder.py:74-134 with a HuggingfaceDecoder: (encoder_output, text logits, hidden_state)"""
+    enc = orc.encode(osd, cfg, images, training=False)
+    mem = enc if (cfg.use_cross_attn and cross) else None
+    if soft:
+        ncls = enc.shape[1]
+        emb = torch.cat((enc, hf.transformer.wte(ids)), dim=-2)[..., :hf.config.n_positions, :]
+        out = hf(inputs_embeds=emb, encoder_hidden_states=mem, output_hidden_states=True)
+        return enc, out.logits[..., ncls:, :], out.hidden_states[-1]
+    out = hf(input_ids=ids, encoder_hidden_states=mem, output_hidden_states=True)
+    return enc, out.logits, out.hidden_states[-1]
+
+
+def _build(tmp_path, monkeypatch, cross, soft, **hf_kw):
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    _local_hf_gpt2(tmp_path, monkeypatch)
+    cfg = _model_config(cross, soft, **hf_kw)
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)                          # deterministic, LayerNorm parameters off their 1 / 0 initialisation (encoder)
+    m.decoder.load_state_dict(keep)               # ... the decoder keeps the checkpoint's weights
+    return cfg, m
+
+
+@pytest.mark.parametrize('cross,soft', [(True, True), (False, True), (True, False)])
+def test_gpt2_hf_decoder_forward_and_gradients(tmp_path, monkeypatch, cross, soft):
+    """forward(): logits, hidden_state (prompt rows included) and encoder_output; then a loss over logits AND hidden_state back-propagated
+    -- every parameter's gradient against autograd through oracle encoder + transformers' GPT-2 (which has no gradient normaliser in
+    its blocks: the hot path's decoder must not apply one here, while the encoder blocks keep theirs)."""
+    from oracle import reference_model as orc
+    tag = f'hf_gpt2.{"cross" if cross else "nocross"}.{"soft" if soft else "ids"}'
+    cfg, m = _build(tmp_path, monkeypatch, cross, soft)
+    hf = _hf_twin(m, cross)
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    m = m.to(dev()).train()                       # the checkpoint's dropout rates are 0: train mode only enables the backward
+    assert m._engine.dec.prefixed == soft and not m._engine.dec.grad_norm
+    images, labels = synthetic_batch(3, 32, 12, 384, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls if soft else 0
+    g = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, 128, generator=g) * 0.05
+    wl = torch.randn(3, 12, 384, generator=g) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    enc, ologits, ohid = _reference_forward(orc, esd, hf, cfg, images, ids, cross, soft)
+    assert tuple(out.hidden_state.shape) == tuple(ohid.shape) == (3, n_p + 12, 128)
+    for name, got, ref, tol in (('logits', out.logits, ologits, 1e-2), ('hidden', out.hidden_state, ohid, 1.5e-2),
+                                ('encoder_output', out.encoder_output, enc, 1e-2)):
+        err, scale = float((got.float().cpu() - ref.detach()).abs().max()), max(1.0, float(ref.abs().max()))
+        REPORT[f'{tag}.{name}'] = {'max_abs_err': err, 'tol': tol * scale}
+        assert err <= tol * scale, (name, err, tol * scale)
+    loss = (out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()
+    loss.backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    # transformers' gradients in the plugin's internal (nn.Linear) layout: through a plugin-shaped container's state-dict hooks
+    from image2text_amd.models.decoder import Decoder
+    shell = Decoder.from_config(cfg.decoder_config)
+    hf_g = {'backbone.' + k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in hf.named_parameters()}
+    hf_g['backbone.lm_head.weight'] = hf_g['backbone.transformer.wte.weight']
+    shell.load_state_dict(hf_g, strict=True)
+    for k, v in shell.named_parameters():
+        ref_grads['decoder.' + k] = v.detach()
+    fails, checked = [], 0
+    for name, p in m.named_parameters():
+        if name not in ref_grads:
+            continue
+        checked += 1
+        try:
+            grad_close(f'{tag}.{name}', p.grad, ref_grads[name].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert checked == len(list(m.named_parameters())), (checked, len(list(m.named_parameters())))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+
+
+@pytest.mark.parametrize('cross,soft', [(True, True), (False, True)])
+def test_gpt2_hf_decoder_train_step_and_generate(tmp_path, monkeypatch, cross, soft):
+    """ModelTrainerWrapper.train_step / val_step (weighted cross-entropy over the text rows) against the same composition, and
+    generate(): the KV cache opened by the prompt rows' keys/values + hipGraph replay == greedy decoding by repeated full forwards"""
+    from oracle import reference_model as orc
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    tag = f'hf_gpt2.step.{"cross" if cross else "nocross"}'
+    _local_hf_gpt2(tmp_path, monkeypatch)
+    cfg = _model_config(cross, soft)
+    tok = fake_tokenizer(384)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    keep = {k: v.detach().clone() for k, v in w.model.decoder.state_dict().items()}
+    det_init_(w.model, seed=0)
+    w.model.decoder.load_state_dict(keep)
+    hf = _hf_twin(w.model, cross)
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in w.model.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    w = w.to(dev()).train()
+    images, labels = synthetic_batch(4, 32, 14, 384, seed=5)
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    ids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
+    _, ologits, _ = _reference_forward(orc, esd, hf, cfg, images, ids, cross, soft)
+    wts = orc.loss_weights(labels, -100)
+    ce = F.cross_entropy(ologits.reshape(-1, ologits.size(-1)), labels.reshape(-1), ignore_index=-100, reduction='none')
+    oloss = (ce * wts.reshape(-1)).sum()
+    oloss.backward()
+    REPORT[f'{tag}.loss'] = {'got': float(loss.detach()), 'ref': float(oloss)}
+    assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * float(oloss)
+    from image2text_amd.models.decoder import Decoder
+    shell = Decoder.from_config(cfg.decoder_config)
+    hf_g = {'backbone.' + k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in hf.named_parameters()}
+    hf_g['backbone.lm_head.weight'] = hf_g['backbone.transformer.wte.weight']
+    shell.load_state_dict(hf_g, strict=True)
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.' + k: v.detach() for k, v in shell.named_parameters()})
+    fails = []
+    for name, p in w.model.named_parameters():
+        try:
+            grad_close(f'{tag}.{name}', p.grad, ref_grads[name].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    w.eval()
+    with torch.no_grad():
+        vloss, _ = w.val_step(images.to(dev()), labels.to(dev()))
+        assert abs(float(vloss) - float(oloss)) <= 1e-2 * float(oloss)
+        # generation: KV cache (prompt rows first) vs the reference's loop of full forwards, on the device
+        prompt = torch.full((4, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = w.model.generate(images.to(dev()), prompt, max_new_tokens=12, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(12):
+            lg = w.model(images=images.to(dev()), ids=cur).logits[:, -1].float().cpu()
+            lg = orc.apply_ngram_ban(cur.cpu(), lg, cfg.no_repeat_n_grams)
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * lg[torch.isfinite(lg)].abs().max().clamp(min=1.0)
+            same_prefix = (gen[:, :cur.shape[1]].cpu() == cur.cpu()).all(dim=1)
+            ok = gen[:, cur.shape[1]].cpu() == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
+        REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
+        assert total >= 12 and agree == total, (agree, total)
+        # ... and the first generated token against transformers itself
+        ids0 = prompt.cpu()
+        _, l0, _ = _reference_forward(orc, esd, hf, cfg, images, ids0, cross, soft)
+        l0 = l0[:, -1].detach()
+        t2 = l0.topk(2, dim=-1).values
+        sure = (t2[:, 0] - t2[:, 1]) > 3e-2 * l0.abs().max()
+        assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
+
+
+def test_gpt2_hf_decoder_standalone_call(tmp_path, monkeypatch):
+    """decoder(idx | inputs_embeds, cross_attn_embeds, attn_msk) as the reference's HuggingfaceDecoder.forward (decoder.py:332-361):
+    the mask argument is accepted and ignored, cross inputs are used only when the decoder has the layers"""
+    cfg, m = _build(tmp_path, monkeypatch, True, True)
+    hf = _hf_twin(m, True)
+    m = m.to(dev()).eval()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 380, (3, 40), generator=g)
+    mem = torch.randn(3, 8, 128, generator=g) * 0.5
+    emb = torch.randn(3, 20, 128, generator=g) * 0.1
+    with torch.no_grad():
+        for kind, kw, hkw in (('ids', dict(idx=ids.to(dev())), dict(input_ids=ids)),
+                              ('embeds', dict(inputs_embeds=emb.to(dev())), dict(inputs_embeds=emb))):
+            ref = hf(encoder_hidden_states=mem, output_hidden_states=True, **hkw)
+            logits, hidden = m.decoder(cross_attn_embeds=mem.to(dev()), attn_msk=torch.ones(40, 40, dtype=torch.bool), **kw)
+            err = float((logits.float().cpu() - ref.logits).abs().max())
+            REPORT[f'hf_gpt2.standalone.{kind}'] = {'max_abs_err': err, 'ref_absmax': float(ref.logits.abs().max())}
+            assert err <= 1e-2 * max(1.0, float(ref.logits.abs().max())), (kind, err)
+            assert float((hidden.float().cpu() - ref.hidden_states[-1]).abs().max()) <= 1.5e-2 * max(1.0, float(ref.hidden_states[-1].abs().max()))

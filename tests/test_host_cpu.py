@@ -254,6 +254,95 @@ def _tiny_hf_gpt2(monkeypatch):
     return hf
 
 
+def _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-tiny', **kw):
+    """a randomly initialised 2-layer GPT-2 saved under ./gpt2-tiny: what HuggingfaceDecoderConfig(model_str='gpt2-tiny') loads
+    through transformers' own from_pretrained (a local directory: no network, no monkeypatching of the loader)"""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    torch.manual_seed(5)
+    args = dict(n_layer=2, n_head=2, n_embd=128, n_positions=64, vocab_size=380, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                bos_token_id=379, eos_token_id=379)
+    args.update(kw)
+    hf = GPT2LMHeadModel(GPT2Config(**args)).eval()
+    with torch.no_grad():                                  # biases and LayerNorm parameters away from their 0 / 1 initialisation
+        for n_, p_ in hf.named_parameters():
+            if n_.endswith('.bias') or '.ln_' in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    hf.save_pretrained(str(tmp_path / name))
+    monkeypatch.chdir(tmp_path)
+    return hf
+
+
+def _hf_decoder_config(name='gpt2-tiny', **kw):
+    from image2text_amd.configs.models import HuggingfaceDecoderConfig
+    args = dict(vocab_size=380, use_cross_attn=False, model_str=name, extra_tokens=4, load_in_4bit=False, prepare_for_kbit_training=False)
+    args.update(kw)
+    return HuggingfaceDecoderConfig(**args)
+
+
+def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
+    """HuggingfaceDecoderConfig(model_str='gpt2*') (reference decoder.py:119-121, 285-382): the checkpoint's weights land in the hot
+    path's decoder, embeddings resized by extra_tokens, the state dict speaks Hugging Face's names and Conv1D layout in both
+    directions (a transformers GPT2LMHeadModel loads it strictly), cross-attention layers appear on request; everything else of
+    the family is refused by name"""
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.decoder import GPT2HuggingfaceDecoder
+    from transformers import GPT2Config, GPT2LMHeadModel
+    hf = _local_hf_gpt2(tmp_path, monkeypatch)
+    d = Decoder.from_config(_hf_decoder_config(), space_for_prompt=3)
+    assert isinstance(d, GPT2HuggingfaceDecoder) and d.n_embd == 128 and d.block_size == 64 and not d.use_cross_attn
+    sd, sh = d.state_dict(), hf.state_dict()
+    assert set(sd) == {'backbone.' + k for k in sh}
+    for k, v in sh.items():
+        mine = sd['backbone.' + k]
+        assert mine.shape[1:] == v.shape[1:] and mine.shape[0] == (384 if k in ('transformer.wte.weight', 'lm_head.weight') else v.shape[0]), k
+        assert torch.equal(mine[:v.shape[0]], v), k                       # rows 380..383 are transformers' fresh rows
+    assert d.lm_head.weight is d.transformer.wte.weight and d.get_inputs_embeds(torch.tensor([[1, 2]])).shape == (1, 2, 128)
+    # internal layout: nn.Linear [out, in] (what the GEMMs read); the Conv1D transposes happen at the state-dict boundary
+    assert torch.equal(d.transformer.h[1].mlp.c_fc.weight, sh['transformer.h.1.mlp.c_fc.weight'].t())
+    # ... and back: transformers loads our state dict strictly, we load transformers' strictly
+    hf2 = GPT2LMHeadModel(GPT2Config(n_layer=2, n_head=2, n_embd=128, n_positions=64, vocab_size=384))
+    hf2.load_state_dict({k[len('backbone.'):]: v for k, v in sd.items()}, strict=True)
+    d2 = Decoder.from_config(_hf_decoder_config())
+    with torch.no_grad():
+        for p_ in d2.parameters():
+            p_.zero_()
+    d2.load_state_dict(sd, strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(d.parameters(), d2.parameters()))
+    # cross-attention on request: Hugging Face's q_attn / c_attn / c_proj / ln_cross_attn <-> in_proj / out_proj / ln_3
+    dc = Decoder.from_config(_hf_decoder_config(use_cross_attn=True))
+    sdc = dc.state_dict()
+    blk = dc.transformer.h[0]
+    assert dc.use_cross_attn and dc.hot_config.transformer_config.is_cross_attn and not dc.hot_config.skip_alternate_cross_attn
+    assert torch.equal(sdc['backbone.transformer.h.0.crossattention.q_attn.weight'], blk.cross_attn.in_proj_weight[:128].t())
+    assert torch.equal(sdc['backbone.transformer.h.0.crossattention.c_attn.weight'], blk.cross_attn.in_proj_weight[128:].t())
+    assert torch.equal(sdc['backbone.transformer.h.0.crossattention.c_attn.bias'], blk.cross_attn.in_proj_bias[128:])
+    assert torch.equal(sdc['backbone.transformer.h.1.crossattention.c_proj.weight'], dc.transformer.h[1].cross_attn.out_proj.weight.t())
+    assert torch.equal(sdc['backbone.transformer.h.1.ln_cross_attn.weight'], dc.transformer.h[1].ln_3.weight)
+    hf3 = GPT2LMHeadModel(GPT2Config(n_layer=2, n_head=2, n_embd=128, n_positions=64, vocab_size=384, add_cross_attention=True))
+    hf3.load_state_dict({k[len('backbone.'):]: v for k, v in sdc.items()}, strict=True)
+    assert float(blk.cross_attn.in_proj_weight.detach().std()) > 0.01               # initialised by transformers (normal, 0.02), not left at zero
+    # inside the full model the keys sit under decoder.backbone.* as in the reference
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.synth import tiny_config
+    cfg = tiny_config(dec_d=128, dec_heads=2, dec_layers=2, block_size=64).model_copy(update=dict(decoder_config=_hf_decoder_config(use_cross_attn=True)))
+    m = VisionEncoderDecoder(cfg)
+    keys = [k for k in m.state_dict() if k.startswith('decoder.')]
+    assert keys and all(k.startswith('decoder.backbone.') for k in keys)
+    assert m._engine.dec.V == 384 and m._engine.dec_cross == [True, True] and m._engine.cross_inputs
+    m_soft = VisionEncoderDecoder(cfg.model_copy(update=dict(decoder_config=_hf_decoder_config())))
+    assert not m_soft._engine.cross_inputs                                  # model asks for cross-attention, the decoder has none: dropped
+    # refusals
+    with pytest.raises(NotImplementedError, match='LoRA'):
+        Decoder.from_config(_hf_decoder_config(lora_spec=LoraSpec(r=4, target_modules=['c_attn'])))
+    with pytest.raises(NotImplementedError, match='4-bit'):
+        Decoder.from_config(_hf_decoder_config(load_in_4bit=True))
+    with pytest.raises(NotImplementedError, match='Llama'):
+        Decoder.from_config(_hf_decoder_config(name='meta-llama/Llama-2-7b-hf', vocab_size=32000))
+    hf_relu = _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-relu', activation_function='relu')
+    with pytest.raises(NotImplementedError, match='activation'):
+        Decoder.from_config(_hf_decoder_config(name='gpt2-relu'))
+
+
 def _gpt2_decoder_config(**kw):
     from image2text_amd.configs.models import MLPConfig, ModelType, SelfAttentionConfig, SelfAttentionType, TransformerConfig
     tc = TransformerConfig(rotator_config=MLPConfig(ff_mult=4), is_causal=True, is_cross_attn=True,
