@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Train-step and greedy-decode throughput of a GPT2HuggingfaceDecoder model on one MI355X (BASELINE.json configs[2]'s decoder side;
+reference training_configs/local/gpt2.yaml without the pieces this image cannot load: torchvision's pretrained ViT-B/16 -> the
+nano-224 from-scratch ViT; peft LoRA -> every parameter trains).
+
+    python tools/bench_gpt2_hf.py [--size gpt2|gpt2-medium] [--batch 1024] [--steps 6] [--warmup 2] [--decode-batch 1024] [--cpu]
+
+There is no network: the 'checkpoint' is a randomly initialised GPT-2 of the named size written to a scratch directory and loaded
+back through AutoModelForCausalLM.from_pretrained, exactly the path a real checkpoint takes (cross-attention layers added by
+transformers, embeddings resized by extra_tokens = 2, soft prompt = the 64 encoder outputs in front of the text: one causal sequence
+of 64 + 64 positions).  Prints one JSON line; --cpu adds the reference composition (oracle encoder + transformers' GPT-2, fp32, host
+cores) on a small batch.  Synthetic data.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SIZES = {'gpt2': dict(n_layer=12, n_head=12, n_embd=768), 'gpt2-medium': dict(n_layer=24, n_head=16, n_embd=1024)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--size', default='gpt2', choices=sorted(SIZES))
+    ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--caption-len', type=int, default=64)
+    ap.add_argument('--decode-batch', type=int, default=1024)
+    ap.add_argument('--new-tokens', type=int, default=64)
+    ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--cpu', action='store_true')
+    args = ap.parse_args()
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from image2text_amd import ops
+    from image2text_amd.configs.models import HuggingfaceDecoderConfig
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import fake_tokenizer, nano224_config, synthetic_batch
+    from image2text_amd.training.optim import FusedAdamW
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    dev = torch.device('cuda:0')
+    scratch = tempfile.mkdtemp(prefix='i2t_gpt2_')
+    os.chdir(scratch)
+    name = args.size + '-random'                          # the reference dispatches on model_str.startswith('gpt2') (decoder.py:120)
+    torch.manual_seed(0)
+    GPT2LMHeadModel(GPT2Config(vocab_size=50257, n_positions=1024, **SIZES[args.size])).save_pretrained(name)
+    base = nano224_config(dropout=0.1)
+    dcfg = HuggingfaceDecoderConfig(vocab_size=50257, use_cross_attn=True, model_str=name, extra_tokens=2, load_in_4bit=False,
+                                    prepare_for_kbit_training=False)
+    cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
+    V = 50259
+    tok = fake_tokenizer(V, eos=50256)
+    wrapper = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
+    eng = wrapper.model._engine
+    n_params = sum(p.numel() for p in wrapper.model.parameters())
+    opt = FusedAdamW(wrapper.model.parameters(), wrapper.model, lr=6e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    images, labels = synthetic_batch(args.batch, 224, args.caption_len, V, seed=1, eos=50256)
+    images, labels = images.to(dev), labels.to(dev)
+
+    def step():
+        loss, _ = wrapper.train_step(images, labels)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    out = {'workload': f'nano-224 ViT (12x768, 224x224x3, 64 CLS) + GPT2HuggingfaceDecoder({args.size}, randomly initialised checkpoint, '
+                       f'cross-attention, soft prompt of 64 + {args.caption_len} text positions, dropout 0.1), every parameter trains',
+           'params_M': round(n_params / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
+           'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
+           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
+           'decoder': {'prefixed': eng.dec.prefixed, 'grad_norm': eng.dec.grad_norm, 'layers': eng.dec.L, 'd': eng.dec.d, 'vocab': eng.dec.V}}
+    from bench import GemmTimer
+    with GemmTimer(ops) as gt:
+        step()
+        gs = gt.summary()
+    out['gemm_family'] = {'launches': gs['launches'], 'ms_per_step': round(gs['total_ms'], 2), 'tflops': round(gs['tflops'], 1),
+                          'frac_of_2500_tflops': round(gs['tflops'] / 2500.0, 3)}
+    if not args.no_decode:
+        wrapper.eval()
+        Bd = args.decode_batch
+        dimgs = synthetic_batch(Bd, 224, args.caption_len, V, seed=7, eos=50256)[0].to(dev)
+        prompt = torch.full((Bd, 1), tok.bos_token_id, dtype=torch.long, device=dev)
+        with torch.no_grad():
+            wrapper.model.generate(dimgs, prompt, max_new_tokens=args.new_tokens, temperature=1.0, top_k=1)      # capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ids = wrapper.model.generate(dimgs, prompt, max_new_tokens=args.new_tokens, temperature=1.0, top_k=1)
+            torch.cuda.synchronize()
+            dd = time.perf_counter() - t0
+        assert ids.shape == (Bd, 1 + args.new_tokens)
+        out['greedy_captions_per_sec'] = round(Bd / dd, 1)
+        out['greedy'] = {'captions': Bd, 'new_tokens': args.new_tokens, 'seconds': round(dd, 3),
+                         'includes': 'encoder forward + prompt-row prefill of the KV cache + hipGraph replay per token'}
+    if args.cpu:
+        import torch.nn.functional as F
+        from oracle import reference_model as orc
+        b = 4
+        wrapper.train()
+        sd = {k: v.detach().float().cpu().clone() for k, v in wrapper.model.state_dict().items()}
+        hf = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=1024, add_cross_attention=True, **SIZES[args.size]))
+        hf.load_state_dict({k[len('decoder.backbone.'):]: v for k, v in sd.items() if k.startswith('decoder.backbone.')}, strict=True)
+        hf.train()
+        esd = {k: v.requires_grad_(True) for k, v in sd.items() if not k.startswith('decoder.')}
+        ci, cl = synthetic_batch(b, 224, args.caption_len, V, seed=1, eos=50256)
+        ids, _ = orc.shifted_inputs(cl, tok.bos_token_id, tok.eos_token_id, -100)
+
+        def cpu_step():
+            enc = orc.encode(esd, cfg, ci, training=True)
+            emb = torch.cat((enc, hf.transformer.wte(ids)), dim=-2)
+            logits = hf(inputs_embeds=emb, encoder_hidden_states=enc).logits[:, enc.shape[1]:]
+            ce = F.cross_entropy(logits.reshape(-1, V), cl.reshape(-1), ignore_index=-100, reduction='none')
+            (ce * orc.loss_weights(cl, -100).reshape(-1)).sum().backward()
+        cpu_step()
+        t0 = time.perf_counter()
+        cpu_step()
+        dc = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': round(b / dc, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': f'1 forward+backward of {b} images, oracle encoder + transformers GPT-2 (fp32), no optimizer step'}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
