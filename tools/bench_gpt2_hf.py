@@ -78,7 +78,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    out = {'workload': f'nano-224 ViT (12x768, 224x224x3, 64 CLS) + GPT2HuggingfaceDecoder({args.size}, randomly initialised checkpoint, '
+    out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + GPT2HuggingfaceDecoder({args.size}, randomly initialised checkpoint, '
                        f'cross-attention, soft prompt of 64 + {args.caption_len} text positions, dropout 0.1), every parameter trains',
            'params_M': round(n_params / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
