@@ -61,6 +61,8 @@ class GreedyDecoder:
         off = ncls if cfg.use_soft_prompting else 0
         tmax = dc.block - off
         d, ff = dc.d, dc.ff
+        if dc.llama is not None:        # i2t_gq_decode_attention walks at most 1024 cached keys per caption (prompt rows included)
+            tmax = min(tmax, 1024 - min(ncls, dc.block))
         # Hugging Face decoder + soft prompt (engine.decode_prefixed): the encoder outputs are the first cache positions of every caption
         prefix = min(ncls, dc.block) if dc.prefixed else 0
         st = SimpleNamespace(B=B, ids_ld=ids_ld, off=off, tmax=tmax, arena=a, sparse_epoch=eng.sparse_epoch, prefix=prefix,
@@ -78,7 +80,12 @@ class GreedyDecoder:
         st.hid = e(B, d)
         st.logits = e(B, dc.Vp, dtype=F32)                      # rows padded to 8 columns: 16-byte aligned rows for the GEMM epilogue
         st.margin = e(B, dtype=F32)
-        if dc.fam is None:
+        if dc.llama is not None:
+            ls = dc.llama
+            st.qkv, st.ao, st.gu = e(B, (ls.H + 2 * ls.Hkv) * ls.hd), e(B, ls.H * ls.hd), e(B, 2 * ff)
+            st.kc = [e(B, st.clen, ls.Hkv * ls.hd) for _ in range(dc.L)]
+            st.vc = [e(B, st.clen, ls.Hkv * ls.hd) for _ in range(dc.L)]
+        elif dc.fam is None:
             st.kc = [e(B, st.clen, d) for _ in range(dc.L)]
             st.vc = [e(B, st.clen, d) for _ in range(dc.L)]
         S = ncls
@@ -198,8 +205,8 @@ class GreedyDecoder:
         B, d, ff, H = st.B, dc.d, dc.ff, dc.H
         pos_ptr, len_ptr = st.counters[0:1], st.counters[1:2]
         dp = eng.dp
-        ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(f'{dp}transformer.wte.weight'),
-                       None if dc.advpos else a.P(f'{dp}transformer.wpe.weight'), st.x, B, d, st.off, dc.V)
+        ops.embed_step(st.ids, st.ids_ld, len_ptr, a.P(eng.n_wte),
+                       None if (dc.advpos or dc.llama is not None) else a.P(f'{dp}transformer.wpe.weight'), st.x, B, d, st.off, dc.V)
         if dc.advpos:           # x = MLP_p(e) + e with p = off + pos read on the device: the same captured launches serve every position
             pv = eng._pos_views()
             ops.cast_f32_bf16(st.x, st.ln)
@@ -211,13 +218,18 @@ class GreedyDecoder:
                                  bias_group_stride=pv.stride, act=0 if last else 1, residual=st.x if last else None, n_groups=1, max_rows=B,
                                  group_ptr=pos_ptr, group0=st.off)
                 h = out
-        if dc.fam is not None:
+        if dc.llama is not None:
+            self._layers_llama(st)
+        elif dc.fam is not None:
             self._layers_family(st)
         else:
             self._layers_dense(st)
         if with_head:
-            ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
-            ops.gemm(st.hid, a.W(f'{dp}transformer.wte.weight'), st.logits, B, dc.V, d)
+            if dc.llama is not None:
+                ops.rmsnorm_fwd(st.x, a.P(f'{dp}backbone.model.norm.weight'), st.hid, None, B, d, dc.llama.eps)
+            else:
+                ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
+            ops.gemm(st.hid, a.W(eng.n_head), st.logits, B, dc.V, d)
             if sampling is None:
                 ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
             else:
@@ -249,6 +261,26 @@ class GreedyDecoder:
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
             ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
             ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
+
+    def _layers_llama(self, st):
+        """The Llama-2 / Qwen2 blocks of one decode step (engine_llama.py): the rotary angle is looked up at the position counter on
+        the device (absolute position = cache slot: prompt rows first), so one captured graph serves every step."""
+        eng, dc, ls = self.eng, self.eng.dec, self.eng.dec.llama
+        B, d, ff, H, G, hd = st.B, dc.d, dc.ff, ls.H, ls.Hkv, ls.hd
+        pos_ptr = st.counters[0:1]
+        cs = eng.rope_table()
+        for l in range(dc.L):
+            v = eng._llama_views(l)
+            ops.rmsnorm_fwd(st.x, v.n1, st.ln, None, B, d, ls.eps)
+            ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, bias=v.bqkv)
+            ops.rope(st.qkv, v.nq, 0, H + G, hd, cs, B, pos_ptr=pos_ptr)
+            ops.gq_decode_attention(st.qkv[:, :H * hd], st.qkv[:, H * hd:(H + G) * hd], st.qkv[:, (H + G) * hd:], st.kc[l], st.vc[l],
+                                    st.clen * G * hd, G * hd, st.ao, pos_ptr, 0, st.clen, B, H, G, hd)
+            ops.gemm(st.ao, v.Wo, st.x, B, d, H * hd, residual=st.x)
+            ops.rmsnorm_fwd(st.x, v.n2, st.ln, None, B, d, ls.eps)
+            ops.gemm(st.ln, v.Wgu, st.gu, B, 2 * ff, d)
+            ops.swiglu_fwd(st.gu, st.h, B, ff)
+            ops.gemm(st.h, v.Wdn, st.x, B, d, ff, residual=st.x)
 
     def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None):
         side = torch.cuda.Stream(device=st.arena.device)
@@ -306,6 +338,12 @@ class GreedyDecoder:
             _, _, pctx = eng.decode_segment(B, n_p, eng._mem_bf16(enc_out) if eng.cross_inputs else None, S, True,
                                             embeds=enc_out[:, :n_p].reshape(B * n_p, dc.d), pos_offset=0)
             for l in range(dc.L):
+                if dc.llama is not None:      # row-major cache [B][slot][Hkv hd]; the saved keys already carry their rotation
+                    ls = dc.llama
+                    qkv = pctx.saves[l].qkv.view(B, n_p, -1)
+                    st.kc[l][:, :n_p].copy_(qkv[..., ls.H * ls.hd:(ls.H + ls.Hkv) * ls.hd])
+                    st.vc[l][:, :n_p].copy_(qkv[..., (ls.H + ls.Hkv) * ls.hd:])
+                    continue
                 qkv = pctx.saves[l].qkv.view(B, n_p, 3, dc.H, 64)
                 st.kc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 1].transpose(1, 2))
                 st.vc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 2].transpose(1, 2))
@@ -389,7 +427,7 @@ def generate_by_recompute(model, images, prompt_ids: torch.Tensor, max_new_token
         Tc = cond.shape[1]
         _, hb, _ = eng.decode_segment(B, Tc, mem, ncls, False, ids=cond.contiguous(), pos_offset=off)
         last = hb.view(B, Tc, dc.d)[:, -1].contiguous()
-        ops.gemm(last, a.W(f'{eng.dp}transformer.wte.weight'), logits, B, dc.V, dc.d)
+        ops.gemm(last, a.W(eng.n_head), logits, B, dc.V, dc.d)
         if sampling is None:
             ops.ngram_ban_argmax(logits, dc.Vp, ids, total, counters[1:2], ngrams, ngrams.numel(), B, dc.V, margin)
         else:

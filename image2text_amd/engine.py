@@ -39,6 +39,7 @@ import torch
 
 from . import ops, rng
 from .engine_family import FamilyBlocks, family_spec
+from .engine_llama import LlamaBlocks
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -99,6 +100,7 @@ def arena_of(param: torch.Tensor):
 
 
 _MOE_PARAM = re.compile(r'^(.*)\.experts\.(\d+)\.(l1|l2)\.(weight|bias)$')
+_QKV_PARAM = re.compile(r'^(.*\.self_attn)\.(q|k|v)_proj\.(weight|bias)$')
 
 
 def _arena_order(named):
@@ -113,7 +115,15 @@ def _arena_order(named):
     Returns (name, parameter | None, numel, shape) tuples; None marks a pad entry (zeros, never trained: no optimizer group holds
     it, so the fused optimizers keep it frozen)."""
     groups, order = {}, []
+    qkv = {}
     for name, p in named:
+        mq = _QKV_PARAM.match(name)
+        if mq:      # transformers' Llama / Qwen2 attention: q | k | v weights adjacent, then q | k | v biases (Qwen2) -> one fused GEMM
+            if mq.group(1) not in qkv:
+                qkv[mq.group(1)] = {}
+                order.append((mq.group(1) + '.<qkv>', 'qkv'))
+            qkv[mq.group(1)][f'{mq.group(2)}_proj.{mq.group(3)}'] = p
+            continue
         m = _MOE_PARAM.match(name)
         key = m.group(1) if m else (name.split('.expert_gates.')[0] if '.expert_gates.model.' in name else None)
         if key is None:
@@ -125,6 +135,12 @@ def _arena_order(named):
         groups[key][name[len(key) + 1:]] = p
     out = []
     for name, p in order:
+        if isinstance(p, str):
+            g = qkv[name[:-len('.<qkv>')]]
+            for k in [f'{x}_proj.{w}' for w in ('weight', 'bias') for x in 'qkv']:
+                if k in g:
+                    out.append((f"{name[:-len('.<qkv>')]}.{k}", g[k], g[k].numel(), g[k].shape))
+            continue
         if p is not None:
             out.append((name, p, p.numel(), p.shape))
             continue
@@ -196,6 +212,20 @@ class ParamArena:
         e = self.entries.get(name)
         return None if e is None else self.g32[e[0]:e[0] + e[1]].view(e[2])
 
+    def span(self, kind: str, names, shape):
+        """One view over several ADJACENT entries (e.g. q_proj | k_proj | v_proj weights = the fused projection's [N, K] matrix);
+        kind: 'P' fp32 parameters, 'W' bf16 shadow, 'G' fp32 gradients."""
+        o0, end = self.entries[names[0]][0], None
+        for n in names:
+            o, numel, _ = self.entries[n]
+            if end is not None and o != end:
+                raise I2TError(f'arena entries {names} are not adjacent')
+            if numel % 8 and n != names[-1]:
+                raise I2TError(f'arena entry {n} ({numel} elements) breaks the 8-element alignment of a fused view')
+            end = o + numel
+        buf = {'P': self.p32, 'W': self.pbf, 'G': self.g32}[kind]
+        return buf[o0:end].view(shape)
+
     def begin_backward(self):
         """Zero the gradient arena when this is a fresh accumulation window (every p.grad is None)."""
         fresh = all(p.grad is None for p in self.params.values())
@@ -214,11 +244,13 @@ class ParamArena:
 
 def decoder_hot_config(model):
     """The TransformerDecoderConfig the decoder's arithmetic follows: the model config's own, or the one a GPT2HuggingfaceDecoder
-    derived from its checkpoint (models/decoder.py)."""
+    derived from its checkpoint (models/decoder.py); None for the Llama-2 / Qwen2 decoders (their own spec, ``llama_spec``)."""
+    if getattr(model.decoder, 'llama_spec', None) is not None:
+        return None
     return getattr(model.decoder, 'hot_config', None) or model.config.decoder_config
 
 
-class HotPath(FamilyBlocks):
+class HotPath(FamilyBlocks, LlamaBlocks):
     """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
 
     def __init__(self, model: torch.nn.Module):
@@ -233,25 +265,39 @@ class HotPath(FamilyBlocks):
         self.has_bridge = model.has_bridge
         self.ep = 'encoder.0.' if self.has_bridge else 'encoder.'
         self.dp = 'decoder.'
-        eac, dac = ecfg.transformer_config.attn_config, dcfg.transformer_config.attn_config
+        eac = ecfg.transformer_config.attn_config
         self.enc = SimpleNamespace(d=eac.n_embd, H=eac.n_head, L=ecfg.n_layer, ncls=ecfg.n_cls,
                                    P2=ecfg.num_patches ** 2, causal=ecfg.transformer_config.is_causal,
                                    ff=int(_ff_mult(ecfg.transformer_config.rotator_config) * eac.n_embd),
                                    dropout=eac.dropout, attn_dropout=eac.attn_dropout,
                                    k=ecfg.feature_extractor_kernel_size[0])
-        self.dec = SimpleNamespace(d=dac.n_embd, H=dac.n_head, L=dcfg.n_layer, V=dcfg.vocab_size,
-                                   Vp=_round_up(dcfg.vocab_size, 8), block=dcfg.block_size,
-                                   causal=dcfg.transformer_config.is_causal,
-                                   ff=int(_ff_mult(dcfg.transformer_config.rotator_config) * dac.n_embd),
-                                   dropout=dac.dropout, attn_dropout=dac.attn_dropout)
-        # the nano-mini block family (multi-query / MoE / sparse / head widths other than 64): engine_family.FamilyBlocks
         self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
-        self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer, force=not dcfg.transformer_config.is_causal)
+        ls = getattr(model.decoder, 'llama_spec', None)
+        if ls is not None:
+            # Llama-2 / Qwen2 blocks (engine_llama.LlamaBlocks): RMSNorm, rotary embedding, grouped K/V heads, SwiGLU; no learned
+            # positions, no dropout, no cross-attention, no gradient normaliser; the parameters keep transformers' names
+            self.dec = SimpleNamespace(d=ls.d, H=ls.H, L=ls.L, V=ls.V, Vp=_round_up(ls.V, 8), block=ls.block, causal=True, ff=ls.ff,
+                                       dropout=0.0, attn_dropout=0.0, fam=None, grad_norm=False, advpos=False, llama=ls,
+                                       prefixed=bool(self.cfg.use_soft_prompting))
+            self.dcfg = dcfg = SimpleNamespace(skip_alternate_cross_attn=False, advanced_pos_emb_gate_sizes=None, n_layer=ls.L,
+                                               transformer_config=SimpleNamespace(is_cross_attn=False))
+            self.n_wte = f'{self.dp}backbone.model.embed_tokens.weight'
+            self.n_head = self.n_wte if ls.tied else f'{self.dp}backbone.lm_head.weight'
+        else:
+            dac = dcfg.transformer_config.attn_config
+            self.dec = SimpleNamespace(d=dac.n_embd, H=dac.n_head, L=dcfg.n_layer, V=dcfg.vocab_size,
+                                       Vp=_round_up(dcfg.vocab_size, 8), block=dcfg.block_size,
+                                       causal=dcfg.transformer_config.is_causal,
+                                       ff=int(_ff_mult(dcfg.transformer_config.rotator_config) * dac.n_embd),
+                                       dropout=dac.dropout, attn_dropout=dac.attn_dropout, llama=None)
+            # the nano-mini block family (multi-query / MoE / sparse / head widths other than 64): engine_family.FamilyBlocks
+            self.dec.fam = family_spec(dcfg.transformer_config, dcfg.n_layer, force=not dcfg.transformer_config.is_causal)
+            self.dec.grad_norm = not hasattr(model.decoder, 'hot_config')     # layers.py:606-607; transformers' GPT-2 block has none
+            self.dec.prefixed = hasattr(model.decoder, 'hot_config') and bool(self.cfg.use_soft_prompting)     # see decode_prefixed
+            self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
+            self.n_wte = self.n_head = f'{self.dp}transformer.wte.weight'      # token embedding / lm_head weight (tied, decoder.py:189-204)
         self._sparse_idx, self._sparse_versions, self.sparse_epoch = {'enc': None, 'dec': None}, None, 0
         self._refresh_sparse_sets()
-        self.dec.grad_norm = not hasattr(model.decoder, 'hot_config')     # layers.py:606-607; transformers' GPT-2 block has none
-        self.dec.prefixed = hasattr(model.decoder, 'hot_config') and bool(self.cfg.use_soft_prompting)     # see decode_prefixed
-        self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
         self._moe_cache, self._sub_cache = {}, {}
         self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
         gates = list(ecfg.feature_extractor_gate_sizes or [])
@@ -716,6 +762,8 @@ class HotPath(FamilyBlocks):
         a, dc = self.arena, self.dec
         if T + pos_offset > dc.block:
             raise AssertionError(f'Cannot forward sequence of length {T + pos_offset}, block size is only {dc.block}')
+        if dc.llama is not None:
+            return self.llama_decode_fwd(B, T, save, ids, embeds, pos_offset, vl)
         if split and (save or vl is not None or dc.fam is None):
             raise I2TError('split visibility is a forward-only feature of the grouped attention kernels on dense rows')
         d, M = dc.d, (vl.total if vl is not None else B * T)
@@ -729,9 +777,9 @@ class HotPath(FamilyBlocks):
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()
             if vl is not None:
-                ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, M, 1, d, pos_offset, dc.V, pos=vl.pos)
+                ops.embed_fwd(ids, a.P(self.n_wte), wpe, x, M, 1, d, pos_offset, dc.V, pos=vl.pos)
             else:
-                ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), wpe, x, B, T, d, pos_offset, dc.V)
+                ops.embed_fwd(ids, a.P(self.n_wte), wpe, x, B, T, d, pos_offset, dc.V)
             if dc.advpos:
                 x, pos_ctx = self.posmlp_fwd(x, B, T, pos_offset, vl, save)
             if emb_drop is not None:
@@ -777,7 +825,7 @@ class HotPath(FamilyBlocks):
         emb[:, :n_p].copy_(enc_out[:, :n_p])
         if T:
             tok = self._empty(B * T, dc.d)
-            ops.embed_fwd(ids, a.P(f'{self.dp}transformer.wte.weight'), None, tok, B, T, dc.d, 0, dc.V)
+            ops.embed_fwd(ids, a.P(self.n_wte), None, tok, B, T, dc.d, 0, dc.V)
             emb[:, n_p:].copy_(tok.view(B, T, dc.d))
         hid, hb, ctx = self.decode_segment(B, n_p + T, mem_bf, ncls, save, embeds=emb.view(B * (n_p + T), dc.d), pos_offset=0,
                                            dropout_without_save=dropout_without_save)
@@ -791,12 +839,12 @@ class HotPath(FamilyBlocks):
         gradient is added to dmem (they ARE the encoder outputs), the text rows' is scattered into wte."""
         a, dc, px = self.arena, self.dec, ctx.prefixed
         B, n_p, T, d = ctx.B, px.n_p, px.T, dc.d
-        wte = f'{self.dp}transformer.wte.weight'
+        wte, head = self.n_wte, self.n_head
         dh = torch.zeros(B, n_p + T, d, dtype=F32, device=a.device) if dhid is None else dhid.to(F32).reshape(B, n_p + T, d).clone()
         if dlogits_bf is not None and T:
-            ops.gemm(dlogits_bf, px.hb_text, a.G(wte), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # tied lm_head
+            ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
             dht = self._empty(B * T, d)
-            ops.gemm(dlogits_bf, a.W(wte), dht, B * T, d, dc.V, b_kmajor=True)
+            ops.gemm(dlogits_bf, a.W(head), dht, B * T, d, dc.V, b_kmajor=True)
             dh[:, n_p:] += dht.view(B, T, d)
         dx = self.decode_backward(ctx, None, dh.view(B * (n_p + T), d), dmem).view(B, n_p + T, d)
         dmem.view(B, -1, d)[:, :n_p] += dx[:, :n_p]
@@ -805,7 +853,7 @@ class HotPath(FamilyBlocks):
 
     def logits_f32(self, hb: torch.Tensor, M: int):
         out = self._empty(M, self.dec.V)
-        ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), out, M, self.dec.V, self.dec.d)
+        ops.gemm(hb, self.arena.W(self.n_head), out, M, self.dec.V, self.dec.d)
         return out
 
     def logits_bf16(self, hb: torch.Tensor, M: int, capacity: Optional[int] = None):
@@ -817,7 +865,7 @@ class HotPath(FamilyBlocks):
             buf = torch.zeros(cap, self.dec.Vp, dtype=BF16, device=self.arena.device)
             self._logits_cache[cap] = buf
         buf = buf[:M]
-        ops.gemm(hb, self.arena.W(f'{self.dp}transformer.wte.weight'), buf, M, self.dec.V, self.dec.d)
+        ops.gemm(hb, self.arena.W(self.n_head), buf, M, self.dec.V, self.dec.d)
         return buf
 
     @staticmethod
@@ -860,13 +908,22 @@ class HotPath(FamilyBlocks):
     def _decode_backward_steps(self, ctx, dlogits_bf, dhid, dmem, paired: bool):
         a, dc = self.arena, self.dec
         B, T, d, M = ctx.B, ctx.T, dc.d, ctx.M
-        wte = f'{self.dp}transformer.wte.weight'
+        wte, head = self.n_wte, self.n_head
         dh = torch.zeros(M, d, dtype=F32, device=a.device) if dlogits_bf is None else self._empty(M, d)
         if dlogits_bf is not None:
-            ops.gemm(dlogits_bf, ctx.hb, a.G(wte), dc.V, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)   # tied lm_head
-            ops.gemm(dlogits_bf, a.W(wte), dh, M, d, dc.V, b_kmajor=True)
+            ops.gemm(dlogits_bf, ctx.hb, a.G(head), dc.V, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
+            ops.gemm(dlogits_bf, a.W(head), dh, M, d, dc.V, b_kmajor=True)
         if dhid is not None:
             ops.add_(dh, dhid.contiguous())
+        if dc.llama is not None:
+            dx = self.llama_decode_bwd(ctx, dh)
+            if ctx.ids is not None:
+                if ctx.vl is not None:
+                    ops.embed_bwd(ctx.ids, dx, a.G(wte), None, M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
+                else:
+                    ops.embed_bwd(ctx.ids, dx, a.G(wte), None, B, T, d, ctx.pos_offset, dc.V)
+                return None
+            return dx
         dx = self._empty(M, d)
         ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)

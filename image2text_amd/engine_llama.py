@@ -1,0 +1,149 @@
+"""Llama-2 / Qwen2 decoder blocks on the HIP hot path (reference models/decoder.py:404-440 wraps transformers'
+LlamaForCausalLM / Qwen2ForCausalLM -- the arithmetic followed here is transformers' modeling_llama.py / modeling_qwen2.py):
+
+    h   = x + o_proj(attention(rope(q_proj(n1)), rope(k_proj(n1)), v_proj(n1))),     n1 = RMSNorm(x)       H query heads on Hkv K/V heads
+    out = h + down_proj(silu(gate_proj(n2)) * up_proj(n2)),                           n2 = RMSNorm(h)
+
+How it maps to the MI355X:
+  * q | k | v and gate | up are ONE GEMM each: the arena lays the three (two) weight matrices next to each other (engine._arena_order),
+    so the fused [N, K] operand is a view -- the persistent 256^2 MFMA kernel sees N = (H + 2 Hkv) hd and N = 2 ff;
+  * the rotary embedding runs in place on the q and k columns of that GEMM's bf16 output (i2t_rope: table lookup of transformers' own
+    cos / sin values, 16-byte accesses); its backward is the same kernel with the angle negated, in place on dq | dk;
+  * attention = the grouped-query kernels of the nano-mini family (attention_g.hip) with Hkv > 1;
+  * the residual stream stays fp32 ([M, d]); o_proj and down_proj add it in their GEMM epilogue; RMSNorm backward accumulates
+    the branch gradient onto the fp32 stream gradient and emits the bf16 copy the next GEMM reads (as LayerNorm backward does);
+  * no dropout (transformers' attention_dropout is 0 for these checkpoints), no gradient normaliser, no learned positions.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class LlamaBlocks:
+    """Mixin of engine.HotPath (uses its arena, ``_empty``, ``dec`` namespace and parameter prefix ``dp``)."""
+
+    def _llama_views(self, l: int):
+        key = ('llama', l, id(self.arena))
+        v = self._sub_cache.get(key)
+        if v is not None:
+            return v
+        a, ls = self.arena, self.dec.llama
+        p = f'{self.dp}backbone.model.layers.{l}'
+        nq = ls.H * ls.hd + 2 * ls.Hkv * ls.hd
+        qkv_w = [f'{p}.self_attn.{x}_proj.weight' for x in 'qkv']
+        qkv_b = [f'{p}.self_attn.{x}_proj.bias' for x in 'qkv']
+        gu = [f'{p}.mlp.gate_proj.weight', f'{p}.mlp.up_proj.weight']
+        v = SimpleNamespace(
+            nq=nq,
+            Wqkv=a.span('W', qkv_w, (nq, ls.d)), Gqkv=a.span('G', qkv_w, (nq, ls.d)),
+            bqkv=a.span('P', qkv_b, (nq,)) if ls.qkv_bias else None, gbqkv=a.span('G', qkv_b, (nq,)) if ls.qkv_bias else None,
+            Wo=a.W(f'{p}.self_attn.o_proj.weight'), Go=a.G(f'{p}.self_attn.o_proj.weight'),
+            Wgu=a.span('W', gu, (2 * ls.ff, ls.d)), Ggu=a.span('G', gu, (2 * ls.ff, ls.d)),
+            Wdn=a.W(f'{p}.mlp.down_proj.weight'), Gdn=a.G(f'{p}.mlp.down_proj.weight'),
+            n1=a.P(f'{p}.input_layernorm.weight'), gn1=a.G(f'{p}.input_layernorm.weight'),
+            n2=a.P(f'{p}.post_attention_layernorm.weight'), gn2=a.G(f'{p}.post_attention_layernorm.weight'))
+        self._sub_cache[key] = v
+        return v
+
+    def rope_table(self):
+        """fp32 [block, hd] = [cos | sin] per position, taken from the checkpoint's own rotary module (models/decoder.py)"""
+        key = ('rope', str(self.arena.device))
+        t = self._sub_cache.get(key)
+        if t is None:
+            t = self._sub_cache[key] = self.model.decoder.rope_table(self.dec.block).to(device=self.arena.device, dtype=F32).contiguous()
+        return t
+
+    # ------------------------------------------------------------------------------------------------ one block
+    def llama_block_fwd(self, l: int, x, B: int, T: int, pos_offset: int, save: bool):
+        ls, v = self.dec.llama, self._llama_views(l)
+        M, d, H, G, hd, ff = B * T, ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        cs = self.rope_table()
+        n1, r1 = self._empty(M, d, dtype=BF16), self._empty(M)
+        ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
+        qkv = self._empty(M, v.nq, dtype=BF16)
+        ops.gemm(n1, v.Wqkv, qkv, M, v.nq, d, bias=v.bqkv)
+        ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos_offset=pos_offset, T=T)         # q heads and k heads are adjacent columns
+        q3 = qkv.view(B, T, v.nq)
+        ao, lse = self._empty(M, H * hd, dtype=BF16), self._empty(H * M)
+        ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], ao.view(B, T, H * hd), lse,
+                             B, H, G, hd, T, T, True)
+        x1 = self._empty(M, d)
+        ops.gemm(ao, v.Wo, x1, M, d, H * hd, residual=x)
+        n2, r2 = self._empty(M, d, dtype=BF16), self._empty(M)
+        ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
+        gu = self._empty(M, 2 * ff, dtype=BF16)
+        ops.gemm(n2, v.Wgu, gu, M, 2 * ff, d)
+        h = self._empty(M, ff, dtype=BF16)
+        ops.swiglu_fwd(gu, h, M, ff)
+        x2 = self._empty(M, d)
+        ops.gemm(h, v.Wdn, x2, M, d, ff, residual=x1)
+        return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h) if save else None)
+
+    def llama_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int):
+        """dx fp32 / dxb bf16: gradient w.r.t. the block output; on return both hold the gradient w.r.t. the block input"""
+        ls, v = self.dec.llama, self._llama_views(l)
+        M, d, H, G, hd, ff = B * T, ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        # ---- MLP
+        ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        dh = self._empty(M, ff, dtype=BF16)
+        ops.gemm(dxb, v.Wdn, dh, M, ff, d, b_kmajor=True)
+        dgu = self._empty(M, 2 * ff, dtype=BF16)
+        ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
+        ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        dn = self._empty(M, d, dtype=BF16)
+        ops.gemm(dgu, v.Wgu, dn, M, d, 2 * ff, b_kmajor=True)
+        ops.rmsnorm_bwd(dn, sv.x1, v.n2, sv.r2, dx, v.gn2, M, d, dx_accumulate=True, dx_bf16=dxb)
+        # ---- attention
+        ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        dao = self._empty(M, H * hd, dtype=BF16)
+        ops.gemm(dxb, v.Wo, dao, M, H * hd, d, b_kmajor=True)
+        dqkv = self._empty(M, v.nq, dtype=BF16)
+        q3, g3 = sv.qkv.view(B, T, v.nq), dqkv.view(B, T, v.nq)
+        sl = (slice(0, H * hd), slice(H * hd, (H + G) * hd), slice((H + G) * hd, v.nq))
+        ops.gq_attention_bwd(q3[..., sl[0]], q3[..., sl[1]], q3[..., sl[2]], sv.ao.view(B, T, H * hd), dao.view(B, T, H * hd), sv.lse,
+                             self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True)
+        ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos_offset=pos_offset, T=T, inverse=True)
+        if v.gbqkv is not None:
+            ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
+        ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        ops.gemm(dqkv, v.Wqkv, dn, M, d, v.nq, b_kmajor=True)
+        ops.rmsnorm_bwd(dn, sv.x, v.n1, sv.r1, dx, v.gn1, M, d, dx_accumulate=True, dx_bf16=dxb)
+
+    # ------------------------------------------------------------------------------------------------ the decoder stack
+    def llama_decode_fwd(self, B: int, T: int, save: bool, ids, embeds, pos_offset: int, vl):
+        """decode_segment for these decoders: (hidden fp32 [M, d] after the final norm, its bf16 copy, ctx)"""
+        if vl is not None:
+            raise NotImplementedError('packed variable-length rows are not wired for the Llama-2 / Qwen2 decoders')
+        a, dc, ls = self.arena, self.dec, self.dec.llama
+        d, M = dc.d, B * T
+        if ids is not None:
+            ids = ids.to(device=a.device, dtype=torch.long).contiguous()
+            x = self._empty(M, d)
+            ops.embed_fwd(ids, a.P(self.n_wte), None, x, B, T, d, 0, dc.V)
+        else:
+            x = embeds.to(device=a.device, dtype=F32).contiguous().view(M, d)
+        saves, cur = [], x
+        for l in range(dc.L):
+            cur, sv = self.llama_block_fwd(l, cur, B, T, pos_offset, save)
+            saves.append(sv)
+        wn = a.P(f'{self.dp}backbone.model.norm.weight')
+        hid, hb, rf = self._empty(M, d), self._empty(M, d, dtype=BF16), self._empty(M)
+        ops.rmsnorm_fwd(cur, wn, hb, rf, M, d, ls.eps, y_f32=hid)
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, rf=rf, hb=hb, B=B, T=T, S=0, pos_offset=pos_offset, vl=None, M=M,
+                              emb_drop=None, pos_ctx=None) if save else None
+        return hid, hb, ctx
+
+    def llama_decode_bwd(self, ctx, dh):
+        """dh fp32 [M, d]: gradient w.r.t. the final norm's output.  Returns the gradient w.r.t. the block stack's input."""
+        a, dc = self.arena, self.dec
+        M, d = ctx.M, dc.d
+        dx, dxb = self._empty(M, d), self._empty(M, d, dtype=BF16)
+        wn = f'{self.dp}backbone.model.norm.weight'
+        ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn), ctx.rf, dx, a.G(wn), M, d, dx_bf16=dxb)
+        for l in reversed(range(dc.L)):
+            self.llama_block_bwd(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset)
+        return dx

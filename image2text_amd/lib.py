@@ -71,6 +71,11 @@ SIGNATURES = {
     'i2t_grouped_gemm': [P, I, P, I, P, I, L, P, I, L, I, P, L, I, P, P, I, P, I, I, P, I, I, P, I, I, I],
     'i2t_grouped_colsum': [P, P, I, P, I, P, L, I, I],
     'i2t_sumsq': [P, P, L, P, I],
+    'i2t_rmsnorm_fwd': [P, P, P, P, P, P, I, I, F],
+    'i2t_rmsnorm_bwd': [P, P, I, P, P, P, P, I, P, P, I, I],
+    'i2t_rope': [P, P, I, I, I, I, P, I, P, P, I, I, I, I],
+    'i2t_swiglu_fwd': [P, P, I, P, I, I],
+    'i2t_swiglu_bwd': [P, P, P, I, P, I, I],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

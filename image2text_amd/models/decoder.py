@@ -6,10 +6,13 @@ weights (``pretrained_model: gpt2 | gpt2-medium | gpt2-large | gpt2-xl``: the sa
 Hugging Face cache through ``GPT2LMHeadModel.from_pretrained``; there is no network in the build image, so an absent cache
 surfaces as transformers' own error).  ``HuggingfaceDecoderConfig`` with ``model_str: gpt2*`` (reference decoder.py:285-382,
 ``GPT2HuggingfaceDecoder``) is the same arithmetic again -- Hugging Face's GPT-2 block, cross-attention included, IS the nanoGPT
-block -- so it runs on the HIP path too and keeps Hugging Face's parameter names and Conv1D layout in its state dict.  The other
-architectures of the family (Falcon / Llama-2 / Qwen2), 4-bit loading and LoRA are refused loudly.
+block -- so it runs on the HIP path too and keeps Hugging Face's parameter names and Conv1D layout in its state dict.
+``model_str: meta-llama/Llama-2*`` / ``*Qwen*`` (decoder.py:404-440) run their own block kind (engine_llama.py: RMSNorm, rotary
+embedding, grouped K/V heads, SwiGLU) and keep the transformers module itself as the parameter container.  Falcon, 4-bit loading
+and LoRA are refused loudly.
 """
 import abc
+from types import SimpleNamespace
 from typing import Optional, Tuple, Union
 
 import torch
@@ -36,8 +39,12 @@ class Decoder(nn.Module, abc.ABC):
                 raise NotImplementedError('LoRA adapters (peft) are outside the HIP hot path (SURVEY.md 8(f) next #3)')
             if config.model_str.startswith('gpt2'):                    # reference decoder.py:120-121
                 return GPT2HuggingfaceDecoder(config, space_for_prompt)
-            raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: only the GPT-2 members of the family run on the HIP '
-                                      'hot path (Falcon / Llama-2 / Qwen2 blocks: SURVEY.md 8(f) next #3)')
+            if config.model_str.startswith('meta-llama/Llama-2'):      # reference decoder.py:124-125
+                return Llama2HuggingfaceDecoder(config)
+            if 'Qwen' in config.model_str:                             # reference decoder.py:126-127
+                return Qwen2HuggingfaceDecoder(config)
+            raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: GPT-2, Llama-2 and Qwen2 checkpoints run on the HIP hot '
+                                      'path; Falcon blocks and free-form AutoModelForCausalLM architectures do not (SURVEY.md 8(f) next #3)')
         raise ValueError('Unknown config type!!!')
 
     @staticmethod
@@ -262,3 +269,96 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
     @property
     def n_embd(self):
         return self.hf_config.n_embd
+
+
+class _LlamaFamilyHuggingfaceDecoder(Decoder):
+    """Llama-2 / Qwen2 checkpoints behind the reference's ``HuggingfaceDecoder`` surface (decoder.py:285-361, 404-440).
+
+    ``self.backbone`` IS the transformers module ``AutoModelForCausalLM.from_pretrained`` returned (embeddings resized by
+    ``extra_tokens``): it owns the parameters -- state-dict keys, ``tie_weights`` and ``get_inputs_embeds`` are the reference's by
+    construction -- but is never called; the arithmetic is engine_llama.LlamaBlocks over the flat arena its parameters become views
+    of.  These decoders have no cross-attention (``use_cross_attn`` raises the reference's ValueError) and are always causal."""
+
+    def __init__(self, config: HuggingfaceDecoderConfig):
+        super().__init__()
+        if config.load_in_4bit or config.prepare_for_kbit_training:
+            raise NotImplementedError('4-bit loading / k-bit training (bitsandbytes) is outside the HIP hot path')
+        if config.use_cross_attn:
+            raise ValueError("Don't know how to use cross attention with this model. Suggest you try a different config!!!")
+        from transformers import AutoModelForCausalLM
+        self.config = config
+        self.use_cross_attn = False
+        hf = AutoModelForCausalLM.from_pretrained(config.model_str)
+        hc = self.hf_config = hf.config
+        hf.resize_token_embeddings(config.vocab_size + config.extra_tokens)
+        hd = getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads
+        attn0 = hf.model.layers[0].self_attn
+        problems = [msg for bad, msg in (
+            (hc.model_type not in ('llama', 'qwen2'), f'model_type {hc.model_type!r}'),
+            (hc.hidden_act != 'silu', f'activation {hc.hidden_act!r}'),
+            (hd not in (16, 32, 64, 128), f'head_dim {hd}'),
+            (hc.num_attention_heads % hc.num_key_value_heads != 0, 'query heads not a multiple of key/value heads'),
+            (attn0.o_proj.bias is not None, 'o_proj bias'),
+            (hf.model.layers[0].mlp.gate_proj.bias is not None, 'mlp bias'),
+            ((attn0.q_proj.bias is None) != (attn0.k_proj.bias is None) or (attn0.q_proj.bias is None) != (attn0.v_proj.bias is None),
+             'q / k / v biases present on some projections only'),
+            (float(getattr(hc, 'attention_dropout', 0.0) or 0.0) != 0.0, 'attention_dropout > 0'),
+            (bool(getattr(hc, 'use_sliding_window', False)), 'sliding-window attention'),
+            (getattr(hc, 'pretraining_tp', 1) not in (None, 1), 'pretraining_tp > 1'),
+            (hc.hidden_size % 8 != 0 or hc.intermediate_size % 8 != 0, 'hidden / intermediate size not a multiple of 8'),
+        ) if bad]
+        if problems:
+            raise NotImplementedError(f'{hc.model_type} checkpoint outside the HIP hot path: ' + '; '.join(problems))
+        if config.enable_gradient_checkpointing:
+            pass            # the hot path keeps what its hand-written backward needs; nothing to switch on (decoder.py:322-323)
+        self.backbone = hf
+        self.llama_spec = SimpleNamespace(
+            d=hc.hidden_size, H=hc.num_attention_heads, Hkv=hc.num_key_value_heads, hd=hd, L=hc.num_hidden_layers,
+            ff=hc.intermediate_size, V=config.vocab_size + config.extra_tokens, eps=float(hc.rms_norm_eps), block=self.block_size,
+            qkv_bias=attn0.q_proj.bias is not None, tied=hf.lm_head.weight is hf.model.embed_tokens.weight)
+
+    def rope_table(self, n_positions: int) -> torch.Tensor:
+        """fp32 [n_positions, head_dim] = [cos(p f_i) | sin(p f_i)], i < head_dim / 2: the values the checkpoint's own rotary module
+        produces (whatever its rope type and scaling), in the layout of i2t_rope"""
+        rot = self.backbone.model.rotary_emb
+        dev = rot.inv_freq.device
+        with torch.no_grad():
+            cos, sin = rot(torch.zeros(1, 1, dtype=torch.float32, device=dev), torch.arange(n_positions, device=dev)[None])
+        half = cos.shape[-1] // 2
+        return torch.cat((cos[0, :, :half], sin[0, :, :half]), dim=-1).float()
+
+    def tie_weights(self):
+        self.backbone.tie_weights()
+
+    def forward(self, idx=None, inputs_embeds=None, cross_attn_embeds=None, attn_msk=None):
+        from .vision_encoder_decoder import run_decoder_standalone
+        return run_decoder_standalone(self, idx, inputs_embeds, cross_attn_embeds, attn_msk)
+
+    def get_inputs_embeds(self, idx: torch.LongTensor):
+        return self.backbone.model.embed_tokens(idx)
+
+    @property
+    def n_embd(self):
+        return self.hf_config.hidden_size
+
+
+class Llama2HuggingfaceDecoder(_LlamaFamilyHuggingfaceDecoder):
+    def __init__(self, config: HuggingfaceDecoderConfig):
+        assert config.model_str.startswith('meta-llama/Llama-2')
+        assert config.vocab_size >= 32000
+        super().__init__(config)
+
+    @property
+    def block_size(self):
+        return 4096                                        # reference decoder.py:416-417
+
+
+class Qwen2HuggingfaceDecoder(_LlamaFamilyHuggingfaceDecoder):
+    def __init__(self, config: HuggingfaceDecoderConfig):
+        assert 'Qwen' in config.model_str
+        assert config.vocab_size >= 151936
+        super().__init__(config)
+
+    @property
+    def block_size(self):
+        return self.hf_config.max_position_embeddings      # reference decoder.py:434-435

@@ -249,7 +249,7 @@ def run_decoder_standalone(decoder, idx, inputs_embeds, cross_attn_embeds, attn_
     owner = _owner_of(decoder)
     assert not (idx is None and inputs_embeds is None)
     assert idx is None or inputs_embeds is None
-    if hasattr(decoder, 'hot_config'):       # Hugging Face decoders: always causal, cross inputs dropped without the layers (decoder.py:341-361)
+    if hasattr(decoder, 'hf_config'):        # Hugging Face decoders: always causal, cross inputs dropped without the layers (decoder.py:341-361)
         attn_msk = None
         cross_attn_embeds = cross_attn_embeds if decoder.use_cross_attn else None
     if attn_msk is not None:

@@ -319,6 +319,39 @@ def grad_normalize(g: torch.Tensor, ws: torch.Tensor, g_bf16=None, bf16_drop=Non
     return g
 
 
+def rmsnorm_fwd(x, w, y, rstd, M, d, eps, y_f32=None):
+    _need_cuda(x, w)
+    _l.check(_lib().i2t_rmsnorm_fwd(_stream(), _p(x), _p(w), _p(y), _p(y_f32), _p(rstd), M, d, float(eps)), 'i2t_rmsnorm_fwd')
+    return y
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dx, dw, M, d, dx_accumulate=False, dx_bf16=None):
+    _need_cuda(dy, x, w, rstd, dx)
+    _l.check(_lib().i2t_rmsnorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(w), _p(rstd), _p(dx), int(dx_accumulate),
+                                    _p(dx_bf16), _p(dw), M, d), 'i2t_rmsnorm_bwd')
+    return dx
+
+
+def rope(x, rs, col0, n_heads, hd, cos_sin, M, pos=None, pos_ptr=None, pos_offset=0, T=0, inverse=False):
+    """in place on bf16 rows (include/i2t.h::i2t_rope)"""
+    _need_cuda(x, cos_sin)
+    _l.check(_lib().i2t_rope(_stream(), _p(x), rs, col0, n_heads, hd, _p(cos_sin), cos_sin.shape[0], _p(pos), _p(pos_ptr), pos_offset,
+                             T, M, int(inverse)), 'i2t_rope')
+    return x
+
+
+def swiglu_fwd(gate_up, h, M, ff):
+    _need_cuda(gate_up, h)
+    _l.check(_lib().i2t_swiglu_fwd(_stream(), _p(gate_up), gate_up.stride(0), _p(h), M, ff), 'i2t_swiglu_fwd')
+    return h
+
+
+def swiglu_bwd(dh, gate_up, d_gate_up, M, ff):
+    _need_cuda(dh, gate_up, d_gate_up)
+    _l.check(_lib().i2t_swiglu_bwd(_stream(), _p(dh), _p(gate_up), gate_up.stride(0), _p(d_gate_up), M, ff), 'i2t_swiglu_bwd')
+    return d_gate_up
+
+
 def sumsq(g: torch.Tensor, ws: torch.Tensor, accumulate=False):
     """ws[0] (+)= sum(g^2)  (include/i2t.h::i2t_sumsq)"""
     _need_cuda(g, ws)

@@ -373,6 +373,30 @@ int i2t_gq_decode_attention(void* stream, const void* q, int q_rs, const void* k
 int i2t_sparse_step_setup(void* stream, const int* pos_ptr, const int* rank, const int* member, int* lpos, int* lmem, int L, int tmax);
 int i2t_select_rows(void* stream, const int* flag, const float* a, const float* b, float* out, long n);
 
+/* -----------------------------------------------------------------------------------------------------------
+ * Llama-2 / Qwen2 decoder blocks (reference models/decoder.py:404-440: Llama2HuggingfaceDecoder / Qwen2HuggingfaceDecoder wrap
+ * transformers' LlamaForCausalLM / Qwen2ForCausalLM, a go-through dependency -- transformers 5.x models/llama/modeling_llama.py:
+ * LlamaRMSNorm, apply_rotary_pos_emb with rotate_half, LlamaMLP).  Projections are i2t_gemm_bf16, attention
+ * is i2t_gq_attention_* (H query heads on Hkv key/value heads).
+ *
+ * RMSNorm: y (bf16) / y_f32 [M][d] = w * x * rstd (either output may be null), rstd[m] = rsqrt(mean(x[m]^2) + eps) (fp32 x; rstd
+ * may be null).  Backward:
+ * dx (+)= rstd (dy w - xh mean(dy w xh)), xh = x rstd; dw += sum_m dy xh (null: skipped); dx_bf16 (nullable) = bf16 copy of the
+ * dx written (the next GEMM's operand). */
+int i2t_rmsnorm_fwd(void* stream, const float* x, const float* w, void* y, float* y_f32, float* rstd, int M, int d, float eps);
+int i2t_rmsnorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* w, const float* rstd,
+                    float* dx, int dx_accumulate, void* dx_bf16, float* dw, int M, int d);
+/* Rotary position embedding in place on n_heads heads of width hd starting at column col0 of the bf16 rows x [M][rs]:
+ * [x1 | x2] -> [x1 cos - x2 sin | x2 cos + x1 sin] (halves of the head; transformers' rotate_half convention).  cos_sin fp32
+ * [n_positions][hd] = [cos(p f_i), i < hd/2 | sin(p f_i)].  Position of row m: pos[m] (packed rows) | *pos_ptr + pos_offset (decode
+ * step under hipGraph) | pos_offset + m % T.  inverse != 0 rotates by the negative angle (= the backward of the forward). */
+int i2t_rope(void* stream, void* x, int rs, int col0, int n_heads, int hd, const float* cos_sin, int n_positions,
+             const int* pos, const int* pos_ptr, int pos_offset, int T, int M, int inverse);
+/* SwiGLU on the fused projection gate_up bf16 [M][ld] = [gate (ff) | up (ff)]: h [M][ff] = silu(gate) * up; backward writes
+ * d_gate_up [M][ld] from dh [M][ff]. */
+int i2t_swiglu_fwd(void* stream, const void* gate_up, int ld, void* h, int M, int ff);
+int i2t_swiglu_bwd(void* stream, const void* dh, const void* gate_up, int ld, void* d_gate_up, int M, int ff);
+
 /* Grouped small GEMMs for AdvancedPositionalBiasMLP (reference models/layers.py:617-638, decoder.py:231-232: every position owns a
  * private MLP, so one layer of the module is one GEMM per position).  Group g = position; its rows are rows [seg[g], seg[g+1]) of
  * the row-major operands (position-major order; seg = device int[n_groups + 1]; max_rows = the largest group), its weights

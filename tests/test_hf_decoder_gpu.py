@@ -220,3 +220,172 @@ def test_gpt2_hf_decoder_standalone_call(tmp_path, monkeypatch):
             REPORT[f'hf_gpt2.standalone.{kind}'] = {'max_abs_err': err, 'ref_absmax': float(ref.logits.abs().max())}
             assert err <= 1e-2 * max(1.0, float(ref.logits.abs().max())), (kind, err)
             assert float((hidden.float().cpu() - ref.hidden_states[-1]).abs().max()) <= 1.5e-2 * max(1.0, float(ref.hidden_states[-1].abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Llama2HuggingfaceDecoder / Qwen2HuggingfaceDecoder (reference decoder.py:404-440): RMSNorm, rotary embedding, grouped K/V heads,
+# SwiGLU (image2text_amd/engine_llama.py, csrc/llama.hip).  Checker: the checkpoint's own transformers module on the CPU in fp32.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _llama_model(tmp_path, monkeypatch, kind):
+    import copy
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from test_host_cpu import _local_hf_llama
+    _, name, vocab = _local_hf_llama(tmp_path, monkeypatch, kind)
+    extra = 4 if kind == 'llama' else 0
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    m.decoder.tie_weights()
+    hf = copy.deepcopy(m.decoder.backbone).float().eval()
+    return cfg, m, hf, vocab + extra
+
+
+def _llama_reference(orc, esd, hf, cfg, images, ids):
+    enc = orc.encode(esd, cfg, images, training=False)
+    emb = torch.cat((enc, hf.model.embed_tokens(ids)), dim=-2)
+    out = hf(inputs_embeds=emb, output_hidden_states=True)
+    return enc, out.logits[..., enc.shape[1]:, :], out.hidden_states[-1]
+
+
+@pytest.mark.parametrize('kind', ['llama', 'qwen'])
+def test_llama_family_decoder_forward_gradients_generate(tmp_path, monkeypatch, kind):
+    """forward() -- logits, hidden_state over [prompt rows | text rows], encoder_output -- a loss over both back-propagated (every
+    parameter's gradient: fused q|k|v and gate|up projections, their biases, RMSNorm gains, tied or untied head, the encoder through
+    the prompt rows), then the trainer's train_step loss, and generate() on the KV cache against greedy decoding by full forwards."""
+    from oracle import reference_model as orc
+    tag = f'hf_{kind}'
+    cfg, m, hf, V = _llama_model(tmp_path, monkeypatch, kind)
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    m = m.to(dev()).train()
+    eng = m._engine
+    assert eng.dec.prefixed and eng.dec.llama is not None and not eng.cross_inputs
+    images, labels = synthetic_batch(3, 32, 12, V, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls
+    g = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, 256, generator=g) * 0.05
+    wl = torch.randn(3, 12, V, generator=g) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    enc, ologits, ohid = _llama_reference(orc, esd, hf, cfg, images, ids)
+    for name, got, ref, tol in (('logits', out.logits, ologits, 1e-2), ('hidden', out.hidden_state, ohid, 1.5e-2),
+                                ('encoder_output', out.encoder_output, enc, 1e-2)):
+        err, scale = float((got.float().cpu() - ref.detach()).abs().max()), max(1.0, float(ref.detach().abs().max()))
+        REPORT[f'{tag}.{name}'] = {'max_abs_err': err, 'tol': tol * scale}
+        assert err <= tol * scale, (name, err, tol * scale)
+    ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.backbone.' + k: p.grad for k, p in hf.named_parameters()})
+    fails, names = [], [n for n, _ in m.named_parameters()]
+    assert set(names) == set(ref_grads), set(names) ^ set(ref_grads)
+    for name, p in m.named_parameters():
+        try:
+            grad_close(f'{tag}.{name}', p.grad, ref_grads[name].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    # trainer step on the same model
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    tok = fake_tokenizer(V)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    w.model.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    w.model.decoder.tie_weights()
+    w = w.to(dev()).train()
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    sids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
+    with torch.no_grad():
+        _, sl, _ = _llama_reference(orc, esd, hf, cfg, images, sids)
+    ce = F.cross_entropy(sl.reshape(-1, V), labels.reshape(-1), ignore_index=-100, reduction='none')
+    oloss = float((ce * orc.loss_weights(labels, -100).reshape(-1)).sum())
+    REPORT[f'{tag}.train_loss'] = {'got': float(loss.detach()), 'ref': oloss}
+    assert abs(float(loss.detach()) - oloss) <= 1e-2 * oloss
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in w.model.parameters())
+    # generation
+    w.eval()
+    with torch.no_grad():
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = w.model.generate(images.to(dev()), prompt, max_new_tokens=12, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(12):
+            lg = w.model(images=images.to(dev()), ids=cur).logits[:, -1].float().cpu()
+            lg = orc.apply_ngram_ban(cur.cpu(), lg, cfg.no_repeat_n_grams)
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * lg[torch.isfinite(lg)].abs().max().clamp(min=1.0)
+            same_prefix = (gen[:, :cur.shape[1]].cpu() == cur.cpu()).all(dim=1)
+            ok = gen[:, cur.shape[1]].cpu() == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
+        REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
+        assert total >= 9 and agree == total, (agree, total)
+        _, l0, _ = _llama_reference(orc, esd, hf, cfg, images, prompt.cpu())
+        l0 = l0[:, -1].detach()
+        t2 = l0.topk(2, dim=-1).values
+        sure = (t2[:, 0] - t2[:, 1]) > 3e-2 * l0.abs().max()
+        assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
+
+
+def test_llama_row_kernels():
+    """i2t_rmsnorm_fwd / _bwd, i2t_rope (forward, inverse, position sources) and i2t_swiglu_fwd / _bwd against torch fp32"""
+    from image2text_amd import ops
+    g = torch.Generator().manual_seed(0)
+    M, d = 70, 2304                                         # more than one column panel (2048) in the backward, a ragged last row group
+    x = torch.randn(M, d, generator=g).to(dev())
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
+    dy = torch.randn(M, d, generator=g).to(dev())
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = wr * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5)
+    yr.backward(dy)
+    y, y32, rs = torch.empty(M, d, dtype=torch.bfloat16, device=dev()), torch.empty(M, d, device=dev()), torch.empty(M, device=dev())
+    ops.rmsnorm_fwd(x, w, y, rs, M, d, 1e-5, y_f32=y32)
+    assert float((y32 - yr.detach()).abs().max()) < 1e-5 and float((y.float() - yr.detach()).abs().max()) < 3e-2
+    for dy_in in (dy, dy.to(torch.bfloat16)):
+        dx, dxb, dw = torch.full((M, d), 0.5, device=dev()), torch.empty(M, d, dtype=torch.bfloat16, device=dev()), torch.zeros(d, device=dev())
+        ops.rmsnorm_bwd(dy_in, x, w, rs, dx, dw, M, d, dx_accumulate=True, dx_bf16=dxb)
+        tol = 1e-4 if dy_in.dtype == torch.float32 else 3e-2
+        assert float((dx - 0.5 - xr.grad).abs().max()) < tol * max(1.0, float(xr.grad.abs().max()))
+        assert float((dw - wr.grad).abs().max()) < tol * float(wr.grad.abs().max()) + 1e-3
+        assert float((dxb.float() - dx).abs().max()) < 2e-2 * float(dx.abs().max())
+    # rotary embedding
+    B, T, H, hd = 2, 9, 3, 64
+    rsz = H * hd + 32
+    q = torch.randn(B * T, rsz, generator=g).to(torch.bfloat16).to(dev())
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(40).float(), inv)
+    tab = torch.cat((ang.cos(), ang.sin()), -1).to(dev())
+
+    def ref_rope(t, pos, sign=1.0):
+        t = t.float()[:, :H * hd].view(-1, H, hd)
+        c, s_ = tab[pos, :hd // 2][:, None], sign * tab[pos, hd // 2:][:, None]
+        a, b = t[..., :hd // 2], t[..., hd // 2:]
+        return torch.cat((a * c - b * s_, b * c + a * s_), -1).reshape(-1, H * hd)
+    pos_dense = (3 + torch.arange(B * T, device=dev()) % T)
+    for kw, pos in ((dict(pos_offset=3, T=T), pos_dense),
+                    (dict(pos=torch.arange(B * T, dtype=torch.int32, device=dev()).flip(0).contiguous()), torch.arange(B * T, device=dev()).flip(0)),
+                    (dict(pos_ptr=torch.tensor([5], dtype=torch.int32, device=dev()), pos_offset=2), torch.full((B * T,), 7, device=dev()))):
+        for inverse in (False, True):
+            z = q.clone()
+            ops.rope(z, rsz, 0, H, hd, tab, B * T, inverse=inverse, **kw)
+            want = ref_rope(q, pos, -1.0 if inverse else 1.0)
+            assert float((z[:, :H * hd].float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+            assert torch.equal(z[:, H * hd:], q[:, H * hd:])                       # columns past the heads untouched
+    # SwiGLU
+    M, ff = 37, 96
+    gu = torch.randn(M, 2 * ff, generator=g).to(torch.bfloat16).to(dev())
+    dh = torch.randn(M, ff, generator=g).to(torch.bfloat16).to(dev())
+    gr = gu.float().clone().requires_grad_(True)
+    hr = F.silu(gr[:, :ff]) * gr[:, ff:]
+    hr.backward(dh.float())
+    h, dgu = torch.empty(M, ff, dtype=torch.bfloat16, device=dev()), torch.empty(M, 2 * ff, dtype=torch.bfloat16, device=dev())
+    ops.swiglu_fwd(gu, h, M, ff)
+    ops.swiglu_bwd(dh, gu, dgu, M, ff)
+    assert float((h.float() - hr.detach()).abs().max()) < 2e-2 * float(hr.abs().max())
+    assert float((dgu.float() - gr.grad).abs().max()) < 2e-2 * float(gr.grad.abs().max())

@@ -336,11 +336,70 @@ def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
         Decoder.from_config(_hf_decoder_config(lora_spec=LoraSpec(r=4, target_modules=['c_attn'])))
     with pytest.raises(NotImplementedError, match='4-bit'):
         Decoder.from_config(_hf_decoder_config(load_in_4bit=True))
-    with pytest.raises(NotImplementedError, match='Llama'):
-        Decoder.from_config(_hf_decoder_config(name='meta-llama/Llama-2-7b-hf', vocab_size=32000))
+    with pytest.raises(NotImplementedError, match='Falcon'):
+        Decoder.from_config(_hf_decoder_config(name='tiiuae/falcon-7b', vocab_size=65024))
     hf_relu = _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-relu', activation_function='relu')
     with pytest.raises(NotImplementedError, match='activation'):
         Decoder.from_config(_hf_decoder_config(name='gpt2-relu'))
+
+
+def _local_hf_llama(tmp_path, monkeypatch, kind='llama'):
+    """a randomly initialised 2-layer Llama-2 / Qwen2 checkpoint in a local directory whose name satisfies the reference's dispatch
+    (decoder.py:124-127, 404-440: 'meta-llama/Llama-2*' with vocab >= 32000, '*Qwen*' with vocab >= 151936)"""
+    from transformers import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM
+    torch.manual_seed(7)
+    if kind == 'llama':     # 4 query heads of 64 on 2 K/V heads, no biases, untied head
+        name, vocab = 'meta-llama/Llama-2-tiny', 32000
+        hf = LlamaForCausalLM(LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                          num_key_value_heads=2, vocab_size=vocab, max_position_embeddings=128, rms_norm_eps=1e-5))
+    else:                   # 2 query heads of 128 on 1 K/V head, q / k / v biases, tied head
+        name, vocab = 'Qwen-tiny', 151936
+        hf = Qwen2ForCausalLM(Qwen2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                                          num_key_value_heads=1, vocab_size=vocab, max_position_embeddings=128, tie_word_embeddings=True))
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if n_.endswith('.bias') or 'norm' in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    hf.save_pretrained(str(tmp_path / name))
+    monkeypatch.chdir(tmp_path)
+    return hf.eval(), name, vocab
+
+
+def test_llama_qwen2_huggingface_decoder_plugins(tmp_path, monkeypatch):
+    """Llama2HuggingfaceDecoder / Qwen2HuggingfaceDecoder (reference decoder.py:124-127, 404-440): the transformers module is the
+    parameter container (state-dict keys = the reference's), the arena lays q | k | v (and their biases) and gate | up next to each
+    other so that the fused projections are single views, the rotary table holds transformers' own cos / sin values"""
+    from image2text_amd.engine import _arena_order
+    from image2text_amd.models.decoder import Llama2HuggingfaceDecoder, Qwen2HuggingfaceDecoder
+    for kind, cls, extra in (('llama', Llama2HuggingfaceDecoder, 4), ('qwen', Qwen2HuggingfaceDecoder, 0)):
+        hf, name, vocab = _local_hf_llama(tmp_path, monkeypatch, kind)
+        d = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra))
+        assert isinstance(d, cls) and d.n_embd == 256 and d.block_size == (4096 if kind == 'llama' else 128)
+        ls = d.llama_spec
+        assert (ls.H, ls.Hkv, ls.hd, ls.L, ls.ff, ls.V) == ((4, 2, 64) if kind == 'llama' else (2, 1, 128)) + (2, 512, vocab + extra)
+        assert ls.qkv_bias == (kind == 'qwen') and ls.tied == (kind == 'qwen')
+        sd, sh = d.state_dict(), hf.state_dict()
+        assert set(sd) == {'backbone.' + k for k in sh}
+        assert all(torch.equal(sd['backbone.' + k][:v.shape[0]], v) for k, v in sh.items())
+        assert d.get_inputs_embeds(torch.tensor([[1, 2]])).shape == (1, 2, 256)
+        order = [n for n, *_ in _arena_order(list(d.named_parameters()))]
+        i = order.index('backbone.model.layers.1.self_attn.q_proj.weight')
+        want = [f'backbone.model.layers.1.self_attn.{x}_proj.weight' for x in 'qkv']
+        if kind == 'qwen':
+            want += [f'backbone.model.layers.1.self_attn.{x}_proj.bias' for x in 'qkv']
+        assert order[i:i + len(want)] == want
+        j = order.index('backbone.model.layers.0.mlp.gate_proj.weight')
+        assert order[j + 1] == 'backbone.model.layers.0.mlp.up_proj.weight' and sorted(order) == sorted(n for n, _ in d.named_parameters())
+        # rotary table against transformers' module: [cos | sin] halves
+        tab = d.rope_table(16)
+        cos, sin = hf.model.rotary_emb(torch.zeros(1, 1), torch.arange(16)[None])
+        assert tab.shape == (16, ls.hd) and torch.equal(tab[:, :ls.hd // 2], cos[0, :, :ls.hd // 2]) and torch.equal(tab[:, ls.hd // 2:], sin[0, :, ls.hd // 2:])
+        with pytest.raises(ValueError, match='cross attention'):
+            Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, use_cross_attn=True))
+    with pytest.raises(AssertionError):
+        Decoder.from_config(_hf_decoder_config(name='meta-llama/Llama-2-tiny', vocab_size=1000))          # 'vocab should not shrink' (decoder.py:407)
+    with pytest.raises(NotImplementedError, match='Falcon'):
+        Decoder.from_config(_hf_decoder_config(name='tiiuae/falcon-7b', vocab_size=65024))
 
 
 def _gpt2_decoder_config(**kw):
