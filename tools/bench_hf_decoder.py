@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Train-step and greedy-decode throughput of a GPT2HuggingfaceDecoder model on one MI355X (BASELINE.json configs[2]'s decoder side;
-reference training_configs/local/gpt2.yaml without the pieces this image cannot load: torchvision's pretrained ViT-B/16 -> the
-nano-224 from-scratch ViT; peft LoRA -> every parameter trains).
+"""Train-step and greedy-decode throughput of a Hugging Face decoder behind the reference's plugin surface on one MI355X
+(BASELINE.json configs[2]'s decoder side; reference training_configs/local/gpt2.yaml, local/qwen-1.5b-deepseek-distill.yaml without
+the pieces this image cannot load: torchvision's pretrained ViT-B/16 -> the nano-224 from-scratch ViT; peft LoRA -> every parameter
+trains).
 
-    python tools/bench_gpt2_hf.py [--size gpt2|gpt2-medium] [--batch 1024] [--steps 6] [--warmup 2] [--decode-batch 1024] [--cpu]
+    python tools/bench_hf_decoder.py [--size gpt2|gpt2-medium|qwen2-1.5b|llama2-tiny] [--batch 1024] [--steps 6] [--warmup 2]
+                                     [--decode-batch 1024] [--cpu]
 
-There is no network: the 'checkpoint' is a randomly initialised GPT-2 of the named size written to a scratch directory and loaded
-back through AutoModelForCausalLM.from_pretrained, exactly the path a real checkpoint takes (cross-attention layers added by
-transformers, embeddings resized by extra_tokens = 2, soft prompt = the 64 encoder outputs in front of the text: one causal sequence
-of 64 + 64 positions).  Prints one JSON line; --cpu adds the reference composition (oracle encoder + transformers' GPT-2, fp32, host
-cores) on a small batch.  Synthetic data.
+There is no network: the 'checkpoint' is a randomly initialised model of the named shape written to a scratch directory and loaded
+back through AutoModelForCausalLM.from_pretrained, exactly the path a real checkpoint takes (GPT-2: cross-attention layers added by
+transformers, embeddings resized by extra_tokens = 2; soft prompt = the 64 encoder outputs in front of the text: one causal sequence
+of 64 + 64 positions).  qwen2-1.5b is the shape of deepseek-ai/DeepSeek-R1-Distill-Qwen-1.5B (28 x 1536, 12 query heads of 128 on 2
+K/V heads, SwiGLU 8960, vocabulary 151 936, untied head: 1.78 B parameters).  Prints one JSON line; --cpu adds the reference
+composition (oracle encoder + the transformers module, fp32, host cores) on a small batch.  Synthetic data.
 """
 import argparse
 import json
@@ -23,11 +26,19 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SIZES = {'gpt2': dict(n_layer=12, n_head=12, n_embd=768), 'gpt2-medium': dict(n_layer=24, n_head=16, n_embd=1024)}
+LLAMA_SIZES = {      # name -> (checkpoint directory name satisfying decoder.py:120-127, config class, config, vocabulary)
+    'qwen2-1.5b': ('Qwen2-1.5B-random', 'Qwen2Config', dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
+                                                             num_attention_heads=12, num_key_value_heads=2, max_position_embeddings=4096,
+                                                             rms_norm_eps=1e-6, tie_word_embeddings=False), 151936),
+    'llama2-tiny': ('meta-llama/Llama-2-tiny-random', 'LlamaConfig', dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=8,
+                                                                          num_attention_heads=8, num_key_value_heads=8,
+                                                                          max_position_embeddings=4096, rms_norm_eps=1e-5), 32000),
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--size', default='gpt2', choices=sorted(SIZES))
+    ap.add_argument('--size', default='gpt2', choices=sorted(SIZES) + sorted(LLAMA_SIZES))
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
@@ -47,20 +58,31 @@ def main():
     dev = torch.device('cuda:0')
     scratch = tempfile.mkdtemp(prefix='i2t_gpt2_')
     os.chdir(scratch)
-    name = args.size + '-random'                          # the reference dispatches on model_str.startswith('gpt2') (decoder.py:120)
     torch.manual_seed(0)
-    GPT2LMHeadModel(GPT2Config(vocab_size=50257, n_positions=1024, **SIZES[args.size])).save_pretrained(name)
     base = nano224_config(dropout=0.1)
-    dcfg = HuggingfaceDecoderConfig(vocab_size=50257, use_cross_attn=True, model_str=name, extra_tokens=2, load_in_4bit=False,
-                                    prepare_for_kbit_training=False)
-    cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
-    V = 50259
-    tok = fake_tokenizer(V, eos=50256)
+    llama = args.size in LLAMA_SIZES
+    if llama:
+        import transformers
+        name, cfg_cls, kw, vocab = LLAMA_SIZES[args.size]
+        hf_cfg = getattr(transformers, cfg_cls)(vocab_size=vocab, **kw)
+        transformers.AutoModelForCausalLM.from_config(hf_cfg).save_pretrained(name)
+        dcfg = HuggingfaceDecoderConfig(vocab_size=vocab, use_cross_attn=False, model_str=name, extra_tokens=0, load_in_4bit=False,
+                                        prepare_for_kbit_training=False)
+        cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=False, use_soft_prompting=True))
+        V, eos = vocab, vocab - 1
+    else:
+        name = args.size + '-random'                      # the reference dispatches on model_str.startswith('gpt2') (decoder.py:120)
+        GPT2LMHeadModel(GPT2Config(vocab_size=50257, n_positions=1024, **SIZES[args.size])).save_pretrained(name)
+        dcfg = HuggingfaceDecoderConfig(vocab_size=50257, use_cross_attn=True, model_str=name, extra_tokens=2, load_in_4bit=False,
+                                        prepare_for_kbit_training=False)
+        cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
+        V, eos = 50259, 50256
+    tok = fake_tokenizer(V, eos=eos)
     wrapper = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
     eng = wrapper.model._engine
     n_params = sum(p.numel() for p in wrapper.model.parameters())
     opt = FusedAdamW(wrapper.model.parameters(), wrapper.model, lr=6e-4, betas=(0.9, 0.95), weight_decay=0.0)
-    images, labels = synthetic_batch(args.batch, 224, args.caption_len, V, seed=1, eos=50256)
+    images, labels = synthetic_batch(args.batch, 224, args.caption_len, V, seed=1, eos=eos)
     images, labels = images.to(dev), labels.to(dev)
 
     def step():
@@ -78,8 +100,10 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + GPT2HuggingfaceDecoder({args.size}, randomly initialised checkpoint, '
-                       f'cross-attention, soft prompt of 64 + {args.caption_len} text positions, dropout 0.1), every parameter trains',
+    kind = type(wrapper.model.decoder).__name__
+    out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + {kind}({args.size}, randomly initialised checkpoint, '
+                       + ('' if llama else 'cross-attention, dropout 0.1, ') +
+                       f'soft prompt of 64 + {args.caption_len} text positions), every parameter trains',
            'params_M': round(n_params / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
@@ -93,7 +117,7 @@ def main():
     if not args.no_decode:
         wrapper.eval()
         Bd = args.decode_batch
-        dimgs = synthetic_batch(Bd, 224, args.caption_len, V, seed=7, eos=50256)[0].to(dev)
+        dimgs = synthetic_batch(Bd, 224, args.caption_len, V, seed=7, eos=eos)[0].to(dev)
         prompt = torch.full((Bd, 1), tok.bos_token_id, dtype=torch.long, device=dev)
         with torch.no_grad():
             wrapper.model.generate(dimgs, prompt, max_new_tokens=args.new_tokens, temperature=1.0, top_k=1)      # capture
@@ -112,17 +136,20 @@ def main():
         b = 4
         wrapper.train()
         sd = {k: v.detach().float().cpu().clone() for k, v in wrapper.model.state_dict().items()}
-        hf = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=1024, add_cross_attention=True, **SIZES[args.size]))
+        if llama:
+            hf = transformers.AutoModelForCausalLM.from_config(hf_cfg)
+        else:
+            hf = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=1024, add_cross_attention=True, **SIZES[args.size]))
         hf.load_state_dict({k[len('decoder.backbone.'):]: v for k, v in sd.items() if k.startswith('decoder.backbone.')}, strict=True)
         hf.train()
         esd = {k: v.requires_grad_(True) for k, v in sd.items() if not k.startswith('decoder.')}
-        ci, cl = synthetic_batch(b, 224, args.caption_len, V, seed=1, eos=50256)
+        ci, cl = synthetic_batch(b, 224, args.caption_len, V, seed=1, eos=eos)
         ids, _ = orc.shifted_inputs(cl, tok.bos_token_id, tok.eos_token_id, -100)
 
         def cpu_step():
             enc = orc.encode(esd, cfg, ci, training=True)
-            emb = torch.cat((enc, hf.transformer.wte(ids)), dim=-2)
-            logits = hf(inputs_embeds=emb, encoder_hidden_states=enc).logits[:, enc.shape[1]:]
+            emb = torch.cat((enc, hf.get_input_embeddings()(ids)), dim=-2)
+            logits = (hf(inputs_embeds=emb) if llama else hf(inputs_embeds=emb, encoder_hidden_states=enc)).logits[:, enc.shape[1]:]
             ce = F.cross_entropy(logits.reshape(-1, V), cl.reshape(-1), ignore_index=-100, reduction='none')
             (ce * orc.loss_weights(cl, -100).reshape(-1)).sum().backward()
         cpu_step()
@@ -130,7 +157,7 @@ def main():
         cpu_step()
         dc = time.perf_counter() - t0
         out['cpu_baseline'] = {'value': round(b / dc, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                               'sample': f'1 forward+backward of {b} images, oracle encoder + transformers GPT-2 (fp32), no optimizer step'}
+                               'sample': f'1 forward+backward of {b} images, oracle encoder + the transformers module (fp32), no optimizer step'}
     print(json.dumps(out))
 
 
