@@ -23,7 +23,7 @@ def write_report():
     yield
     import json
     import test_model_gpu
-    REPORT.update({k: v for k, v in test_model_gpu.REPORT.items() if k.startswith('grad.hf_gpt2')})     # grad_close records there
+    REPORT.update({k: v for k, v in test_model_gpu.REPORT.items() if k.startswith('grad.hf_')})     # grad_close records there
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/parity_report_hf_decoder.json', 'w') as fh:
         json.dump(REPORT, fh, indent=1, sort_keys=True)
