@@ -787,6 +787,9 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         else:
             if dc.advpos:
                 x, pos_ctx = self.posmlp_fwd(embeds.to(device=a.device, dtype=F32).contiguous().view(M, d), B, T, pos_offset, vl, save)
+            elif vl is not None:      # packed rows: each row's own position (the prefixed sequence of a Hugging Face decoder)
+                torch.index_select(wpe, 0, vl.pos.long() + pos_offset, out=x)
+                ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
             else:
                 ops.bcast_rows(wpe[pos_offset:pos_offset + T], x, T * d, B, T, d)
                 ops.add_(x, embeds.to(device=a.device, dtype=F32).contiguous())
@@ -813,9 +816,10 @@ class HotPath(FamilyBlocks, LlamaBlocks):
     # ---- Hugging Face decoders with a soft prompt: ONE causal sequence [encoder outputs | text] (the reference passes no mask to
     # transformers, decoder.py:349-361: text rows see the prompt rows, prompt rows see their predecessors) instead of the two
     # independent segments the nanoGPT decoder's mask leaves (vision_encoder_decoder.py:84-113)
-    def decode_prefixed(self, B: int, T: int, enc_out, mem_bf, save: bool, ids, dropout_without_save: bool = False):
+    def decode_prefixed(self, B: int, T: int, enc_out, mem_bf, save: bool, ids, dropout_without_save: bool = False, text_mask=None):
         """ids [B, T] after the n_p = min(n_cls, block) encoder outputs.  Returns (hidden fp32 [B, n_p + T, d], bf16 hidden of the
-        text rows [B * T, d], ctx)."""
+        text rows [B * T, d], ctx).  text_mask (bool [B, T], a prefix of every row True: the live text positions of a training step,
+        wrapper._pack_rows): the sequences are packed -- n_p + len_b rows each -- and both outputs hold the packed rows only."""
         a, dc = self.arena, self.dec
         ncls = enc_out.shape[1]
         n_p = min(ncls, dc.block)
@@ -827,11 +831,25 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             tok = self._empty(B * T, dc.d)
             ops.embed_fwd(ids, a.P(self.n_wte), None, tok, B, T, dc.d, 0, dc.V)
             emb[:, n_p:].copy_(tok.view(B, T, dc.d))
+        if text_mask is not None:
+            full = torch.cat((torch.ones(B, n_p, dtype=torch.bool, device=a.device), text_mask[:, :T]), dim=1)
+            lens = full.sum(dim=1)
+            cu = torch.zeros(B + 1, dtype=torch.int32, device=a.device)
+            cu[1:] = torch.cumsum(lens, 0)
+            pos = torch.arange(n_p + T, dtype=torch.int32, device=a.device).expand(B, n_p + T)[full].contiguous()
+            vl = SimpleNamespace(cu=cu, pos=pos, total=int(pos.numel()), mask=full)
+            is_text = pos >= n_p
+            hid, hb, ctx = self.decode_segment(B, n_p + T, mem_bf, ncls, save, embeds=emb[full], pos_offset=0, vl=vl,
+                                               dropout_without_save=dropout_without_save)
+            hb_text = hb[is_text]
+            if ctx is not None:
+                ctx.prefixed = SimpleNamespace(ids=ids[text_mask[:, :T]].contiguous(), n_p=n_p, T=T, hb_text=hb_text, is_text=is_text)
+            return hid, hb_text, ctx
         hid, hb, ctx = self.decode_segment(B, n_p + T, mem_bf, ncls, save, embeds=emb.view(B * (n_p + T), dc.d), pos_offset=0,
                                            dropout_without_save=dropout_without_save)
         hb_text = hb.view(B, n_p + T, dc.d)[:, n_p:].contiguous().view(B * T, dc.d)
         if ctx is not None:
-            ctx.prefixed = SimpleNamespace(ids=ids, n_p=n_p, T=T, hb_text=hb_text)
+            ctx.prefixed = SimpleNamespace(ids=ids, n_p=n_p, T=T, hb_text=hb_text, is_text=None)
         return hid.view(B, n_p + T, dc.d), hb_text, ctx
 
     def decode_prefixed_backward(self, ctx, dlogits_bf, dhid, dmem):
@@ -840,6 +858,20 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         a, dc, px = self.arena, self.dec, ctx.prefixed
         B, n_p, T, d = ctx.B, px.n_p, px.T, dc.d
         wte, head = self.n_wte, self.n_head
+        if px.is_text is not None:        # packed rows (training step): dlogits_bf covers the packed text rows, dhid is not offered
+            assert dhid is None
+            Mt = int(px.hb_text.shape[0])
+            dh = torch.zeros(ctx.M, d, dtype=F32, device=a.device)
+            if dlogits_bf is not None and Mt:
+                ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, Mt, a_kmajor=True, b_kmajor=True, accumulate=True)
+                dht = self._empty(Mt, d)
+                ops.gemm(dlogits_bf, a.W(head), dht, Mt, d, dc.V, b_kmajor=True)
+                dh[px.is_text] = dht
+            dx = self.decode_backward(ctx, None, dh, dmem)
+            dmem.view(B, -1, d)[:, :n_p] += dx[~px.is_text].view(B, n_p, d)
+            if Mt:
+                ops.embed_bwd(px.ids, dx[px.is_text].contiguous(), a.G(wte), None, Mt, 1, d, 0, dc.V)
+            return
         dh = torch.zeros(B, n_p + T, d, dtype=F32, device=a.device) if dhid is None else dhid.to(F32).reshape(B, n_p + T, d).clone()
         if dlogits_bf is not None and T:
             ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
@@ -957,5 +989,8 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             return None
         if dc.advpos:
             return self.posmlp_bwd(ctx.pos_ctx, dx)
+        if ctx.vl is not None:
+            a.G(f'{self.dp}transformer.wpe.weight').index_add_(0, ctx.vl.pos.long() + ctx.pos_offset, dx)
+            return dx
         ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)
         return dx

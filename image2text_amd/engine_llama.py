@@ -58,19 +58,22 @@ class LlamaBlocks:
         return t
 
     # ------------------------------------------------------------------------------------------------ one block
-    def llama_block_fwd(self, l: int, x, B: int, T: int, pos_offset: int, save: bool):
+    def llama_block_fwd(self, l: int, x, B: int, T: int, pos_offset: int, save: bool, vl=None):
+        """vl: packed variable-length rows (cu, pos, total) -- x is [total, d], T the longest sequence"""
         ls, v = self.dec.llama, self._llama_views(l)
-        M, d, H, G, hd, ff = B * T, ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        M, d, H, G, hd, ff = (vl.total if vl is not None else B * T), ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
         cs = self.rope_table()
         n1, r1 = self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
         qkv = self._empty(M, v.nq, dtype=BF16)
         ops.gemm(n1, v.Wqkv, qkv, M, v.nq, d, bias=v.bqkv)
-        ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos_offset=pos_offset, T=T)         # q heads and k heads are adjacent columns
-        q3 = qkv.view(B, T, v.nq)
+        ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos=rpos, pos_offset=pos_offset, T=T)      # q heads and k heads are adjacent columns
+        q3 = v3(qkv, v.nq)
         ao, lse = self._empty(M, H * hd, dtype=BF16), self._empty(H * M)
-        ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], ao.view(B, T, H * hd), lse,
-                             B, H, G, hd, T, T, True)
+        ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], v3(ao, H * hd), lse,
+                             B, H, G, hd, T, T, True, cu_q=cu, cu_k=cu, total_q=M)
         x1 = self._empty(M, d)
         ops.gemm(ao, v.Wo, x1, M, d, H * hd, residual=x)
         n2, r2 = self._empty(M, d, dtype=BF16), self._empty(M)
@@ -83,10 +86,12 @@ class LlamaBlocks:
         ops.gemm(h, v.Wdn, x2, M, d, ff, residual=x1)
         return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h) if save else None)
 
-    def llama_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int):
+    def llama_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int, vl=None):
         """dx fp32 / dxb bf16: gradient w.r.t. the block output; on return both hold the gradient w.r.t. the block input"""
         ls, v = self.dec.llama, self._llama_views(l)
-        M, d, H, G, hd, ff = B * T, ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        M, d, H, G, hd, ff = (vl.total if vl is not None else B * T), ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
         # ---- MLP
         ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dh = self._empty(M, ff, dtype=BF16)
@@ -102,11 +107,12 @@ class LlamaBlocks:
         dao = self._empty(M, H * hd, dtype=BF16)
         ops.gemm(dxb, v.Wo, dao, M, H * hd, d, b_kmajor=True)
         dqkv = self._empty(M, v.nq, dtype=BF16)
-        q3, g3 = sv.qkv.view(B, T, v.nq), dqkv.view(B, T, v.nq)
+        q3, g3 = v3(sv.qkv, v.nq), v3(dqkv, v.nq)
         sl = (slice(0, H * hd), slice(H * hd, (H + G) * hd), slice((H + G) * hd, v.nq))
-        ops.gq_attention_bwd(q3[..., sl[0]], q3[..., sl[1]], q3[..., sl[2]], sv.ao.view(B, T, H * hd), dao.view(B, T, H * hd), sv.lse,
-                             self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True)
-        ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos_offset=pos_offset, T=T, inverse=True)
+        ops.gq_attention_bwd(q3[..., sl[0]], q3[..., sl[1]], q3[..., sl[2]], v3(sv.ao, H * hd), v3(dao, H * hd), sv.lse,
+                             self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True,
+                             cu_q=cu, cu_k=cu, total_q=M)
+        ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos=rpos, pos_offset=pos_offset, T=T, inverse=True)
         if v.gbqkv is not None:
             ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
         ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
@@ -116,24 +122,25 @@ class LlamaBlocks:
     # ------------------------------------------------------------------------------------------------ the decoder stack
     def llama_decode_fwd(self, B: int, T: int, save: bool, ids, embeds, pos_offset: int, vl):
         """decode_segment for these decoders: (hidden fp32 [M, d] after the final norm, its bf16 copy, ctx)"""
-        if vl is not None:
-            raise NotImplementedError('packed variable-length rows are not wired for the Llama-2 / Qwen2 decoders')
         a, dc, ls = self.arena, self.dec, self.dec.llama
-        d, M = dc.d, B * T
+        d, M = dc.d, (vl.total if vl is not None else B * T)
         if ids is not None:
             ids = ids.to(device=a.device, dtype=torch.long).contiguous()
             x = self._empty(M, d)
-            ops.embed_fwd(ids, a.P(self.n_wte), None, x, B, T, d, 0, dc.V)
+            if vl is not None:
+                ops.embed_fwd(ids, a.P(self.n_wte), None, x, M, 1, d, 0, dc.V)
+            else:
+                ops.embed_fwd(ids, a.P(self.n_wte), None, x, B, T, d, 0, dc.V)
         else:
             x = embeds.to(device=a.device, dtype=F32).contiguous().view(M, d)
         saves, cur = [], x
         for l in range(dc.L):
-            cur, sv = self.llama_block_fwd(l, cur, B, T, pos_offset, save)
+            cur, sv = self.llama_block_fwd(l, cur, B, T, pos_offset, save, vl)
             saves.append(sv)
         wn = a.P(f'{self.dp}backbone.model.norm.weight')
         hid, hb, rf = self._empty(M, d), self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(cur, wn, hb, rf, M, d, ls.eps, y_f32=hid)
-        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, rf=rf, hb=hb, B=B, T=T, S=0, pos_offset=pos_offset, vl=None, M=M,
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, rf=rf, hb=hb, B=B, T=T, S=0, pos_offset=pos_offset, vl=vl, M=M,
                               emb_drop=None, pos_ctx=None) if save else None
         return hid, hb, ctx
 
@@ -145,5 +152,5 @@ class LlamaBlocks:
         wn = f'{self.dp}backbone.model.norm.weight'
         ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn), ctx.rf, dx, a.G(wn), M, d, dx_bf16=dxb)
         for l in reversed(range(dc.L)):
-            self.llama_block_bwd(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset)
+            self.llama_block_bwd(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset, ctx.vl)
         return dx

@@ -39,10 +39,15 @@ class _LMLossFunction(torch.autograd.Function):
         off = ncls if cfg.use_soft_prompting else 0
         T = min(L, eng.dec.block - off)
         if eng.dec.prefixed:       # Hugging Face decoder + soft prompt: one causal sequence [encoder outputs | text] (engine.decode_prefixed)
-            M = B * T
-            lab, w = labels[:, :T].contiguous().view(M), weights[:, :T].contiguous().view(M)
-            _, hb, dctx = eng.decode_prefixed(B, T, enc_out, mem, save, ids)
-            logits = eng.logits_bf16(hb, M, capacity=M)
+            tvl = wrapper._pack_rows(labels[:, :T], B, T) if wrapper.pack_rows else None
+            if tvl is not None:     # rows past a caption's last label are dead (causal, zero loss weight): n_p + len_b rows per sequence
+                M = tvl.total
+                lab, w = labels[:, :T][tvl.mask].contiguous(), weights[:, :T][tvl.mask].contiguous()
+            else:
+                M = B * T
+                lab, w = labels[:, :T].contiguous().view(M), weights[:, :T].contiguous().view(M)
+            _, hb, dctx = eng.decode_prefixed(B, T, enc_out, mem, save, ids, text_mask=tvl.mask if tvl is not None else None)
+            logits = eng.logits_bf16(hb, M, capacity=B * T)
             lse = torch.empty(M, dtype=F32, device=a.device)
             loss = torch.zeros(1, dtype=F32, device=a.device)
             inv_t = 1.0 / wrapper.temperature

@@ -300,14 +300,26 @@ def test_llama_family_decoder_forward_gradients_generate(tmp_path, monkeypatch, 
     w = w.to(dev()).train()
     loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
     loss.backward()
+    assert w.pack_rows                                   # ragged captions: the step runs on packed rows (n_p + len_b per sequence)
     sids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
-    with torch.no_grad():
-        _, sl, _ = _llama_reference(orc, esd, hf, cfg, images, sids)
+    for t in list(esd.values()) + list(hf.parameters()):
+        t.grad = None
+    _, sl, _ = _llama_reference(orc, esd, hf, cfg, images, sids)
     ce = F.cross_entropy(sl.reshape(-1, V), labels.reshape(-1), ignore_index=-100, reduction='none')
-    oloss = float((ce * orc.loss_weights(labels, -100).reshape(-1)).sum())
+    oloss_t = (ce * orc.loss_weights(labels, -100).reshape(-1)).sum()
+    oloss_t.backward()
+    oloss = float(oloss_t.detach())
     REPORT[f'{tag}.train_loss'] = {'got': float(loss.detach()), 'ref': oloss}
     assert abs(float(loss.detach()) - oloss) <= 1e-2 * oloss
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in w.model.parameters())
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.backbone.' + k: p.grad for k, p in hf.named_parameters()})
+    fails = []
+    for name, p in w.model.named_parameters():
+        try:
+            grad_close(f'{tag}.step.{name}', p.grad, ref_grads[name].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} train-step gradients out of tolerance: ' + '; '.join(fails[:6])
     # generation
     w.eval()
     with torch.no_grad():
