@@ -64,20 +64,22 @@ class DropPlan:
     emb = embedding dropout (decoder.py:243, encoder.py:171); qkv = per-token q/k/v multipliers (layers.py:454-461,
     rate attn_dropout); sdpa = dropout_p of the self-attention probabilities (layers.py:465); resid = after attn.c_proj
     (layers.py:469); xattn = nn.MultiheadAttention's attention-weight dropout (layers.py:537-542); mlp = after
-    mlp.c_proj (layers.py:485).  The same plan object is kept in the saved context and re-evaluated in backward."""
-    KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5}
+    mlp.c_proj (layers.py:485); xresid = after the cross-attention output projection -- transformers' GPT-2 only (its
+    crossattention ends in resid_dropout like its self-attention; nn.MultiheadAttention has no such site), ``xresid=True``.
+    The same plan object is kept in the saved context and re-evaluated in backward."""
+    KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5, 'xresid': 6}
 
-    def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0):
+    def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0, xresid: bool = False):
         """compact_layer / live_rows: in that layer only the first ``live_rows`` rows of every sequence are computed after
         the K/V projections (the encoder's last block: only its CLS rows are ever read), so its sdpa / resid / mlp masks are
         indexed over those rows alone; ``get`` then appends live_rows to the tuple so that a full-row consumer (the oracle)
         can place the mask (rows past live_rows are dead, any mask does)."""
         self.seed, self.tower, self.p, self.p_attn = seed, tower, p, p_attn
-        self.compact_layer, self.live_rows = compact_layer, live_rows
+        self.compact_layer, self.live_rows, self.xresid = compact_layer, live_rows, xresid
 
     def get(self, layer: int, kind: str):
         p = self.p_attn if kind == 'qkv' else self.p
-        if p <= 0.0:
+        if p <= 0.0 or (kind == 'xresid' and not self.xresid):
             return None
         site = self.tower * 4096 + layer * 16 + self.KINDS[kind]
         e = (2 if kind == 'qkv' else 1, rng.site_key(self.seed, site), rng.threshold(p), rng.scale(rng.threshold(p)))
@@ -379,8 +381,9 @@ class HotPath(FamilyBlocks, LlamaBlocks):
                 self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout,
                                          compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
             if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
-                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout)
-                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout)
+                hf_sites = hasattr(self.model.decoder, 'hot_config')          # transformers' GPT-2: resid_dropout after crossattention.c_proj
+                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites)
+                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites)
         return self.arena
 
     @property
@@ -407,7 +410,7 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         M = vl.total if vl is not None else B * T
         cu = vl.cu if vl is not None else None
         v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))      # attention operand views
-        dr = {k: (plan.get(layer, k) if plan is not None else None) for k in ('qkv', 'sdpa', 'resid', 'xattn', 'mlp')}
+        dr = {k: (plan.get(layer, k) if plan is not None else None) for k in ('qkv', 'sdpa', 'resid', 'xattn', 'mlp', 'xresid')}
         sv = SimpleNamespace(x=x, cross=False, dr=dr)
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
@@ -443,7 +446,7 @@ class HotPath(FamilyBlocks, LlamaBlocks):
                                   cu_q=cu, total_q=M)
             x2 = self._empty(M, d)
             ops.gemm(co, a.W(f'{pfx}.cross_attn.out_proj.weight'), x2, M, d, d,
-                     bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1)
+                     bias=a.P(f'{pfx}.cross_attn.out_proj.bias'), residual=x1, drop=dr['xresid'])
             sv.cross, sv.ln3, sv.m3, sv.r3, sv.q, sv.kv, sv.co, sv.lse_c, sv.mem = True, ln3, m3, r3, q, kv, co, lse_c, mem_bf
         ln2, m2, r2 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x2, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, M, d)
@@ -489,7 +492,7 @@ class HotPath(FamilyBlocks, LlamaBlocks):
                          dx_out=dln)
         ops.layernorm_bwd(dln, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.G(f'{pfx}.ln_2.weight'),
                           a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb,
-                          bf16_drop=None if sv.cross else dr['resid'],      # next consumer of dxb: attn.c_proj backward
+                          bf16_drop=dr.get('xresid') if sv.cross else dr['resid'],      # next consumer of dxb: the (cross-)attention output projection's backward
                           dx_pre_sumsq=dx_pre)                              # first fp32 use of dx in the block
         # ---- cross attention: x2 = x1 + out_proj(attn(q(ln_3 x1), kv(mem)))
         if sv.cross:

@@ -170,7 +170,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
     The state dict keeps the reference's names and layout (``backbone.transformer.h.N.attn.c_attn.weight`` as Conv1D ``[in, out]``,
     ``crossattention.q_attn`` / ``c_attn`` / ``c_proj``, ``ln_cross_attn``, ``backbone.lm_head.weight``), so checkpoints travel in both
     directions.  As in the reference the attention mask is ignored (always causal, decoder.py:349-350), ``block_size`` is the
-    checkpoint's 1024 positions and the decoder's dropout rates are the checkpoint's (``resid_pdrop`` for residual and embedding dropout, ``attn_pdrop``)."""
+    checkpoint's 1024 positions and the decoder's dropout rate is the checkpoint's (``resid_pdrop`` = ``embd_pdrop`` = ``attn_pdrop``, as in every GPT-2 release) at
+    transformers' sites: embeddings, attention probabilities, after every ``c_proj`` (cross-attention's included)."""
 
     _CONV1D = ('attn.c_attn.weight', 'attn.c_proj.weight', 'mlp.c_fc.weight', 'mlp.c_proj.weight')
 
@@ -194,7 +195,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
             (hc.activation_function not in ('gelu_new', 'gelu_pytorch_tanh'), f'activation {hc.activation_function!r}'),
             (abs(hc.layer_norm_epsilon - 1e-5) > 1e-12, f'layer_norm_epsilon {hc.layer_norm_epsilon}'),
             (not hc.scale_attn_weights or hc.scale_attn_by_inverse_layer_idx, 'attention scaling other than 1/sqrt(head_dim)'),
-            (abs(hc.embd_pdrop - hc.resid_pdrop) > 1e-12, 'embd_pdrop != resid_pdrop'),
+            (abs(hc.embd_pdrop - hc.resid_pdrop) > 1e-12 or abs(hc.attn_pdrop - hc.resid_pdrop) > 1e-12,
+             'embd_pdrop / attn_pdrop != resid_pdrop (one rate drives the embedding, residual and attention-probability sites)'),
         ) if bad]
         if problems:
             raise NotImplementedError('GPT-2 checkpoint outside the HIP hot path: ' + '; '.join(problems))
@@ -204,8 +206,10 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
             enable_gradient_checkpointing=config.enable_gradient_checkpointing,
             transformer_config=TransformerConfig(
                 rotator_config=MLPConfig(ff_mult=n_inner / hc.n_embd), is_causal=True, is_cross_attn=bool(config.use_cross_attn),
+                # dropout sites of transformers' GPT-2: embeddings, attention probabilities (self and cross), after every c_proj;
+                # attn_dropout = 0: the per-token q / k / v multipliers of the reference's own attention (layers.py:454-461) do not exist here
                 attn_config=SelfAttentionConfig(n_head=hc.n_head, n_embd=hc.n_embd, bias=True, dropout=hc.resid_pdrop,
-                                                attn_dropout=hc.attn_pdrop, attn_type=SelfAttentionType.MULTI_HEAD)),
+                                                attn_dropout=0.0, attn_type=SelfAttentionType.MULTI_HEAD)),
             skip_alternate_cross_attn=False)
         super().__init__(hot, space_for_prompt)
         self.hot_config = hot               # what the HIP engine reads in place of VisionEncoderDecoderConfig.decoder_config

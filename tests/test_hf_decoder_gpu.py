@@ -401,3 +401,36 @@ def test_llama_row_kernels():
     ops.swiglu_bwd(dh, gu, dgu, M, ff)
     assert float((h.float() - hr.detach()).abs().max()) < 2e-2 * float(hr.abs().max())
     assert float((dgu.float() - gr.grad).abs().max()) < 2e-2 * float(gr.grad.abs().max())
+
+
+def test_gpt2_hf_decoder_dropout_sites_train_mode(tmp_path, monkeypatch):
+    """a checkpoint with resid_pdrop = embd_pdrop = attn_pdrop = 0.1: the train step draws masks at transformers' sites (the DropPlan
+    carries the cross-attention residual site, the per-token q/k/v multipliers of the nanoGPT block are off), is reproducible under
+    torch.manual_seed, differs from the eval-mode loss, and back-propagates finite gradients; unequal rates are refused by name"""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.models.decoder import Decoder
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    _local_hf_gpt2(tmp_path, monkeypatch, resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.1)
+    cfg = _model_config(True, True)
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(384), TrainerWrapperConfig(), ignore_index=-100).to(dev()).train()
+    eng = w.model._engine
+    assert eng.dec.dropout == 0.1 and eng.dec.attn_dropout == 0.0
+    images, labels = synthetic_batch(4, 32, 14, 384, seed=5)
+    images, labels = images.to(dev()), labels.to(dev())
+    losses = []
+    for seed in (3, 3, 4):
+        torch.manual_seed(seed)
+        loss, _ = w.train_step(images, labels)
+        losses.append(float(loss.detach()))
+    plan = eng.dec_drop
+    assert plan.get(0, 'xresid') is not None and plan.get(0, 'qkv') is None and plan.get(0, 'sdpa') is not None
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in w.model.parameters())
+    w.eval()
+    with torch.no_grad():
+        vloss, _ = w.val_step(images, labels)
+    assert losses[0] == losses[1] and losses[0] != losses[2] and abs(losses[0] - float(vloss)) > 1e-4
+    assert abs(losses[0] - float(vloss)) < 0.2 * float(vloss)
+    _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-uneven', resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.0)
+    with pytest.raises(NotImplementedError, match='pdrop'):
+        Decoder.from_config(_hf_decoder_config(name='gpt2-uneven'))
