@@ -418,7 +418,7 @@ def test_gpt2_hf_decoder_dropout_sites_train_mode(tmp_path, monkeypatch):
     images, labels = synthetic_batch(4, 32, 14, 384, seed=5)
     images, labels = images.to(dev()), labels.to(dev())
     losses = []
-    for seed in (3, 3, 4):
+    for seed in (3, 4, 3):        # a change of torch's seed restarts the step-seed sequence (engine.prepare)
         torch.manual_seed(seed)
         loss, _ = w.train_step(images, labels)
         losses.append(float(loss.detach()))
@@ -429,7 +429,7 @@ def test_gpt2_hf_decoder_dropout_sites_train_mode(tmp_path, monkeypatch):
     w.eval()
     with torch.no_grad():
         vloss, _ = w.val_step(images, labels)
-    assert losses[0] == losses[1] and losses[0] != losses[2] and abs(losses[0] - float(vloss)) > 1e-4
+    assert losses[0] == losses[2] and losses[0] != losses[1] and abs(losses[0] - float(vloss)) > 1e-4
     assert abs(losses[0] - float(vloss)) < 0.2 * float(vloss)
     _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-uneven', resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.0)
     with pytest.raises(NotImplementedError, match='pdrop'):
