@@ -237,6 +237,15 @@ class GreedyDecoder:
                                  sampling.temperature, sampling.top_k, sampling.nucleus_p, st.seed, dist_out=st.dist)
         ops.advance(st.counters, 1)                            # pos and len together
 
+    def _w(self, l: int, site: str, name: str, rows=None):
+        """bf16 weight of a decoder linear for the decode step: the arena's shadow, or -- under a LoRA adapter -- the merged
+        W + s B A in its persistent buffer (engine_lora.py; generation has no dropout, so merging is exact)"""
+        eng = self.eng
+        if eng._lora_site(l, site) is not None:
+            return eng.lora_merged(l, site, name, rows)
+        w = eng.arena.W(name)
+        return w if rows is None else w[rows]
+
     def _layers_dense(self, st):
         """The decoder blocks of one decode step for the dense multi-head model (64-wide heads, GELU-MLP)."""
         eng, a, dc = self.eng, self.eng.arena, self.eng.dec
@@ -246,7 +255,7 @@ class GreedyDecoder:
         for l in range(dc.L):
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
-            ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
+            ops.gemm(st.ln, self._w(l, 'attn_c_attn', f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
             ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.clen * d, 64, st.ao, d, pos_ptr, 0, B, H, append_dm=d,
                                  cache_hs=st.clen * 64)           # head-major self-attention cache [B][H][prefix + tmax][64]
             ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
@@ -259,8 +268,8 @@ class GreedyDecoder:
                 ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), st.x, B, d, d,
                          bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=st.x)
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
-            ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
-            ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
+            ops.gemm(st.ln, self._w(l, 'mlp_c_fc', f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
+            ops.gemm(st.h, self._w(l, 'mlp_c_proj', f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
 
     def _layers_llama(self, st):
         """The Llama-2 / Qwen2 blocks of one decode step (engine_llama.py): the rotary angle is looked up at the position counter on
@@ -326,13 +335,22 @@ class GreedyDecoder:
                 enc_out[i:i + ENC_CHUNK].copy_(part)
                 del part
         S = enc_out.shape[1]
+        if getattr(dc, 'lora', None) is not None:              # merged adapter weights follow the current parameters
+            for l in range(dc.L):
+                p = f'{eng.dp}transformer.h.{l}'
+                for site, name, rows in (('attn_c_attn', f'{p}.attn.c_attn.weight', None), ('mlp_c_fc', f'{p}.mlp.c_fc.weight', None),
+                                         ('mlp_c_proj', f'{p}.mlp.c_proj.weight', None),
+                                         ('xattn_c_attn', f'{p}.cross_attn.in_proj_weight', slice(dc.d, 3 * dc.d))):
+                    if site != 'xattn_c_attn' or l in st.cross_kv:
+                        self._w(l, site, name, rows)
+            eng.refresh_lora_merged()
         if st.cross_kv:
             assert S == next(iter(st.cross_kv.values()))[1]
             mem = eng._mem_bf16(enc_out)
             for l, (kv, _) in st.cross_kv.items():              # persistent buffers: captured graphs bake their pointers
                 p = f'{eng.dp}transformer.h.{l}.cross_attn'
-                ops.gemm(mem, a.W(f'{p}.in_proj_weight')[dc.d:], kv.view(B * S, 2 * dc.d), B * S, 2 * dc.d, dc.d,
-                         bias=a.P(f'{p}.in_proj_bias')[dc.d:])
+                ops.gemm(mem, self._w(l, 'xattn_c_attn', f'{p}.in_proj_weight', slice(dc.d, 3 * dc.d)), kv.view(B * S, 2 * dc.d), B * S,
+                         2 * dc.d, dc.d, bias=a.P(f'{p}.in_proj_bias')[dc.d:])
         if st.prefix:       # the prompt rows' keys and values (one causal pass over the encoder outputs) open every caption's cache
             n_p = st.prefix
             _, _, pctx = eng.decode_segment(B, n_p, eng._mem_bf16(enc_out) if eng.cross_inputs else None, S, True,

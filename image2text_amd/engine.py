@@ -40,6 +40,7 @@ import torch
 from . import ops, rng
 from .engine_family import FamilyBlocks, family_spec
 from .engine_llama import LlamaBlocks
+from .engine_lora import LoraAdapters
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -65,20 +66,23 @@ class DropPlan:
     rate attn_dropout); sdpa = dropout_p of the self-attention probabilities (layers.py:465); resid = after attn.c_proj
     (layers.py:469); xattn = nn.MultiheadAttention's attention-weight dropout (layers.py:537-542); mlp = after
     mlp.c_proj (layers.py:485); xresid = after the cross-attention output projection -- transformers' GPT-2 only (its
-    crossattention ends in resid_dropout like its self-attention; nn.MultiheadAttention has no such site), ``xresid=True``.
+    crossattention ends in resid_dropout like its self-attention; nn.MultiheadAttention has no such site), ``xresid=True``;
+    lora_<site> = the input dropout of a LoRA adapter (peft's lora_dropout, rate ``p_lora``).
     The same plan object is kept in the saved context and re-evaluated in backward."""
-    KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5, 'xresid': 6}
+    KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5, 'xresid': 6, 'lora_attn_c_attn': 7, 'lora_xattn_c_attn': 8,
+             'lora_mlp_c_fc': 9, 'lora_mlp_c_proj': 10}
 
-    def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0, xresid: bool = False):
+    def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0, xresid: bool = False,
+                 p_lora: float = 0.0):
         """compact_layer / live_rows: in that layer only the first ``live_rows`` rows of every sequence are computed after
         the K/V projections (the encoder's last block: only its CLS rows are ever read), so its sdpa / resid / mlp masks are
         indexed over those rows alone; ``get`` then appends live_rows to the tuple so that a full-row consumer (the oracle)
         can place the mask (rows past live_rows are dead, any mask does)."""
         self.seed, self.tower, self.p, self.p_attn = seed, tower, p, p_attn
-        self.compact_layer, self.live_rows, self.xresid = compact_layer, live_rows, xresid
+        self.compact_layer, self.live_rows, self.xresid, self.p_lora = compact_layer, live_rows, xresid, p_lora
 
     def get(self, layer: int, kind: str):
-        p = self.p_attn if kind == 'qkv' else self.p
+        p = self.p_attn if kind == 'qkv' else (self.p_lora if kind.startswith('lora_') else self.p)      # lora_*: the adapters' input dropout
         if p <= 0.0 or (kind == 'xresid' and not self.xresid):
             return None
         site = self.tower * 4096 + layer * 16 + self.KINDS[kind]
@@ -102,6 +106,7 @@ def arena_of(param: torch.Tensor):
 
 
 _MOE_PARAM = re.compile(r'^(.*)\.experts\.(\d+)\.(l1|l2)\.(weight|bias)$')
+_LORA_A = re.compile(r'^(.*\.)?lora_params\.h\d+_\w+_A$')
 _QKV_PARAM = re.compile(r'^(.*\.self_attn)\.(q|k|v)_proj\.(weight|bias)$')
 
 
@@ -145,6 +150,9 @@ def _arena_order(named):
             continue
         if p is not None:
             out.append((name, p, p.numel(), p.shape))
+            if _LORA_A.match(name) and p.shape[0] < 64:      # LoRA rank -> 64 zero-padded rows: lora_A is the [64, in] operand of the adapter GEMMs
+                pad = (64 - p.shape[0]) * p.shape[1]
+                out.append((name + '.<pad>', None, pad, torch.Size([pad])))
             continue
         g = groups[name]
         E = 1 + max(int(k.split('.')[1]) for k in g if k.startswith('experts.'))
@@ -214,6 +222,15 @@ class ParamArena:
         e = self.entries.get(name)
         return None if e is None else self.g32[e[0]:e[0] + e[1]].view(e[2])
 
+    def trainable(self, name: str) -> bool:
+        """False for a frozen parameter (requires_grad off, e.g. LoRA's base weights): backward skips its gradient GEMM"""
+        p = self.params.get(name)
+        return p is None or p.requires_grad
+
+    def Gt(self, name: str) -> Optional[torch.Tensor]:
+        """the gradient view of a TRAINABLE parameter, else None (kernels skip null gradient outputs)"""
+        return self.G(name) if self.trainable(name) else None
+
     def span(self, kind: str, names, shape):
         """One view over several ADJACENT entries (e.g. q_proj | k_proj | v_proj weights = the fused projection's [N, K] matrix);
         kind: 'P' fp32 parameters, 'W' bf16 shadow, 'G' fp32 gradients."""
@@ -252,7 +269,7 @@ def decoder_hot_config(model):
     return getattr(model.decoder, 'hot_config', None) or model.config.decoder_config
 
 
-class HotPath(FamilyBlocks, LlamaBlocks):
+class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
     """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
 
     def __init__(self, model: torch.nn.Module):
@@ -298,9 +315,13 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             self.dec.prefixed = hasattr(model.decoder, 'hot_config') and bool(self.cfg.use_soft_prompting)     # see decode_prefixed
             self.dec.advpos = bool(dcfg.use_advanced_pos_emb)       # decoder.wpe = one MLP per position (layers.py:617-638)
             self.n_wte = self.n_head = f'{self.dp}transformer.wte.weight'      # token embedding / lm_head weight (tied, decoder.py:189-204)
+            self.dec.lora = getattr(model.decoder, 'lora', None)              # LoRA adapters on a GPT2HuggingfaceDecoder (engine._lora_*)
+            if self.dec.lora is not None and self.dec.fam is not None:
+                raise NotImplementedError('LoRA adapters run on the dense decoder blocks only')
         self._sparse_idx, self._sparse_versions, self.sparse_epoch = {'enc': None, 'dec': None}, None, 0
         self._refresh_sparse_sets()
         self._moe_cache, self._sub_cache = {}, {}
+        self._lora_merge_list = []
         self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
         gates = list(ecfg.feature_extractor_gate_sizes or [])
         chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
@@ -365,6 +386,7 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             self._logits_cache.clear()
             self._moe_cache.clear()
             self._sub_cache.clear()
+            self._lora_merge_list = []
         self.arena.refresh_shadow()
         self._refresh_sparse_sets()
         self.enc_drop = self.dec_drop = self.dec_drop_prompt = None
@@ -380,10 +402,11 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             if self.enc.dropout > 0 or self.enc.attn_dropout > 0:
                 self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout,
                                          compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
-            if self.dec.dropout > 0 or self.dec.attn_dropout > 0:
+            p_lora = self.dec.lora.p if getattr(self.dec, 'lora', None) is not None else 0.0
+            if self.dec.dropout > 0 or self.dec.attn_dropout > 0 or p_lora > 0:
                 hf_sites = hasattr(self.model.decoder, 'hot_config')          # transformers' GPT-2: resid_dropout after crossattention.c_proj
-                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites)
-                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites)
+                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
+                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
         return self.arena
 
     @property
@@ -415,7 +438,15 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(f'{pfx}.ln_1.weight'), a.P(f'{pfx}.ln_1.bias'), ln1, m1, r1, M, d)
         qkv = self._empty(M, 3 * d, dtype=BF16)
-        ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv, M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'), drop=dr['qkv'])
+        ldrop = (lambda site: plan.get(layer, f'lora_{site}') if plan is not None else None)
+        lo = {site: self._lora_site(layer, site) for site in ('attn_c_attn', 'xattn_c_attn', 'mlp_c_fc', 'mlp_c_proj')} \
+            if (pfx.startswith(self.dp) and getattr(self.dec, 'lora', None) is not None) else {}
+        sv.lo, sv.lo_drop = {}, {site: ldrop(site) for site in lo}
+        if lo.get('attn_c_attn') is not None:      # LoRA: the adapter rides in the GEMM's K panel (engine_lora.py)
+            sv.lo['attn_c_attn'] = self._lora_gemm(lo['attn_c_attn'], ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv, M, ldrop('attn_c_attn'), save,
+                                                   bias=a.P(f'{pfx}.attn.c_attn.bias'), drop=dr['qkv'])
+        else:
+            ops.gemm(ln1, a.W(f'{pfx}.attn.c_attn.weight'), qkv, M, 3 * d, d, bias=a.P(f'{pfx}.attn.c_attn.bias'), drop=dr['qkv'])
         ao, lse = self._empty(M, d, dtype=BF16), self._empty(H * M)
         q3 = v3(qkv, 3 * d)
         ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], v3(ao, d), lse, B, H, T, T, causal, drop=dr['sdpa'],
@@ -435,7 +466,12 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             ops.gemm(ln3, win[:d], q, M, d, d, bias=bin_[:d])
             kv = self._empty(B, S, 2 * d, dtype=BF16)
             co, lse_c = self._empty(M, d, dtype=BF16), self._empty(H * M)
-            if self.xattn_fused and S == 64 and H % 2 == 0 and d == 64 * H:
+            if lo.get('xattn_c_attn') is not None:      # adapted K/V projection: the un-fused form
+                sv.lo['xattn_c_attn'] = self._lora_gemm(lo['xattn_c_attn'], mem_bf, win[d:], kv.view(B * S, 2 * d), B * S, ldrop('xattn_c_attn'),
+                                                        save, bias=bin_[d:])
+                ops.attention_fwd(v3(q, d), kv[..., :d], kv[..., d:], v3(co, d), lse_c, B, H, T, S, False, drop=dr['xattn'],
+                                  cu_q=cu, total_q=M)
+            elif self.xattn_fused and S == 64 and H % 2 == 0 and d == 64 * H:
                 # ONE launch: K/V projection GEMM whose waves run the attention of their (image, head) out of the accumulators
                 # (K and V are written once for the backward pass and never read back here)
                 ops.xattn_kv_fused(mem_bf, win[d:], bin_[d:], v3(q, d), kv, v3(co, d), lse_c, B, S, H, T, drop=dr['xattn'],
@@ -452,20 +488,30 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         ops.layernorm_fwd(x2, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, M, d)
         h = self._empty(M, ff, dtype=BF16)
         pre = self._empty(M, ff, dtype=BF16) if save else None
-        ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+        if lo.get('mlp_c_fc') is not None:
+            sv.lo['mlp_c_fc'] = self._lora_gemm(lo['mlp_c_fc'], ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ldrop('mlp_c_fc'), save,
+                                                bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+        else:
+            ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
         x3 = self._empty(M, d)
-        ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2,
-                 drop=dr['mlp'])
+        if lo.get('mlp_c_proj') is not None:
+            sv.lo['mlp_c_proj'] = self._lora_gemm(lo['mlp_c_proj'], h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, ldrop('mlp_c_proj'), save,
+                                                  bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2, drop=dr['mlp'])
+        else:
+            ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x2,
+                     drop=dr['mlp'])
         sv.x2, sv.ln2, sv.m2, sv.r2, sv.h, sv.pre = x2, ln2, m2, r2, h, pre
+        sv.layer = layer
         return x3, (sv if save else None)
 
     def _linear_bwd(self, dyb, M, N, K, x_bf, wname: str, bname: Optional[str], dx_out=None, **dx_kw):
         """y = x W^T + b with y [M,N], x [M,K], W [N,K]: accumulates dW, db; returns/fills dX when requested."""
         a = self.arena
-        gb = a.G(bname) if bname else None
+        gb = a.Gt(bname) if bname else None
         if gb is not None:
             ops.colsum(dyb, gb, M, N, accumulate=True)
-        ops.gemm(dyb, x_bf, a.G(wname), N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if a.trainable(wname):
+            ops.gemm(dyb, x_bf, a.G(wname), N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         if dx_out is not None:
             ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
         return dx_out
@@ -485,13 +531,26 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         # ---- MLP: x3 = x2 + drop(c_proj(gelu(c_fc(ln_2 x2)))).  dxb arrives already masked with the MLP dropout (the
         # producer of the bf16 copy applies it: the branch sees the masked gradient, dx -- the residual path -- does not)
         dpre = self._empty(M, ff, dtype=BF16)
-        self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
-                         dx_out=dpre, act=2, aux_in=sv.pre)
+        svlo = getattr(sv, 'lo', None) or {}
+        lsite = (lambda site: self._lora_site(sv.layer, site))
+        ldrop = (lambda site: sv.lo_drop.get(site))          # the adapter's input-dropout mask of the forward pass
+        if svlo.get('mlp_c_proj') is not None:        # LoRA (engine_lora.py): fp32 dh = dY . W + dropout(du . A), then the GELU derivative
+            dh32 = self._lora_bwd(lsite('mlp_c_proj'), svlo['mlp_c_proj'], dxb, sv.h, a.W(f'{pfx}.mlp.c_proj.weight'),
+                                  a.Gt(f'{pfx}.mlp.c_proj.weight'), a.Gt(f'{pfx}.mlp.c_proj.bias'), M, ldrop('mlp_c_proj'))
+            ops.dgelu_mul(dh32, sv.pre, dpre)
+        else:
+            self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
+                             dx_out=dpre, act=2, aux_in=sv.pre)
         dln = self._empty(M, d, dtype=BF16)
-        self._linear_bwd(dpre, M, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', f'{pfx}.mlp.c_fc.bias' if a.G(f'{pfx}.mlp.c_fc.bias') is not None else None,
-                         dx_out=dln)
-        ops.layernorm_bwd(dln, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.G(f'{pfx}.ln_2.weight'),
-                          a.G(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb,
+        dln2 = dln
+        if svlo.get('mlp_c_fc') is not None:
+            dln2 = self._lora_bwd(lsite('mlp_c_fc'), svlo['mlp_c_fc'], dpre, sv.ln2, a.W(f'{pfx}.mlp.c_fc.weight'),
+                                  a.Gt(f'{pfx}.mlp.c_fc.weight'), a.Gt(f'{pfx}.mlp.c_fc.bias'), M, ldrop('mlp_c_fc'))
+        else:
+            self._linear_bwd(dpre, M, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', f'{pfx}.mlp.c_fc.bias' if a.G(f'{pfx}.mlp.c_fc.bias') is not None else None,
+                             dx_out=dln)
+        ops.layernorm_bwd(dln2, sv.x2, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dx, a.Gt(f'{pfx}.ln_2.weight'),
+                          a.Gt(f'{pfx}.ln_2.bias'), M, d, dx_accumulate=True, dx_bf16=dxb,
                           bf16_drop=dr.get('xresid') if sv.cross else dr['resid'],      # next consumer of dxb: the (cross-)attention output projection's backward
                           dx_pre_sumsq=dx_pre)                              # first fp32 use of dx in the block
         # ---- cross attention: x2 = x1 + out_proj(attn(q(ln_3 x1), kv(mem)))
@@ -505,14 +564,24 @@ class HotPath(FamilyBlocks, LlamaBlocks):
             ops.attention_bwd(v3(sv.q, d), sv.kv[..., :d], sv.kv[..., d:], v3(sv.co, d), v3(dco, d), sv.lse_c, ws, v3(dq, d),
                               dkv[..., :d], dkv[..., d:], B, H, T, S, False, drop=dr['xattn'], cu_q=cu, total_q=M)
             dqf, dkvf = dq, dkv.view(B * S, 2 * d)
-            ops.colsum(dqf, gbin[:d], M, d, accumulate=True)
-            ops.gemm(dqf, sv.ln3, gin[:d], d, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            train_in, train_inb = a.trainable(f'{pfx}.cross_attn.in_proj_weight'), a.trainable(f'{pfx}.cross_attn.in_proj_bias')
+            if train_inb:
+                ops.colsum(dqf, gbin[:d], M, d, accumulate=True)
+            if train_in:
+                ops.gemm(dqf, sv.ln3, gin[:d], d, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
             ops.gemm(dqf, win[:d], dln, M, d, d, b_kmajor=True)
-            ops.colsum(dkvf, gbin[d:], B * S, 2 * d, accumulate=True)
-            ops.gemm(dkvf, sv.mem, gin[d:], 2 * d, d, B * S, a_kmajor=True, b_kmajor=True, accumulate=True)
-            ops.gemm(dkvf, win[d:], dmem, B * S, d, 2 * d, b_kmajor=True, accumulate=True)
-            ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_3.weight'), sv.m3, sv.r3, dx, a.G(f'{pfx}.ln_3.weight'),
-                              a.G(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb, bf16_drop=dr['resid'])
+            if svlo.get('xattn_c_attn') is not None:
+                dmem32 = self._lora_bwd(lsite('xattn_c_attn'), svlo['xattn_c_attn'], dkvf, sv.mem, win[d:], gin[d:] if train_in else None,
+                                        gbin[d:] if train_inb else None, B * S, ldrop('xattn_c_attn'))
+                ops.add_(dmem, dmem32)
+            else:
+                if train_inb:
+                    ops.colsum(dkvf, gbin[d:], B * S, 2 * d, accumulate=True)
+                if train_in:
+                    ops.gemm(dkvf, sv.mem, gin[d:], 2 * d, d, B * S, a_kmajor=True, b_kmajor=True, accumulate=True)
+                ops.gemm(dkvf, win[d:], dmem, B * S, d, 2 * d, b_kmajor=True, accumulate=True)
+            ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_3.weight'), sv.m3, sv.r3, dx, a.Gt(f'{pfx}.ln_3.weight'),
+                              a.Gt(f'{pfx}.ln_3.bias'), M, d, dx_accumulate=True, dx_bf16=dxb, bf16_drop=dr['resid'])
         # ---- self attention: x1 = x + drop(c_proj(attn(mult * c_attn(ln_1 x)))); dxb carries the resid-dropout mask
         dao = self._empty(M, d, dtype=BF16)
         self._linear_bwd(dxb, M, d, d, sv.ao, f'{pfx}.attn.c_proj.weight',
@@ -522,11 +591,16 @@ class HotPath(FamilyBlocks, LlamaBlocks):
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], v3(sv.ao, d), v3(dao, d), sv.lse, ws, g3[..., :d],
                           g3[..., d:2 * d], g3[..., 2 * d:], B, H, T, T, causal, drop=dr['sdpa'], cu_q=cu, cu_k=cu, total_q=M,
                           out_drop=dr['qkv'])                  # gradient w.r.t. the un-multiplied q/k/v
-        self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
-                         f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
+        dln1 = dln
+        if svlo.get('attn_c_attn') is not None:
+            dln1 = self._lora_bwd(lsite('attn_c_attn'), svlo['attn_c_attn'], dqkv, sv.ln1, a.W(f'{pfx}.attn.c_attn.weight'),
+                                  a.Gt(f'{pfx}.attn.c_attn.weight'), a.Gt(f'{pfx}.attn.c_attn.bias'), M, ldrop('attn_c_attn'))
+        else:
+            self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
+                             f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
         # last writer of dx in this block: it also leaves sum(dx^2) for the next block's gradient normaliser
-        ops.layernorm_bwd(dln, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.G(f'{pfx}.ln_1.weight'),
-                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None,
+        ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.Gt(f'{pfx}.ln_1.weight'),
+                          a.Gt(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None,
                           sumsq_out=sumsq_out)
 
     # ---- the encoder's LAST block, CLS rows only.  The encoder output is ln_f of the first ncls rows (encoder.py:172-173); the

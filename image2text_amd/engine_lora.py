@@ -1,0 +1,103 @@
+"""LoRA adapters on the HIP hot path (reference models/utils.py:46-65 wraps the decoder in peft's LoraModel:
+every targeted linear computes ``y = base(x) + lora_B(lora_A(dropout(x))) * lora_alpha / r``, the base parameters are frozen).
+
+How it maps to the MI355X (dense GPT-2 blocks, engine.block_fwd / block_bwd):
+  * forward: the adapter rides in the K panel of the layer's own GEMM --  ``[x | u] . [W | s B | 0]^T`` with ``u = dropout(x) . A^T`` --
+    so the layer's fused epilogue (bias, GELU + saved pre-activation, residual + dropout) sees base + adapter as ONE accumulator and
+    nothing is added afterwards.  The rank is padded to LPAD = 128 columns (zero rows behind lora_A in the arena, zero columns behind
+    s B): K + 128 keeps the 256^2 persistent kernel's K % 128 rule, and u = x . A_pad^T is itself a plain GEMM (N = 128);
+  * backward: the frozen base weight's dW GEMM -- a third of a layer's GEMM flops -- is skipped (ParamArena.trainable); the adapter
+    costs four thin GEMMs: dB = s . dY^T u (N = 128), du = dY . (s B) (N = 128), dA = du^T dropout(x) (M = 128), and
+    dx = dY . W + dropout(du . A) (K = 128, the adapter's input dropout applied by the GEMM's residual + dropout epilogue);
+  * generation (no dropout): merged weights W + s B A in persistent bf16 buffers, refreshed per generate() call -- the decode graph
+    runs the un-adapted step.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+LPAD = 128
+
+
+class LoraAdapters:
+    """Mixin of engine.HotPath."""
+
+    def _lora_site(self, l: int, site: str):
+        lo = getattr(self.dec, 'lora', None)
+        if lo is None or site not in lo.sites:
+            return None
+        key = ('lora', l, site, id(self.arena))
+        v = self._sub_cache.get(key)
+        if v is None:
+            a = self.arena
+            nA, nB = f'{self.dp}lora_params.h{l}_{site}_A', f'{self.dp}lora_params.h{l}_{site}_B'
+            K, N = a.entries[nA][2][1], a.entries[nB][2][0]
+            names = [nA] + ([nA + '.<pad>'] if lo.r < LPAD else [])
+            v = self._sub_cache[key] = SimpleNamespace(
+                K=K, N=N, r=lo.r, scale=lo.scale, kind=f'lora_{site}', A=a.span('W', names, (LPAD, K)), GA=a.span('G', names, (LPAD, K)),
+                B=a.P(nB), GB=a.G(nB))
+        return v
+
+    def _lora_gemm(self, ls, x, W, out, M: int, drop_l, save: bool, **epilogue):
+        """out = epilogue([x | u] . [W | s B | 0]^T), u = dropout(x) . A^T.  x bf16 [M, K] contiguous, W bf16 [N, K].  Returns what
+        the backward needs (u and s B, both [*, LPAD] bf16) when save."""
+        K, N = ls.K, ls.N
+        xd = x
+        if drop_l is not None:
+            xd = x.clone()
+            ops.dropout_apply(xd, M, K, drop_l)
+        xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
+        xcat[:, :K].copy_(x)
+        ops.gemm(xd, ls.A, xcat[:, K:], M, LPAD, K)
+        wcat = torch.zeros(N, K + LPAD, dtype=BF16, device=x.device)
+        wcat[:, :K].copy_(W)
+        wcat[:, K:K + ls.r].copy_(ls.B * ls.scale)
+        ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
+        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous()) if save else None
+
+    def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
+        """dY bf16 [M, N]: gradient w.r.t. the adapted linear's pre-epilogue output.  gW / gb: gradient views of the base weight /
+        bias or None (frozen).  Accumulates every parameter gradient; returns dx fp32 [M, K] = dY . W + dropout(du . A)."""
+        K, N = ls.K, ls.N
+        if gb is not None:
+            ops.colsum(dY, gb, M, N, accumulate=True)
+        if gW is not None:
+            ops.gemm(dY, x, gW, N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        tmp = torch.zeros(N, LPAD, dtype=F32, device=dY.device)
+        ops.gemm(dY, sv_l.u, tmp, N, LPAD, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        ls.GB.add_(tmp[:, :ls.r], alpha=ls.scale)
+        du = torch.empty(M, LPAD, dtype=BF16, device=dY.device)
+        ops.gemm(dY, sv_l.sB, du, M, LPAD, N, b_kmajor=True)
+        xd = x
+        if drop_l is not None:
+            xd = x.clone()
+            ops.dropout_apply(xd, M, K, drop_l)
+        ops.gemm(du, xd, ls.GA, LPAD, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        dx = torch.empty(M, K, dtype=F32, device=dY.device)
+        ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)
+        ops.gemm(du, ls.A, dx, M, K, LPAD, b_kmajor=True, residual=dx, drop=drop_l)
+        return dx
+
+    # ------------------------------------------------------------------------------------------------ generation: merged weights
+    def lora_merged(self, l: int, site: str, W_name: str, rows=None):
+        """bf16 W + s B A of one adapted linear in a persistent buffer (same address on every call: captured decode graphs read it);
+        ``refresh_lora_merged`` recomputes the contents from the current parameters."""
+        key = ('lora_merged', l, site, id(self.arena))
+        buf = self._sub_cache.get(key)
+        if buf is None:
+            ls = self._lora_site(l, site)
+            buf = self._sub_cache[key] = torch.empty(ls.N, ls.K, dtype=BF16, device=self.arena.device)
+            self._lora_merge_list.append((buf, l, site, W_name, rows))
+        return buf
+
+    def refresh_lora_merged(self):
+        a = self.arena
+        for buf, l, site, W_name, rows in self._lora_merge_list:
+            ls = self._lora_site(l, site)
+            W = a.P(W_name)
+            W = W if rows is None else W[rows]
+            A = a.P(f'{self.dp}lora_params.h{l}_{site}_A')
+            buf.copy_(torch.addmm(W, ls.B, A, alpha=ls.scale))

@@ -76,6 +76,7 @@ SIGNATURES = {
     'i2t_rope': [P, P, I, I, I, I, P, I, P, P, I, I, I, I],
     'i2t_swiglu_fwd': [P, P, I, P, I, I],
     'i2t_swiglu_bwd': [P, P, P, I, P, I, I],
+    'i2t_dgelu_mul': [P, P, P, P, L],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

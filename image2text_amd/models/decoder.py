@@ -35,10 +35,10 @@ class Decoder(nn.Module, abc.ABC):
                 return cls._from_pretrained_gpt2(config, loose, space_for_prompt)
             return TransformerDecoder(config, space_for_prompt)
         if isinstance(config, HuggingfaceDecoderConfig):
-            if config.lora_spec is not None:
-                raise NotImplementedError('LoRA adapters (peft) are outside the HIP hot path (SURVEY.md 8(f) next #3)')
-            if config.model_str.startswith('gpt2'):                    # reference decoder.py:120-121
+            if config.model_str.startswith('gpt2'):                    # reference decoder.py:120-121 (+ get_lora_model, :133-134)
                 return GPT2HuggingfaceDecoder(config, space_for_prompt)
+            if config.lora_spec is not None:
+                raise NotImplementedError('LoRA adapters run on the HIP hot path for the GPT-2 decoder only (SURVEY.md 8(f) next #3)')
             if config.model_str.startswith('meta-llama/Llama-2'):      # reference decoder.py:124-125
                 return Llama2HuggingfaceDecoder(config)
             if 'Qwen' in config.model_str:                             # reference decoder.py:126-127
@@ -218,30 +218,110 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
         self.use_cross_attn = config.use_cross_attn
         self._register_state_dict_hook(self._to_hf_keys)
         self._register_load_state_dict_pre_hook(self._from_hf_keys)
+        self.lora = None
         self.load_state_dict({'backbone.' + k: v for k, v in hf.state_dict().items()
                               if not (k.endswith('.attn.masked_bias') or k.endswith('.attn.bias')
                                       or k.endswith('.crossattention.masked_bias') or k.endswith('.crossattention.bias'))})
         self.tie_weights()
+        if config.lora_spec is not None:
+            self._apply_lora(config.lora_spec)
+
+    # -- LoRA (reference models/utils.py:46-65 -> peft LoraModel over the transformers module) -----------------------------------
+    _LORA_SITES = {'attn.c_attn': 'attn_c_attn', 'crossattention.c_attn': 'xattn_c_attn', 'mlp.c_fc': 'mlp_c_fc', 'mlp.c_proj': 'mlp_c_proj'}
+    _HF_LINEARS = ('attn.c_attn', 'attn.c_proj', 'crossattention.c_attn', 'crossattention.q_attn', 'crossattention.c_proj', 'mlp.c_fc',
+                   'mlp.c_proj')
+
+    def _apply_lora(self, spec):
+        """What ``get_lora_model(backbone, CAUSAL_LM, lora_spec)`` does to the transformers module, on this module's own parameters:
+        every Conv1D whose name ends in one of ``target_modules`` (peft's suffix rule; default ``c_attn``) gets
+        ``y += lora_B(lora_A(dropout(x))) * lora_alpha / r`` with lora_A [r, in] ~ kaiming_uniform(a = sqrt 5) and lora_B [out, r] = 0;
+        every other parameter of the decoder is frozen; ``force_enable_update_modules`` (fnmatch patterns over the LoraModel's
+        parameter names, ``model.transformer...``) switch named ones back on."""
+        import fnmatch
+        import math
+        targets = list(spec.target_modules) if spec.target_modules else ['c_attn']
+        L, d = self.hot_config.n_layer, self.n_embd
+        ff = int(self.hot_config.transformer_config.rotator_config.ff_mult * d)
+        have = [m for m in self._HF_LINEARS if self.use_cross_attn or not m.startswith('crossattention.')]
+        hit = [m for m in have if any(f'transformer.h.0.{m}' == t or f'transformer.h.0.{m}'.endswith('.' + t) for t in targets)]
+        other = [t for t in targets if not any(f'transformer.h.0.{m}'.endswith('.' + t) or f'transformer.h.0.{m}' == t for m in self._HF_LINEARS)]
+        bad = [m for m in hit if m not in self._LORA_SITES] + other
+        if bad or not hit:
+            raise NotImplementedError(f'LoRA target_modules {targets}: the HIP hot path adapts {sorted(self._LORA_SITES)} '
+                                      f'(unsupported here: {bad or "no module matched"})')
+        if not 0 < spec.r <= 64:
+            raise NotImplementedError('LoRA rank must be in 1..64 (the adapters run as GEMMs with the rank padded to 64)')
+        shapes = {'attn.c_attn': (d, 3 * d), 'crossattention.c_attn': (d, 2 * d), 'mlp.c_fc': (d, ff), 'mlp.c_proj': (ff, d)}
+        self.lora_params = nn.ParameterDict()
+        for l in range(L):
+            for m in hit:
+                fin, fout = shapes[m]
+                A = torch.empty(spec.r, fin)
+                nn.init.kaiming_uniform_(A, a=math.sqrt(5))
+                self.lora_params[f'h{l}_{self._LORA_SITES[m]}_A'] = nn.Parameter(A)
+                self.lora_params[f'h{l}_{self._LORA_SITES[m]}_B'] = nn.Parameter(torch.zeros(fout, spec.r))
+        self.lora = SimpleNamespace(r=spec.r, scale=spec.lora_alpha / spec.r, p=float(spec.lora_dropout),
+                                    sites=tuple(self._LORA_SITES[m] for m in hit), hf_sites=tuple(hit))
+        # trainable set: LoRA matrices + whatever force_enable_update_modules names (in the LoraModel's own parameter names)
+        pats = spec.force_enable_update_modules
+        for name, p in self.named_parameters():
+            if name.startswith('lora_params.'):
+                p.requires_grad = True
+                continue
+            peft_names = self._peft_names(name)
+            on = [pats is not None and (len(pats) == 0 or any(fnmatch.fnmatch(n, pat) for pat in pats)) for n in peft_names]
+            if any(on) != all(on):
+                raise NotImplementedError(f'force_enable_update_modules splits {name} (transformers parameters {peft_names} share one '
+                                          'matrix on the HIP hot path)')
+            p.requires_grad = all(on)
+        if pats is not None and len(pats) == 0:          # PatternMatcher: an empty list matches everything (models/utils.py:22-23)
+            for p in self.parameters():
+                p.requires_grad = True
+
+    def _peft_names(self, internal: str):
+        """the LoraModel parameter name(s) of one parameter of this module: ``model.<transformers name>``, ``base_layer`` inside adapted
+        modules (``lm_head.weight`` is tied to wte and never listed by named_parameters)"""
+        return [self._decorate(k) for k, _, _ in self._hf_entries(internal)]
 
     # -- state dict in Hugging Face's names and layout -----------------------------------------------------------------------
-    @classmethod
-    def _to_hf_keys(cls, module, sd, prefix, local_metadata):
-        d = module.hot_config.transformer_config.attn_config.n_embd
+    def _hf_entries(self, name: str):
+        """internal parameter name -> [(transformers key, row slice | None, transposed)]: Conv1D stores [in, out]; the fused
+        cross-attention in_proj is transformers' q_attn (rows 0..d) and c_attn (rows d..3d)"""
+        d = self.n_embd
+        if '.cross_attn.' in name:
+            blk, leaf = name.split('.cross_attn.')
+            base = blk + '.crossattention.'
+            if leaf == 'in_proj_weight':
+                return [(base + 'q_attn.weight', slice(0, d), True), (base + 'c_attn.weight', slice(d, 3 * d), True)]
+            if leaf == 'in_proj_bias':
+                return [(base + 'q_attn.bias', slice(0, d), False), (base + 'c_attn.bias', slice(d, 3 * d), False)]
+            w = leaf.split('.')[1]
+            return [(base + 'c_proj.' + w, None, w == 'weight')]
+        return [(name.replace('.ln_3.', '.ln_cross_attn.'), None, name.endswith(self._CONV1D))]
+
+    def _decorate(self, hf_key: str) -> str:
+        """transformers key -> key under ``backbone.``: unchanged without LoRA; with LoRA the backbone is peft's LoraModel, i.e.
+        ``model.<key>`` and ``<module>.base_layer.<weight|bias>`` for the adapted modules"""
+        if self.lora is None:
+            return hf_key
+        for m in self.lora.hf_sites:
+            if f'.{m}.' in hf_key:
+                hf_key = hf_key.replace(f'.{m}.', f'.{m}.base_layer.')
+        return 'model.' + hf_key
+
+    @staticmethod
+    def _to_hf_keys(module, sd, prefix, local_metadata):
+        sites = {v: k for k, v in module._LORA_SITES.items()}
         for k in [k for k in sd if k.startswith(prefix)]:
             v, name = sd.pop(k), k[len(prefix):]
-            if name.endswith(cls._CONV1D):
-                sd[prefix + 'backbone.' + name] = v.t()
-            elif '.cross_attn.' in name:
-                base = prefix + 'backbone.' + name.split('.cross_attn.')[0] + '.crossattention.'
-                leaf = name.split('.cross_attn.')[1]
-                if leaf == 'in_proj_weight':
-                    sd[base + 'q_attn.weight'], sd[base + 'c_attn.weight'] = v[:d].t(), v[d:].t()
-                elif leaf == 'in_proj_bias':
-                    sd[base + 'q_attn.bias'], sd[base + 'c_attn.bias'] = v[:d], v[d:]
-                else:                                                               # out_proj.weight / out_proj.bias
-                    sd[base + 'c_proj.' + leaf.split('.')[1]] = v.t() if leaf.endswith('weight') else v
-            else:
-                sd[prefix + 'backbone.' + name.replace('.ln_3.', '.ln_cross_attn.')] = v
+            if name.startswith('lora_params.'):                       # h{l}_{site}_{A|B} -> <module>.lora_{A|B}.default.weight
+                l, rest = name[len('lora_params.h'):].split('_', 1)
+                site, ab = rest.rsplit('_', 1)
+                sd[f'{prefix}backbone.model.transformer.h.{l}.{sites[site]}.lora_{ab}.default.weight'] = v
+                continue
+            for hk, rows, tr in module._hf_entries(name):
+                t = v if rows is None else v[rows]
+                sd[prefix + 'backbone.' + module._decorate(hk)] = t.t() if tr else t
         return sd
 
     def _from_hf_keys(self, sd, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -249,7 +329,15 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
         cross = {}
         for k in [k for k in sd if k.startswith(bb)]:
             v, name = sd.pop(k), k[len(bb):]
-            if name.endswith(self._CONV1D):
+            if name.startswith('model.'):                             # a LoraModel's keys (or a checkpoint saved from one)
+                name = name[len('model.'):]
+            name = name.replace('.base_layer.', '.')
+            if '.lora_A.' in name or '.lora_B.' in name:
+                mod, rest = name.split('.lora_')
+                l = mod.split('.')[2]
+                site = self._LORA_SITES.get(mod.split('.', 3)[3])
+                sd[f'{prefix}lora_params.h{l}_{site}_{rest[0]}'] = v
+            elif name.endswith(self._CONV1D):
                 sd[prefix + name] = v.t()
             elif '.crossattention.' in name:
                 cross.setdefault(name.split('.crossattention.')[0], {})[name.split('.crossattention.')[1]] = v

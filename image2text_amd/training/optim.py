@@ -53,7 +53,8 @@ class _ArenaOptimizer(torch.optim.Optimizer):
             for p in g['params']:
                 if arena_of(p) is not arena:
                     raise RuntimeError(f'{type(self).__name__}: a parameter of shape {tuple(p.shape)} lives outside the arena')
-                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p)
+                # (a frozen parameter -- LoRA's base weights -- keeps its value whatever group it was handed over in)
+                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p) if p.requires_grad else (0.0, 0.0, p)
         ends, lrs, wds, self._params = [], [], [], []
         items = sorted(arena.entries.items(), key=lambda kv: kv[1][0])
         for i, (name, (off, n, _)) in enumerate(items):

@@ -397,6 +397,11 @@ int i2t_rope(void* stream, void* x, int rs, int col0, int n_heads, int hd, const
 int i2t_swiglu_fwd(void* stream, const void* gate_up, int ld, void* h, int M, int ff);
 int i2t_swiglu_bwd(void* stream, const void* dh, const void* gate_up, int ld, void* d_gate_up, int M, int ff);
 
+/* LoRA adapters (reference models/utils.py:46-65 -> peft: y = base(x) + lora_B(lora_A(dropout(x))) * alpha / r).  The rank-r products
+ * are i2t_gemm_bf16 calls (rank padded to 64 by zero rows), the input dropout is i2t_dropout_apply; this is the GELU derivative behind
+ * an adapted mlp.c_proj, whose input gradient is the fp32 sum of the base and adapter paths: out (bf16) = dh (fp32) * gelu_tanh'(pre). */
+int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, void* out, long n);
+
 /* Grouped small GEMMs for AdvancedPositionalBiasMLP (reference models/layers.py:617-638, decoder.py:231-232: every position owns a
  * private MLP, so one layer of the module is one GEMM per position).  Group g = position; its rows are rows [seg[g], seg[g+1]) of
  * the row-major operands (position-major order; seg = device int[n_groups + 1]; max_rows = the largest group), its weights

@@ -434,3 +434,142 @@ def test_gpt2_hf_decoder_dropout_sites_train_mode(tmp_path, monkeypatch):
     _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-uneven', resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.0)
     with pytest.raises(NotImplementedError, match='pdrop'):
         Decoder.from_config(_hf_decoder_config(name='gpt2-uneven'))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# LoRA on the GPT-2 plugin (reference decoder.py:133-134 -> models/utils.py:46-65 -> peft LoraModel; peft is not in this image, so
+# the checker restates its published layer: y = base(x) + lora_B(lora_A(dropout(x))) * lora_alpha / r around transformers' Conv1D)
+# ------------------------------------------------------------------------------------------------------------------------------
+class _LoraConv1D(torch.nn.Module):
+    def __init__(self, base, A, B, scale):
+        super().__init__()
+        self.base, self.scale, self.mask = base, scale, None
+        self.A, self.B = torch.nn.Parameter(A.clone()), torch.nn.Parameter(B.clone())
+
+    def forward(self, x):
+        xd = x if self.mask is None else x * self.mask.view(x.shape)           # dropout on the adapter's input only
+        return self.base(x) + (xd @ self.A.t() @ self.B.t()) * self.scale
+
+
+_LORA_MODS = {'attn_c_attn': ('attn', 'c_attn'), 'xattn_c_attn': ('crossattention', 'c_attn'), 'mlp_c_fc': ('mlp', 'c_fc'), 'mlp_c_proj': ('mlp', 'c_proj')}
+
+
+def _lora_twin(model):
+    """transformers GPT-2 + the adapters, from the plugin's (LoraModel-keyed) state dict"""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    dec = model.decoder
+    hc = dec.hf_config
+    hf = GPT2LMHeadModel(GPT2Config(n_layer=hc.n_layer, n_head=hc.n_head, n_embd=hc.n_embd, n_positions=hc.n_positions,
+                                    vocab_size=model._engine.dec.V, add_cross_attention=True, resid_pdrop=0.0, embd_pdrop=0.0,
+                                    attn_pdrop=0.0)).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    hf.load_state_dict({k[len('backbone.model.'):].replace('.base_layer.', '.'): v for k, v in sd.items() if '.lora_' not in k}, strict=True)
+    wraps = {}
+    for l in range(hc.n_layer):
+        for site in dec.lora.sites:
+            parent, leaf = _LORA_MODS[site]
+            mod = getattr(hf.transformer.h[l], parent)
+            key = f'backbone.model.transformer.h.{l}.{parent}.{leaf}.lora_'
+            w = _LoraConv1D(getattr(mod, leaf), sd[key + 'A.default.weight'], sd[key + 'B.default.weight'], dec.lora.scale)
+            setattr(mod, leaf, w)
+            wraps[(l, site)] = w
+    return hf, wraps
+
+
+@pytest.mark.parametrize('p_lora', [0.0, 0.25])
+def test_gpt2_hf_decoder_lora(tmp_path, monkeypatch, p_lora):
+    """lora_spec on the GPT-2 plugin: the adapters in the K panel of their layers' GEMMs (forward), the four thin adapter GEMMs and the
+    skipped base-weight GEMMs (backward), frozen parameters without gradient, the adapter's input dropout with the SAME mask in forward
+    and backward (p = 0.25: the oracle is handed the masks of the step's DropPlan), merged weights in KV-cache generation."""
+    from oracle import reference_model as orc
+    from image2text_amd import rng
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from test_host_cpu import _lora_spec
+    tag = f'hf_gpt2_lora.p{p_lora}'
+    _local_hf_gpt2(tmp_path, monkeypatch)
+    cfg = _model_config(True, True, lora_spec=_lora_spec(lora_dropout=p_lora))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for n, p in m.decoder.lora_params.items():
+            if n.endswith('_B'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)          # lora_B starts at zero: give the adapters something to do
+    hf, wraps = _lora_twin(m)
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    assert 'decoder.transformer.h.0.attn.c_attn.weight' in frozen and 'decoder.transformer.h.0.cross_attn.in_proj_weight' not in frozen
+    m = m.to(dev()).train()
+    eng = m._engine
+    images, labels = synthetic_batch(3, 32, 12, 384, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls
+    gg = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, 128, generator=gg) * 0.05
+    wl = torch.randn(3, 12, 384, generator=gg) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    if p_lora > 0:          # the masks this step drew, replicated on the host for the oracle's adapters
+        plan = eng.dec_drop
+        for (l, site), w in wraps.items():
+            _, key, thr, scale = plan.get(l, f'lora_{site}')
+            rows, K = (3 * n_p if site == 'xattn_c_attn' else 3 * (n_p + 12)), w.A.shape[1]
+            w.mask = rng.keep_mask(key, rows * K, thr).view(rows, K).float() * scale
+    enc, ologits, ohid = _reference_forward(orc, esd, hf, cfg, images, ids, True, True)
+    for name, got, ref, tol in (('logits', out.logits, ologits, 1e-2), ('hidden', out.hidden_state, ohid, 1.5e-2)):
+        err, scale_ = float((got.float().cpu() - ref.detach()).abs().max()), max(1.0, float(ref.detach().abs().max()))
+        REPORT[f'{tag}.{name}'] = {'max_abs_err': err, 'tol': tol * scale_}
+        assert err <= tol * scale_, (name, err, tol * scale_)
+    ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    from image2text_amd.models.decoder import Decoder
+    shell = Decoder.from_config(_hf_decoder_config(use_cross_attn=True))              # un-adapted container: transformers keys -> internal layout
+    hf_g = {'backbone.' + k.replace('.base.', '.'): (p.grad if p.grad is not None else torch.zeros_like(p))
+            for k, p in hf.named_parameters() if not (k.endswith('.A') or k.endswith('.B'))}
+    hf_g['backbone.lm_head.weight'] = hf_g['backbone.transformer.wte.weight']
+    shell.load_state_dict(hf_g, strict=True)
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.' + k: v.detach() for k, v in shell.named_parameters()})
+    for (l, site), w in wraps.items():
+        ref_grads[f'decoder.lora_params.h{l}_{site}_A'], ref_grads[f'decoder.lora_params.h{l}_{site}_B'] = w.A.grad, w.B.grad
+    fails, checked = [], 0
+    for name, p in m.named_parameters():
+        if name in frozen:
+            assert p.grad is None, f'{name} is frozen but received a gradient'
+            continue
+        checked += 1
+        try:
+            grad_close(f'{tag}.{name}', p.grad, ref_grads[name].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert checked > 20 and not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    if p_lora > 0:
+        return
+    # the fused optimizer leaves the frozen base weights alone; generation runs on merged weights
+    from image2text_amd.training.optim import FusedAdamW
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt = FusedAdamW(m.parameters(), m, lr=1e-2, weight_decay=0.1)
+    opt.step()
+    moved = {n: not torch.equal(before[n], p.detach()) for n, p in m.named_parameters()}
+    assert not any(moved[n] for n in frozen) and all(moved[n] for n in moved if n not in frozen)
+    m.eval()
+    tok = fake_tokenizer(384)
+    with torch.no_grad():
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = m.generate(images.to(dev()), prompt, max_new_tokens=10, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(10):
+            lg = m(images=images.to(dev()), ids=cur).logits[:, -1].float().cpu()
+            lg = orc.apply_ngram_ban(cur.cpu(), lg, cfg.no_repeat_n_grams)
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * lg[torch.isfinite(lg)].abs().max().clamp(min=1.0)
+            same_prefix = (gen[:, :cur.shape[1]].cpu() == cur.cpu()).all(dim=1)
+            ok = gen[:, cur.shape[1]].cpu() == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
+        REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
+        assert total >= 8 and agree == total, (agree, total)

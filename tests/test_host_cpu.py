@@ -333,7 +333,7 @@ def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
     assert not m_soft._engine.cross_inputs                                  # model asks for cross-attention, the decoder has none: dropped
     # refusals
     with pytest.raises(NotImplementedError, match='LoRA'):
-        Decoder.from_config(_hf_decoder_config(lora_spec=LoraSpec(r=4, target_modules=['c_attn'])))
+        Decoder.from_config(_hf_decoder_config(name='Qwen-x', vocab_size=151936, lora_spec=LoraSpec(r=4, target_modules=['q_proj'])))
     with pytest.raises(NotImplementedError, match='4-bit'):
         Decoder.from_config(_hf_decoder_config(load_in_4bit=True))
     with pytest.raises(NotImplementedError, match='Falcon'):
@@ -341,6 +341,63 @@ def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
     hf_relu = _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-relu', activation_function='relu')
     with pytest.raises(NotImplementedError, match='activation'):
         Decoder.from_config(_hf_decoder_config(name='gpt2-relu'))
+
+
+def _lora_spec(**kw):
+    from image2text_amd.configs.models import LoraSpec
+    args = dict(r=4, lora_alpha=16, lora_dropout=0.0, target_modules=['c_attn', 'mlp.c_fc', 'mlp.c_proj'],
+                force_enable_update_modules=['*.wpe.*', '*.wte.*', '*.crossattention.*', '*.ln_cross_attn.*'])      # gpu/gpt2-xl.yaml:55-60
+    args.update(kw)
+    return LoraSpec(**args)
+
+
+def test_gpt2_huggingface_decoder_lora(tmp_path, monkeypatch):
+    """lora_spec on the GPT-2 plugin (reference decoder.py:133-134 -> models/utils.py:46-65 -> peft LoraModel): adapters on the modules
+    peft's suffix rule selects (c_attn = self- AND cross-attention's), lora_B zero, everything else of the decoder frozen, the
+    force-enable patterns matched against the LoraModel's parameter names, and a state dict in the LoraModel's keys"""
+    from image2text_amd.engine import _arena_order
+    _local_hf_gpt2(tmp_path, monkeypatch)
+    d = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec()))
+    assert d.lora.sites == ('attn_c_attn', 'xattn_c_attn', 'mlp_c_fc', 'mlp_c_proj') and d.lora.scale == 4.0 and d.lora.r == 4
+    sd = d.state_dict()
+    p_ = 'backbone.model.transformer.h.1.'
+    shapes = {p_ + 'attn.c_attn.base_layer.weight': (128, 384), p_ + 'attn.c_attn.base_layer.bias': (384,), p_ + 'attn.c_attn.lora_A.default.weight': (4, 128),
+              p_ + 'attn.c_attn.lora_B.default.weight': (384, 4), p_ + 'crossattention.c_attn.base_layer.weight': (128, 256),
+              p_ + 'crossattention.c_attn.lora_A.default.weight': (4, 128), p_ + 'crossattention.c_attn.lora_B.default.weight': (256, 4),
+              p_ + 'crossattention.q_attn.weight': (128, 128), p_ + 'mlp.c_fc.base_layer.weight': (128, 512), p_ + 'mlp.c_fc.lora_B.default.weight': (512, 4),
+              p_ + 'mlp.c_proj.lora_A.default.weight': (4, 512), p_ + 'mlp.c_proj.base_layer.bias': (128,), p_ + 'attn.c_proj.weight': (128, 128),
+              p_ + 'ln_cross_attn.weight': (128,), 'backbone.model.transformer.wte.weight': (384, 128), 'backbone.model.lm_head.weight': (384, 128)}
+    for k, shp in shapes.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    assert not any(k.startswith('backbone.transformer.') or 'lora_params' in k for k in sd)
+    assert float(sd[p_ + 'attn.c_attn.lora_B.default.weight'].abs().max()) == 0.0 and float(sd[p_ + 'attn.c_attn.lora_A.default.weight'].std()) > 0.01
+    grads = {n: p.requires_grad for n, p in d.named_parameters()}
+    on = ('lora_params.h0_attn_c_attn_A', 'lora_params.h1_mlp_c_proj_B', 'transformer.wte.weight', 'transformer.wpe.weight',
+          'transformer.h.0.cross_attn.in_proj_weight', 'transformer.h.0.cross_attn.out_proj.bias', 'transformer.h.1.ln_3.weight')
+    off = ('transformer.h.0.attn.c_attn.weight', 'transformer.h.0.attn.c_attn.bias', 'transformer.h.0.attn.c_proj.weight',
+           'transformer.h.1.mlp.c_fc.weight', 'transformer.h.1.ln_1.weight', 'transformer.ln_f.bias')
+    assert all(grads[n] for n in on) and not any(grads[n] for n in off)
+    # the adapters' A matrices are followed by zero pad rows in the arena (rank -> 64: the adapter GEMMs' K / N panel)
+    order = _arena_order(list(d.named_parameters()))
+    i = [n for n, *_ in order].index('lora_params.h0_attn_c_attn_A')
+    assert order[i + 1][0] == 'lora_params.h0_attn_c_attn_A.<pad>' and order[i + 1][1] is None and order[i + 1][2] == 60 * 128
+    # round trip in the LoraModel's keys; a checkpoint of the un-adapted model (plain transformers keys) loads too (loose)
+    d2 = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec()))
+    d2.load_state_dict(sd, strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(d.parameters(), d2.parameters()))
+    plain = Decoder.from_config(_hf_decoder_config(use_cross_attn=True)).state_dict()
+    missing, unexpected = d2.load_state_dict(plain, strict=False)
+    assert not unexpected and all('lora_params' in k for k in missing)
+    # no force-enable list: adapters only
+    d3 = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec(force_enable_update_modules=None, target_modules=None)))
+    assert d3.lora.sites == ('attn_c_attn', 'xattn_c_attn')                  # peft's default target for gpt2: c_attn
+    assert [n for n, p in d3.named_parameters() if p.requires_grad] == [n for n, _ in d3.named_parameters() if n.startswith('lora_params.')]
+    with pytest.raises(NotImplementedError, match='target_modules'):
+        Decoder.from_config(_hf_decoder_config(lora_spec=_lora_spec(target_modules=['attn.c_proj'])))
+    with pytest.raises(NotImplementedError, match='splits'):
+        Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec(force_enable_update_modules=['*.q_attn.*'])))
+    with pytest.raises(NotImplementedError, match='rank'):
+        Decoder.from_config(_hf_decoder_config(lora_spec=_lora_spec(r=100)))
 
 
 def _local_hf_llama(tmp_path, monkeypatch, kind='llama'):
