@@ -40,7 +40,7 @@ import torch
 from . import ops, rng
 from .engine_family import FamilyBlocks, family_spec
 from .engine_llama import LlamaBlocks
-from .engine_lora import LoraAdapters
+from .engine_lora import LPAD, LoraAdapters
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -150,8 +150,8 @@ def _arena_order(named):
             continue
         if p is not None:
             out.append((name, p, p.numel(), p.shape))
-            if _LORA_A.match(name) and p.shape[0] < 64:      # LoRA rank -> 64 zero-padded rows: lora_A is the [64, in] operand of the adapter GEMMs
-                pad = (64 - p.shape[0]) * p.shape[1]
+            if _LORA_A.match(name) and p.shape[0] < LPAD:    # LoRA rank -> LPAD zero-padded rows: lora_A is the [LPAD, in] operand of the adapter GEMMs
+                pad = (LPAD - p.shape[0]) * p.shape[1]
                 out.append((name + '.<pad>', None, pad, torch.Size([pad])))
             continue
         g = groups[name]

@@ -249,8 +249,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
         if bad or not hit:
             raise NotImplementedError(f'LoRA target_modules {targets}: the HIP hot path adapts {sorted(self._LORA_SITES)} '
                                       f'(unsupported here: {bad or "no module matched"})')
-        if not 0 < spec.r <= 64:
-            raise NotImplementedError('LoRA rank must be in 1..64 (the adapters run as GEMMs with the rank padded to 64)')
+        if not 0 < spec.r <= 128:
+            raise NotImplementedError('LoRA rank must be in 1..128 (the adapters run as GEMMs with the rank padded to 128)')
         shapes = {'attn.c_attn': (d, 3 * d), 'crossattention.c_attn': (d, 2 * d), 'mlp.c_fc': (d, ff), 'mlp.c_proj': (ff, d)}
         self.lora_params = nn.ParameterDict()
         for l in range(L):
