@@ -47,6 +47,8 @@ def main():
     ap.add_argument('--new-tokens', type=int, default=64)
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
+                    "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
     args = ap.parse_args()
     from transformers import GPT2Config, GPT2LMHeadModel
     from image2text_amd import ops
@@ -73,14 +75,20 @@ def main():
     else:
         name = args.size + '-random'                      # the reference dispatches on model_str.startswith('gpt2') (decoder.py:120)
         GPT2LMHeadModel(GPT2Config(vocab_size=50257, n_positions=1024, **SIZES[args.size])).save_pretrained(name)
+        lora = None
+        if args.lora:
+            from image2text_amd.configs.models import LoraSpec
+            lora = LoraSpec(r=16, lora_alpha=64, lora_dropout=0.1, target_modules=['c_attn', 'mlp.c_fc', 'mlp.c_proj'],
+                            force_enable_update_modules=['*.wpe.*', '*.wte.*', '*.crossattention.*', '*.ln_cross_attn.*'])
         dcfg = HuggingfaceDecoderConfig(vocab_size=50257, use_cross_attn=True, model_str=name, extra_tokens=2, load_in_4bit=False,
-                                        prepare_for_kbit_training=False)
+                                        prepare_for_kbit_training=False, lora_spec=lora)
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
         V, eos = 50259, 50256
     tok = fake_tokenizer(V, eos=eos)
     wrapper = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
     eng = wrapper.model._engine
     n_params = sum(p.numel() for p in wrapper.model.parameters())
+    n_train = sum(p.numel() for p in wrapper.model.parameters() if p.requires_grad)
     opt = FusedAdamW(wrapper.model.parameters(), wrapper.model, lr=6e-4, betas=(0.9, 0.95), weight_decay=0.0)
     images, labels = synthetic_batch(args.batch, 224, args.caption_len, V, seed=1, eos=eos)
     images, labels = images.to(dev), labels.to(dev)
@@ -103,8 +111,8 @@ def main():
     kind = type(wrapper.model.decoder).__name__
     out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + {kind}({args.size}, randomly initialised checkpoint, '
                        + ('' if llama else 'cross-attention, dropout 0.1, ') +
-                       f'soft prompt of 64 + {args.caption_len} text positions), every parameter trains',
-           'params_M': round(n_params / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
+                       f'soft prompt of 64 + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else ', every parameter trains'),
+           'params_M': round(n_params / 1e6, 1), 'trainable_params_M': round(n_train / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
            'decoder': {'prefixed': eng.dec.prefixed, 'grad_norm': eng.dec.grad_norm, 'layers': eng.dec.L, 'd': eng.dec.d, 'vocab': eng.dec.V}}
