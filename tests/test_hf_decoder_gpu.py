@@ -429,7 +429,8 @@ def test_gpt2_hf_decoder_dropout_sites_train_mode(tmp_path, monkeypatch):
     w.eval()
     with torch.no_grad():
         vloss, _ = w.val_step(images, labels)
-    assert losses[0] == losses[2] and losses[0] != losses[1] and abs(losses[0] - float(vloss)) > 1e-4
+    # (same masks -> same loss up to the order of the cross-entropy's atomic row sums)
+    assert abs(losses[0] - losses[2]) < 1e-5 * losses[0] and abs(losses[0] - losses[1]) > 1e-4 and abs(losses[0] - float(vloss)) > 1e-4
     assert abs(losses[0] - float(vloss)) < 0.2 * float(vloss)
     _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-uneven', resid_pdrop=0.1, embd_pdrop=0.1, attn_pdrop=0.0)
     with pytest.raises(NotImplementedError, match='pdrop'):
