@@ -4,14 +4,15 @@
 the pieces this image cannot load: torchvision's pretrained ViT-B/16 -> the nano-224 from-scratch ViT; peft LoRA -> every parameter
 trains).
 
-    python tools/bench_hf_decoder.py [--size gpt2|gpt2-medium|qwen2-1.5b|llama2-tiny] [--batch 1024] [--steps 6] [--warmup 2]
+    python tools/bench_hf_decoder.py [--size gpt2|gpt2-medium|qwen2-1.5b|llama2-7b|llama2-tiny] [--batch 1024] [--steps 6] [--warmup 2]
                                      [--decode-batch 1024] [--cpu]
 
 There is no network: the 'checkpoint' is a randomly initialised model of the named shape written to a scratch directory and loaded
 back through AutoModelForCausalLM.from_pretrained, exactly the path a real checkpoint takes (GPT-2: cross-attention layers added by
 transformers, embeddings resized by extra_tokens = 2; soft prompt = the 64 encoder outputs in front of the text: one causal sequence
 of 64 + 64 positions).  qwen2-1.5b is the shape of deepseek-ai/DeepSeek-R1-Distill-Qwen-1.5B (28 x 1536, 12 query heads of 128 on 2
-K/V heads, SwiGLU 8960, vocabulary 151 936, untied head: 1.78 B parameters).  Prints one JSON line; --cpu adds the reference
+K/V heads, SwiGLU 8960, vocabulary 151 936, untied head: 1.78 B parameters); llama2-7b is Llama-2-7B's shape (32 x 4096, 32 heads of
+128, SwiGLU 11008: 6.74 B parameters -- fp32 master weights, gradients, bf16 shadow and Adam state are 121 GB of the GPU's 288).  Prints one JSON line; --cpu adds the reference
 composition (oracle encoder + the transformers module, fp32, host cores) on a small batch.  Synthetic data.
 """
 import argparse
@@ -30,6 +31,9 @@ LLAMA_SIZES = {      # name -> (checkpoint directory name satisfying decoder.py:
     'qwen2-1.5b': ('Qwen2-1.5B-random', 'Qwen2Config', dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
                                                              num_attention_heads=12, num_key_value_heads=2, max_position_embeddings=4096,
                                                              rms_norm_eps=1e-6, tie_word_embeddings=False), 151936),
+    'llama2-7b': ('meta-llama/Llama-2-7b-random', 'LlamaConfig', dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                                                                      num_attention_heads=32, num_key_value_heads=32,
+                                                                      max_position_embeddings=4096, rms_norm_eps=1e-5), 32000),
     'llama2-tiny': ('meta-llama/Llama-2-tiny-random', 'LlamaConfig', dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=8,
                                                                           num_attention_heads=8, num_key_value_heads=8,
                                                                           max_position_embeddings=4096, rms_norm_eps=1e-5), 32000),
@@ -67,7 +71,10 @@ def main():
         import transformers
         name, cfg_cls, kw, vocab = LLAMA_SIZES[args.size]
         hf_cfg = getattr(transformers, cfg_cls)(vocab_size=vocab, **kw)
-        transformers.AutoModelForCausalLM.from_config(hf_cfg).save_pretrained(name)
+        big = kw['hidden_size'] * kw['num_hidden_layers'] >= 100000            # multi-billion-parameter shapes: bf16 on disk
+        t_init = time.perf_counter()
+        transformers.AutoModelForCausalLM.from_config(hf_cfg, dtype=torch.bfloat16 if big else torch.float32).save_pretrained(name)
+        print(f'[bench_hf_decoder] random checkpoint written in {time.perf_counter() - t_init:.0f} s', file=sys.stderr, flush=True)
         dcfg = HuggingfaceDecoderConfig(vocab_size=vocab, use_cross_attn=False, model_str=name, extra_tokens=0, load_in_4bit=False,
                                         prepare_for_kbit_training=False)
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=False, use_soft_prompting=True))
@@ -85,7 +92,9 @@ def main():
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
         V, eos = 50259, 50256
     tok = fake_tokenizer(V, eos=eos)
+    t_init = time.perf_counter()
     wrapper = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100).to(dev).train()
+    print(f'[bench_hf_decoder] model loaded and moved in {time.perf_counter() - t_init:.0f} s', file=sys.stderr, flush=True)
     eng = wrapper.model._engine
     n_params = sum(p.numel() for p in wrapper.model.parameters())
     n_train = sum(p.numel() for p in wrapper.model.parameters() if p.requires_grad)
