@@ -43,6 +43,9 @@ class Decoder(nn.Module, abc.ABC):
                 return Llama2HuggingfaceDecoder(config)
             if 'Qwen' in config.model_str:                             # reference decoder.py:126-127
                 return Qwen2HuggingfaceDecoder(config)
+            # (Falcon: the reference's own wrapper reads ``backbone.model.embed_tokens`` (decoder.py:390-393), which neither transformers'
+            # FalconForCausalLM nor its LoraModel wrapping has -- ``transformer.word_embeddings`` -- so its soft-prompt path, the only one
+            # gpu/falcon-7b.yaml uses, cannot run as written; there is no behaviour to be a drop-in for)
             raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: GPT-2, Llama-2 and Qwen2 checkpoints run on the HIP hot '
                                       'path; Falcon blocks and free-form AutoModelForCausalLM architectures do not (SURVEY.md 8(f) next #3)')
         raise ValueError('Unknown config type!!!')
