@@ -574,3 +574,46 @@ def test_gpt2_hf_decoder_lora(tmp_path, monkeypatch, p_lora):
             cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
         REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
         assert total >= 8 and agree == total, (agree, total)
+
+
+def test_hf_decoder_edges(tmp_path, monkeypatch):
+    """captions longer than the position table (cropped like the reference crops its concatenated embeddings, v_e_d.py:88), the
+    sampling modes of generate() on a prefixed KV cache (reproducible under torch.manual_seed), the MLM-corruption trainer option,
+    and the refusals of this path (contrastive loss, momentum distillation)"""
+    from oracle import reference_model as orc
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    _local_hf_gpt2(tmp_path, monkeypatch)
+    cfg = _model_config(True, True)
+    tok = fake_tokenizer(384)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    hf = _hf_twin(w.model, True)
+    esd = {k: v.detach().clone() for k, v in w.model.state_dict().items() if not k.startswith('decoder.')}
+    w = w.to(dev()).eval()
+    n_p = cfg.vision_encoder_config.n_cls                                   # 8 prompt rows + 56 text rows fill the 64 positions
+    images, labels = synthetic_batch(3, 32, 70, 384, seed=23, min_len=60)
+    with torch.no_grad():
+        vloss, _ = w.val_step(images.to(dev()), labels.to(dev()))
+        ids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
+        _, ologits, _ = _reference_forward(orc, esd, hf, cfg, images, ids, True, True)
+        assert ologits.shape[1] == 64 - n_p
+        lab = labels[:, :64 - n_p]
+        ce = F.cross_entropy(ologits.reshape(-1, 384), lab.reshape(-1), ignore_index=-100, reduction='none')
+        oloss = float((ce * orc.loss_weights(lab, -100).reshape(-1)).sum())
+        assert abs(float(vloss) - oloss) <= 1e-2 * oloss, (float(vloss), oloss)
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        outs = []
+        for seed in (5, 6, 5):
+            torch.manual_seed(seed)
+            outs.append(w.model.generate(images.to(dev()), prompt, max_new_tokens=20, temperature=0.9, top_k=8, nucleus_p=0.9).cpu())
+        assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1]) and int(outs[0].max()) < 384
+        with pytest.raises(AssertionError):
+            w.model.generate(images.to(dev()), prompt, max_new_tokens=64 - n_p)                # prompt + new tokens exceed the text window
+    wm = ModelTrainerWrapper(cfg, tok.__class__(**{**tok.__dict__, 'mask_token_id': 380}), TrainerWrapperConfig(mask_fraction=0.2, random_mask_fraction=0.1),
+                             ignore_index=-100).to(dev()).train()
+    loss, _ = wm.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in wm.model.parameters())
+    for kw in (dict(add_contrastive_loss=True), dict(moco_momentum=0.99, moco_alpha=0.4)):
+        with pytest.raises(NotImplementedError, match='soft prompt'):
+            ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(**kw), ignore_index=-100)
