@@ -55,6 +55,7 @@ struct GemmParams {
     int drop_mode;            // 0 none | 1 elementwise (idx = m*N + n) | 2 per (row, third of N) -- the q/k/v token multipliers
     unsigned drop_key, drop_thr;
     float drop_scale;
+    float* ws;                // deterministic split-K (i2t_gemm_bf16_ws): slice `s` of the raw accumulators goes to ws[s][M][N]; null: atomics onto C
     int g2_splits, g2_nk;     // 256^2 kernel: K slices per output tile and K-tiles per slice (even)
     int g2_gn;                // 256^2 kernel: column tiles per group of the tile order
     int g2_dbg;               // experiment (I2T_G256_DBG): 1 = epilogue without its global stores, 2 = no epilogue at all
@@ -172,8 +173,26 @@ template <int MI, int NJ>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int lane);
 
 template <bool SPLITK>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane,
+                                              int split = 0) {
     const int g = lane >> 4, li = lane & 15;
+    if (SPLITK && p.ws) {
+        // deterministic form: this K slice's raw accumulators to its own [M][N] plane; splitk_reduce_kernel adds the planes in a
+        // fixed order and applies the fused epilogue (16 lanes = 64 contiguous bytes per store)
+        float* W = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                    if (m < p.M && n < p.N) W[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     if (SPLITK) {
         // un-swapped accumulators: lane holds C[m0 + wm*64 + 16 i + 4 g + r][n0 + wn*64 + 16 j + li], r = 0..3
         float* C = reinterpret_cast<float*>(p.C);
@@ -754,13 +773,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int nk_per = SPLITK ? (nk_all + (int)gridDim.y - 1) / (int)gridDim.y : nk_all;
     const int kt0 = SPLITK ? split * nk_per : 0;
     const int nk = min(nk_per, nk_all - kt0);
-    if (nk <= 0) return;                                     // block-uniform
+    if (nk <= 0 && !(SPLITK && p.ws)) return;                // block-uniform (a slice plane must be written even when its K range is empty)
 
     Stage sa, sb;
-    stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
-    stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
-    stage_store<A_KMAJOR, PK>(sa, smem, tid);
-    stage_store<B_KMAJOR, PK>(sb, smem + OPERAND_BYTES, tid);
+    if (nk > 0) {
+        stage_load<A_KMAJOR>(sa, p.A, p.lda, m0, a_rows, kt0 * BK, p.K, tid);
+        stage_load<B_KMAJOR>(sb, p.B, p.ldb, n0, b_rows, kt0 * BK, p.K, tid);
+        stage_store<A_KMAJOR, PK>(sa, smem, tid);
+        stage_store<B_KMAJOR, PK>(sb, smem + OPERAND_BYTES, tid);
+    }
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
@@ -793,7 +814,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<SPLITK>(p, acc, m0, n0, wm, wn, lane, split);
 }
 
 
@@ -1688,6 +1709,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
     }
 }
 
+// Second stage of the deterministic split-K form: C = epilogue(sum_s ws[s]) with the planes added in slice order (bit-reproducible,
+// unlike atomics); a thread owns 4 consecutive columns of one row and runs the ordinary fused epilogue on the sum.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+    const int nq = (p.N + 3) >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)p.M * nq) return;
+    const int m = (int)(i / nq), n4 = (int)(i - (long)m * nq) * 4;
+    const size_t plane = (size_t)p.M * p.N;
+    const float* w = p.ws + (size_t)m * p.N + n4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const bool full = n4 + 4 <= p.N && (p.N & 3) == 0;
+    for (int s_ = 0; s_ < splits; ++s_) {
+        if (full) {
+            a += *reinterpret_cast<const f32x4*>(w + s_ * plane);
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (n4 + r < p.N) a[r] += w[s_ * plane + r];
+        }
+    }
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+    epilogue_quad(p, a, m, n4, vec_ok);
+}
+
 template <int MT>
 void launch_skinny(hipStream_t s, const GemmParams& p, int ksplit) {
     dim3 grid((p.N + 15) / 16, ksplit);
@@ -1721,7 +1765,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
     p.drop_mode = drop_mode; p.drop_key = drop_key; p.drop_thr = drop_thr; p.drop_scale = drop_scale;
-    p.g2_splits = 1; p.g2_nk = 0;
+    p.g2_splits = 1; p.g2_nk = 0; p.ws = nullptr;
     { static const char* e = getenv("I2T_G256_GN"); static const int gn = e ? atoi(e) : 8; p.g2_gn = gn > 0 ? gn : 8; }
     {
         static const char* e = getenv("I2T_G256_STAGGER");                   // "units[,groups]"
@@ -1837,6 +1881,40 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, block, 0, s, p);
     }
     I2T_CHECK_LAUNCH("i2t_gemm_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gemm_bf16_ws(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32, int M,
+                                int N, int K, const float* bias, int act, const float* residual, int ldr, float* workspace,
+                                long ws_floats) {
+    // Row-major GEMMs with FEW output tiles and a LONG K (a decode step at a mid-sized caption batch: 64 < M <= ~2048 rows against
+    // N = d .. 3 d, K = d .. 4 d) leave most of the 256 CUs idle in a tile-per-workgroup launch.  Here K is cut into slices, every
+    // (tile, slice) is a workgroup of the 128^2 kernel writing its raw accumulators to its own plane of `workspace`, and a second
+    // launch adds the planes in slice order and applies the fused epilogue: deterministic (greedy decoding stays token-reproducible),
+    // no atomics.  Falls through to i2t_gemm_bf16 when the split does not pay or the workspace is too small.
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk_all = (K + BK - 1) / BK;
+    int splits = 1;
+    while (tiles * splits < 256 && nk_all / (splits * 2) >= 4 && splits < 32) splits *= 2;
+    while (splits > 1 && (long)splits * M * N > ws_floats) splits >>= 1;
+    if (M <= 64 || splits == 1 || !workspace || (act != I2T_ACT_NONE && act != I2T_ACT_GELU) ||
+        (long)((M + 255) / 256) * ((N + 255) / 256) >= 40)
+        return i2t_gemm_bf16(stream, A, lda, 0, B, ldb, 0, C, ldc, c_is_f32, M, N, K, 1.0f, bias, act, nullptr, 0, nullptr, 0, residual,
+                             ldr, 0, 0, 0u, 0u, 1.0f);
+    I2T_REQUIRE(A && B && C, "i2t_gemm_bf16_ws: null operand");
+    I2T_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0 && ALIGNED16(A) && ALIGNED16(B) && lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7) && ldc >= N,
+                "i2t_gemm_bf16_ws: operand layout (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    I2T_REQUIRE(((uintptr_t)C & (c_is_f32 ? 15 : 7)) == 0 && ALIGNED16(workspace), "i2t_gemm_bf16_ws: C / workspace misaligned");
+    GemmParams p = {};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = 1.0f; p.bias = bias; p.act = act; p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32;
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    p.g2_splits = 1; p.g2_gn = 8; p.ws = workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true>), dim3(tiles, splits), dim3(256), 0, s, p);
+    const long quads = (long)M * ((N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, p, splits);
+    I2T_CHECK_LAUNCH("i2t_gemm_bf16_ws");
     return I2T_OK;
 }
 

@@ -38,13 +38,20 @@ def _drop(drop):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
          lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         ldr=None, accumulate=False, drop=None):
-    """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16."""
+         ldr=None, accumulate=False, drop=None, workspace=None):
+    """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16.  workspace (fp32, decode steps): the
+    deterministic split-K form i2t_gemm_bf16_ws when the problem has few tiles and a long K."""
     _need_cuda(a, b, out)
     assert a.dtype == BF16 and b.dtype == BF16 and out.dtype in (BF16, F32)
     lda = a.stride(0) if lda is None else lda
     ldb = b.stride(0) if ldb is None else ldb
     ldc = out.stride(0) if ldc is None else ldc
+    if workspace is not None and not (a_kmajor or b_kmajor or accumulate or drop is not None or aux_in is not None
+                                      or aux_out is not None or alpha != 1.0 or act not in (0, 1)):
+        ldr_ = (residual.stride(0) if residual is not None else 0) if ldr is None else ldr
+        _l.check(_lib().i2t_gemm_bf16_ws(_stream(), _p(a), lda, _p(b), ldb, _p(out), ldc, int(out.dtype == F32), M, N, K, _p(bias), int(act),
+                                         _p(residual), ldr_, _p(workspace), workspace.numel()), 'i2t_gemm_bf16_ws')
+        return out
     ld_ai = aux_in.stride(0) if aux_in is not None else 0
     ld_ao = aux_out.stride(0) if aux_out is not None else 0
     ldr = (residual.stride(0) if residual is not None else 0) if ldr is None else ldr

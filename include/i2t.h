@@ -80,6 +80,14 @@ int i2t_xattn_kv_fused(void* stream, const void* mem, int ld_mem, const void* w_
                        float drop_scale);
 
 /* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients; X bf16 [M][ld]) */
+/* i2t_gemm_bf16 for row-major operands with few output tiles and a long K (a decode step at a mid-sized caption batch): K is cut
+ * into slices, each (tile, slice) workgroup writes its raw accumulators to its own [M][N] fp32 plane of `workspace` (ws_floats
+ * floats), a second launch adds the planes in slice order and applies the epilogue -- bias, act NONE | GELU, fp32 residual, bf16 or
+ * fp32 C.  Deterministic (no atomics).  Falls through to i2t_gemm_bf16 when splitting does not pay, M <= 64 (the weight-streaming
+ * kernel) or the workspace is too small. */
+int i2t_gemm_bf16_ws(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32, int M, int N, int K,
+                     const float* bias, int act, const float* residual, int ldr, float* workspace, long ws_floats);
+
 /* The large-tile GEMM kernels are persistent: one 8-wave workgroup per CU holds the CU's whole LDS and register file and
  * walks a static share of the output tiles.  A kernel from another stream that needs whole CUs for a long time (an RCCL
  * collective overlapped with the backward pass) would leave that many GEMM workgroups waiting for a second round, i.e. double

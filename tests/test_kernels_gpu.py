@@ -489,6 +489,39 @@ def test_grad_normalize(ops):
 
 
 # ------------------------------------------------------------------------------------------------------ conv stack
+@pytest.mark.parametrize('M,N,K,kind', [(256, 1536, 8960, 'res'), (200, 768, 3072, 'gelu'), (1000, 130, 1024, 'bias_f32'), (96, 2304, 768, 'bias'),
+                                        (2048, 768, 3072, 'res'), (64, 768, 3072, 'res'), (300, 50264, 768, 'bias_f32')])
+def test_gemm_deterministic_splitk(ops, M, N, K, kind):
+    """i2t_gemm_bf16_ws (decode steps at mid-sized caption batches): K slices to private fp32 planes + an ordered reduce with the
+    fused epilogue -- against fp64, bit-identical from launch to launch, and falling through to the ordinary kernels where
+    splitting does not pay (M <= 64, many tiles)"""
+    x = rnd(M, K, seed=201, dtype=BF16)
+    w = (rnd(N, K, seed=202) / math.sqrt(K)).to(BF16)
+    bias = 0.1 * rnd(N, seed=203)
+    ws = torch.empty(16 << 20, dtype=F32, device=dev())
+    ref = x.double() @ w.double().t()
+    outs = []
+    for rep in range(3):
+        ws.fill_(float('nan'))                     # a plane that is read without having been written would show
+        if kind == 'res':
+            res0 = rnd(M, N, seed=204)
+            out = res0.clone()
+            ops.gemm(x, w, out, M, N, K, bias=bias, residual=out, workspace=ws)          # in place on the fp32 residual stream
+            want = ref + bias.double() + res0.double()
+        elif kind == 'gelu':
+            out = torch.empty(M, N, dtype=BF16, device=dev())
+            ops.gemm(x, w, out, M, N, K, bias=bias, act=1, workspace=ws)
+            want = F.gelu((ref + bias.double()).float(), approximate='tanh').double()
+        else:
+            out = torch.empty(M, (N + 7) // 8 * 8, dtype=F32 if kind == 'bias_f32' else BF16, device=dev()).zero_()
+            ops.gemm(x, w, out, M, N, K, bias=bias, workspace=ws)
+            want = ref + bias.double()
+            out = out[:, :N]
+        outs.append(out.clone())
+        check(f'splitk {kind} {M}x{N}x{K}', out, want, 2e-2 if out.dtype == BF16 else 3e-3, 1e-2 if out.dtype == BF16 else 2e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), 'the split-K form must be bit-reproducible'
+
+
 def _conv2d(x, w, b):
     """the reference convolution (and, through autograd, its gradients) evaluated on the HOST: keeps MIOpen -- whose first use of a
     configuration on a fresh box builds kernels and once aborted the process -- out of the GPU suite; the device transfers are
