@@ -80,6 +80,9 @@ class GreedyDecoder:
         st.hid = e(B, d)
         st.logits = e(B, dc.Vp, dtype=F32)                      # rows padded to 8 columns: 16-byte aligned rows for the GEMM epilogue
         st.margin = e(B, dtype=F32)
+        # fp32 planes of the deterministic split-K GEMM form (ops.gemm(workspace=...)): the step's GEMMs with few output tiles and a
+        # long K (attention / MLP output projections at anything but the largest caption batches) spread over K slices
+        st.ws = torch.empty(16 << 20, dtype=F32, device=dev)
         if dc.llama is not None:
             ls = dc.llama
             st.qkv, st.ao, st.gu = e(B, (ls.H + 2 * ls.Hkv) * ls.hd), e(B, ls.H * ls.hd), e(B, 2 * ff)
@@ -177,7 +180,7 @@ class GreedyDecoder:
                 kv, S = st.cross_kv[l]
                 win, bin_ = a.W(f'{p}.cross_attn.in_proj_weight'), a.P(f'{p}.cross_attn.in_proj_bias')
                 ops.layernorm_fwd(xo, a.P(f'{p}.ln_3.weight'), a.P(f'{p}.ln_3.bias'), st.ln, None, None, B, d)
-                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d])
+                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d], workspace=st.ws)
                 ops.gq_decode_attention(st.q, None, None, kv, kv.view(-1)[d:], S * 2 * d, 2 * d, st.ao, None, S, S, B, H, H, hd)
                 ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), xo, B, d, d, bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=xo)
             ops.layernorm_fwd(xo, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
@@ -255,21 +258,23 @@ class GreedyDecoder:
         for l in range(dc.L):
             p = f'{dp}transformer.h.{l}'
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
-            ops.gemm(st.ln, self._w(l, 'attn_c_attn', f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
+            ops.gemm(st.ln, self._w(l, 'attn_c_attn', f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'),
+                     workspace=st.ws)
             ops.decode_attention(st.qkv, 3 * d, st.kc[l], st.vc[l], st.clen * d, 64, st.ao, d, pos_ptr, 0, B, H, append_dm=d,
                                  cache_hs=st.clen * 64)           # head-major self-attention cache [B][H][prefix + tmax][64]
-            ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x)
+            ops.gemm(st.ao, a.W(f'{p}.attn.c_proj.weight'), st.x, B, d, d, bias=a.P(f'{p}.attn.c_proj.bias'), residual=st.x, workspace=st.ws)
             if l in st.cross_kv:
                 kv, S = st.cross_kv[l]
                 win, bin_ = a.W(f'{p}.cross_attn.in_proj_weight'), a.P(f'{p}.cross_attn.in_proj_bias')
                 ops.layernorm_fwd(st.x, a.P(f'{p}.ln_3.weight'), a.P(f'{p}.ln_3.bias'), st.ln, None, None, B, d)
-                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d])
+                ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d], workspace=st.ws)
                 ops.decode_attention(st.q, d, kv, kv.view(-1)[d:], S * 2 * d, 2 * d, st.ao, d, None, S, B, H)
                 ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), st.x, B, d, d,
-                         bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=st.x)
+                         bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=st.x, workspace=st.ws)
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
-            ops.gemm(st.ln, self._w(l, 'mlp_c_fc', f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
-            ops.gemm(st.h, self._w(l, 'mlp_c_proj', f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x)
+            ops.gemm(st.ln, self._w(l, 'mlp_c_fc', f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1, workspace=st.ws)
+            ops.gemm(st.h, self._w(l, 'mlp_c_proj', f'{p}.mlp.c_proj.weight'), st.x, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=st.x,
+                     workspace=st.ws)
 
     def _layers_llama(self, st):
         """The Llama-2 / Qwen2 blocks of one decode step (engine_llama.py): the rotary angle is looked up at the position counter on
@@ -281,15 +286,15 @@ class GreedyDecoder:
         for l in range(dc.L):
             v = eng._llama_views(l)
             ops.rmsnorm_fwd(st.x, v.n1, st.ln, None, B, d, ls.eps)
-            ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, bias=v.bqkv)
+            ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, bias=v.bqkv, workspace=st.ws)
             ops.rope(st.qkv, v.nq, 0, H + G, hd, cs, B, pos_ptr=pos_ptr)
             ops.gq_decode_attention(st.qkv[:, :H * hd], st.qkv[:, H * hd:(H + G) * hd], st.qkv[:, (H + G) * hd:], st.kc[l], st.vc[l],
                                     st.clen * G * hd, G * hd, st.ao, pos_ptr, 0, st.clen, B, H, G, hd)
-            ops.gemm(st.ao, v.Wo, st.x, B, d, H * hd, residual=st.x)
+            ops.gemm(st.ao, v.Wo, st.x, B, d, H * hd, residual=st.x, workspace=st.ws)
             ops.rmsnorm_fwd(st.x, v.n2, st.ln, None, B, d, ls.eps)
-            ops.gemm(st.ln, v.Wgu, st.gu, B, 2 * ff, d)
+            ops.gemm(st.ln, v.Wgu, st.gu, B, 2 * ff, d, workspace=st.ws)
             ops.swiglu_fwd(st.gu, st.h, B, ff)
-            ops.gemm(st.h, v.Wdn, st.x, B, d, ff, residual=st.x)
+            ops.gemm(st.h, v.Wdn, st.x, B, d, ff, residual=st.x, workspace=st.ws)
 
     def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None):
         side = torch.cuda.Stream(device=st.arena.device)

@@ -19,7 +19,7 @@ def main():
     shapes = [('qkv  bf16+bias', nq, d, dict()), ('o    f32+res', d, d, dict(res=True)), ('g|u  bf16', 2 * ff, d, dict(nobias=True)),
               ('down f32+res', d, ff, dict(res=True))]
     ws = torch.empty(32 << 20, dtype=F32, device=dev)
-    for M in (64, 128, 256, 512, 1024, 2048):
+    for M in (64, 128, 256, 512, 1024, 2048, 4096):
         for name, N, K, kw in shapes:
             a = (torch.randn(M, K, device=dev) * 0.5).to(BF16)
             w = (torch.randn(N, K, device=dev) * 0.03).to(BF16)
@@ -32,7 +32,7 @@ def main():
                 for m0 in range(0, M, 64):
                     o = out[m0:m0 + 64]
                     ops.gemm(a[m0:m0 + 64], w, o, min(64, M - m0), N, K, bias=bias, residual=o if kw.get('res') else None)
-            t1 = timeit(chunks, reps=20)
+            t1 = timeit(chunks, reps=20) if M <= 512 else float('nan')
             t2 = timeit(lambda: ops.gemm(a, w, out, M, N, K, workspace=ws, **args), reps=20)
             wb = N * K * 2
             print(f'M={M:5d} {name:15s} N={N:5d} K={K:5d}  router {t0 * 1e6:7.1f} us ({wb / t0 / 1e9:6.0f} GB/s of weights)   '
