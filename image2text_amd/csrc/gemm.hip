@@ -1896,7 +1896,9 @@ extern "C" int i2t_gemm_bf16_ws(void* stream, const void* A, int lda, const void
     int splits = 1;
     while (tiles * splits < 256 && nk_all / (splits * 2) >= 4 && splits < 32) splits *= 2;
     while (splits > 1 && (long)splits * M * N > ws_floats) splits >>= 1;
-    if (M <= 64 || splits == 1 || !workspace || (act != I2T_ACT_NONE && act != I2T_ACT_GELU))
+    // (M > 2048: the planes' write + read -- splits x M x N fp32 each way -- is HBM traffic the decode step cannot spare once several
+    // 4096-caption batches run concurrently: the benchmark's decode leg lost 7 % with the split form and keeps the persistent kernel)
+    if (M <= 64 || M > 2048 || splits == 1 || !workspace || (act != I2T_ACT_NONE && act != I2T_ACT_GELU))
         return i2t_gemm_bf16(stream, A, lda, 0, B, ldb, 0, C, ldc, c_is_f32, M, N, K, 1.0f, bias, act, nullptr, 0, nullptr, 0, residual,
                              ldr, 0, 0, 0u, 0u, 1.0f);
     I2T_REQUIRE(A && B && C, "i2t_gemm_bf16_ws: null operand");

@@ -84,7 +84,7 @@ int i2t_xattn_kv_fused(void* stream, const void* mem, int ld_mem, const void* w_
  * into slices, each (tile, slice) workgroup writes its raw accumulators to its own [M][N] fp32 plane of `workspace` (ws_floats
  * floats), a second launch adds the planes in slice order and applies the epilogue -- bias, act NONE | GELU, fp32 residual, bf16 or
  * fp32 C.  Deterministic (no atomics).  Falls through to i2t_gemm_bf16 when splitting does not pay, M <= 64 (the weight-streaming
- * kernel) or the workspace is too small. */
+ * kernel), M > 2048 (the planes' traffic outweighs the idle CUs) or the workspace is too small. */
 int i2t_gemm_bf16_ws(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32, int M, int N, int K,
                      const float* bias, int act, const float* residual, int ldr, float* workspace, long ws_floats);
 

@@ -490,11 +490,11 @@ def test_grad_normalize(ops):
 
 # ------------------------------------------------------------------------------------------------------ conv stack
 @pytest.mark.parametrize('M,N,K,kind', [(256, 1536, 8960, 'res'), (200, 768, 3072, 'gelu'), (1000, 130, 1024, 'bias_f32'), (96, 2304, 768, 'bias'),
-                                        (2048, 768, 3072, 'res'), (64, 768, 3072, 'res'), (300, 50264, 768, 'bias_f32')])
+                                        (2048, 768, 3072, 'res'), (64, 768, 3072, 'res'), (300, 50264, 768, 'bias_f32'), (4096, 768, 3072, 'res')])
 def test_gemm_deterministic_splitk(ops, M, N, K, kind):
     """i2t_gemm_bf16_ws (decode steps at mid-sized caption batches): K slices to private fp32 planes + an ordered reduce with the
     fused epilogue -- against fp64, bit-identical from launch to launch, and falling through to the ordinary kernels where
-    splitting does not pay (M <= 64, many tiles)"""
+    splitting does not pay (M <= 64, M > 2048, many tiles)"""
     x = rnd(M, K, seed=201, dtype=BF16)
     w = (rnd(N, K, seed=202) / math.sqrt(K)).to(BF16)
     bias = 0.1 * rnd(N, seed=203)
