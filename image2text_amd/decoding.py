@@ -168,31 +168,31 @@ class GreedyDecoder:
             pos_ptr = st.lpos[l:l + 1] if st.sparse else st.counters[0:1]
             ops.layernorm_fwd(st.x, a.P(f'{p}.ln_1.weight'), a.P(f'{p}.ln_1.bias'), st.ln, None, None, B, d)
             if sp.mqa:
-                ops.gemm(st.ln, a.W(f'{p}.attn.q_proj.weight'), st.q, B, d, d, bias=a.P(f'{p}.attn.q_proj.bias'))
-                ops.gemm(st.ln, a.W(f'{p}.attn.kv_proj.weight'), st.kvn, B, 2 * hd, d, bias=a.P(f'{p}.attn.kv_proj.bias'))
+                ops.gemm(st.ln, a.W(f'{p}.attn.q_proj.weight'), st.q, B, d, d, bias=a.P(f'{p}.attn.q_proj.bias'), workspace=st.ws)
+                ops.gemm(st.ln, a.W(f'{p}.attn.kv_proj.weight'), st.kvn, B, 2 * hd, d, bias=a.P(f'{p}.attn.kv_proj.bias'), workspace=st.ws)
                 qv, kn, vn, out_name = st.q, st.kvn[:, :hd], st.kvn[:, hd:], 'attn.out_proj'
             else:
-                ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'))
+                ops.gemm(st.ln, a.W(f'{p}.attn.c_attn.weight'), st.qkv, B, 3 * d, d, bias=a.P(f'{p}.attn.c_attn.bias'), workspace=st.ws)
                 qv, kn, vn, out_name = st.qkv[:, :d], st.qkv[:, d:2 * d], st.qkv[:, 2 * d:], 'attn.c_proj'
             ops.gq_decode_attention(qv, kn, vn, st.kc[l], st.vc[l], st.slots * w, w, st.ao, pos_ptr, 0, st.slots, B, H, Hkv, hd)
-            ops.gemm(st.ao, a.W(f'{p}.{out_name}.weight'), xo, B, d, d, bias=a.P(f'{p}.{out_name}.bias'), residual=st.x)
+            ops.gemm(st.ao, a.W(f'{p}.{out_name}.weight'), xo, B, d, d, bias=a.P(f'{p}.{out_name}.bias'), residual=st.x, workspace=st.ws)
             if l in st.cross_kv:
                 kv, S = st.cross_kv[l]
                 win, bin_ = a.W(f'{p}.cross_attn.in_proj_weight'), a.P(f'{p}.cross_attn.in_proj_bias')
                 ops.layernorm_fwd(xo, a.P(f'{p}.ln_3.weight'), a.P(f'{p}.ln_3.bias'), st.ln, None, None, B, d)
                 ops.gemm(st.ln, win[:d], st.q, B, d, d, bias=bin_[:d], workspace=st.ws)
                 ops.gq_decode_attention(st.q, None, None, kv, kv.view(-1)[d:], S * 2 * d, 2 * d, st.ao, None, S, S, B, H, H, hd)
-                ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), xo, B, d, d, bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=xo)
+                ops.gemm(st.ao, a.W(f'{p}.cross_attn.out_proj.weight'), xo, B, d, d, bias=a.P(f'{p}.cross_attn.out_proj.bias'), residual=xo, workspace=st.ws)
             ops.layernorm_fwd(xo, a.P(f'{p}.ln_2.weight'), a.P(f'{p}.ln_2.bias'), st.ln, None, None, B, d)
             if sp.moe is not None:
                 self._moe_step(st, f'{p}.mlp.c_fc', st.ln, st.h, 1, None)
                 self._moe_step(st, f'{p}.mlp.c_proj', st.h, xo, 0, xo)
             else:
-                ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1)
-                ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), xo, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=xo)
+                ops.gemm(st.ln, a.W(f'{p}.mlp.c_fc.weight'), st.h, B, ff, d, bias=a.P(f'{p}.mlp.c_fc.bias'), act=1, workspace=st.ws)
+                ops.gemm(st.h, a.W(f'{p}.mlp.c_proj.weight'), xo, B, d, ff, bias=a.P(f'{p}.mlp.c_proj.bias'), residual=xo, workspace=st.ws)
             if st.sparse:
                 ops.cast_f32_bf16(st.x, st.xnb)
-                ops.gemm(st.xnb, a.W(f'{p}.null_connector.weight'), st.xn, B, d, d, bias=a.P(f'{p}.null_connector.bias'), residual=st.x)
+                ops.gemm(st.xnb, a.W(f'{p}.null_connector.weight'), st.xn, B, d, d, bias=a.P(f'{p}.null_connector.bias'), residual=st.x, workspace=st.ws)
                 ops.select_rows(st.lmem[l:l + 1], st.xb, st.xn, st.x, B * d)
 
     def _cross_layers(self):
@@ -232,7 +232,7 @@ class GreedyDecoder:
                 ops.rmsnorm_fwd(st.x, a.P(f'{dp}backbone.model.norm.weight'), st.hid, None, B, d, dc.llama.eps)
             else:
                 ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
-            ops.gemm(st.hid, a.W(eng.n_head), st.logits, B, dc.V, d)
+            ops.gemm(st.hid, a.W(eng.n_head), st.logits, B, dc.V, d, workspace=st.ws)
             if sampling is None:
                 ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
             else:
