@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_one_rank_rccl_hooked_exchange_matches_unhooked():
+@pytest.mark.parametrize('model', ['nano224', 'gpt2_lora'])
+def test_one_rank_rccl_hooked_exchange_matches_unhooked(model):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', I2T_DP_SELFCHECK_MODEL=model)
     env.pop('NCCL_MAX_NCHANNELS', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_selfcheck.py')]
