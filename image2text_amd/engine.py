@@ -940,24 +940,26 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
             Mt = int(px.hb_text.shape[0])
             dh = torch.zeros(ctx.M, d, dtype=F32, device=a.device)
             if dlogits_bf is not None and Mt:
-                ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, Mt, a_kmajor=True, b_kmajor=True, accumulate=True)
+                if a.trainable(head):
+                    ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, Mt, a_kmajor=True, b_kmajor=True, accumulate=True)
                 dht = self._empty(Mt, d)
                 ops.gemm(dlogits_bf, a.W(head), dht, Mt, d, dc.V, b_kmajor=True)
                 dh[px.is_text] = dht
             dx = self.decode_backward(ctx, None, dh, dmem)
             dmem.view(B, -1, d)[:, :n_p] += dx[~px.is_text].view(B, n_p, d)
-            if Mt:
+            if Mt and a.trainable(wte):
                 ops.embed_bwd(px.ids, dx[px.is_text].contiguous(), a.G(wte), None, Mt, 1, d, 0, dc.V)
             return
         dh = torch.zeros(B, n_p + T, d, dtype=F32, device=a.device) if dhid is None else dhid.to(F32).reshape(B, n_p + T, d).clone()
         if dlogits_bf is not None and T:
-            ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
+            if a.trainable(head):
+                ops.gemm(dlogits_bf, px.hb_text, a.G(head), dc.V, d, B * T, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
             dht = self._empty(B * T, d)
             ops.gemm(dlogits_bf, a.W(head), dht, B * T, d, dc.V, b_kmajor=True)
             dh[:, n_p:] += dht.view(B, T, d)
         dx = self.decode_backward(ctx, None, dh.view(B * (n_p + T), d), dmem).view(B, n_p + T, d)
         dmem.view(B, -1, d)[:, :n_p] += dx[:, :n_p]
-        if T:
+        if T and a.trainable(wte):
             ops.embed_bwd(px.ids, dx[:, n_p:].contiguous().view(B * T, d), a.G(wte), None, B, T, d, 0, dc.V)
 
     def logits_f32(self, hb: torch.Tensor, M: int):
@@ -1020,13 +1022,16 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
         wte, head = self.n_wte, self.n_head
         dh = torch.zeros(M, d, dtype=F32, device=a.device) if dlogits_bf is None else self._empty(M, d)
         if dlogits_bf is not None:
-            ops.gemm(dlogits_bf, ctx.hb, a.G(head), dc.V, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
+            if a.trainable(head):
+                ops.gemm(dlogits_bf, ctx.hb, a.G(head), dc.V, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)   # lm_head (tied or not)
             ops.gemm(dlogits_bf, a.W(head), dh, M, d, dc.V, b_kmajor=True)
         if dhid is not None:
             ops.add_(dh, dhid.contiguous())
         if dc.llama is not None:
             dx = self.llama_decode_bwd(ctx, dh)
             if ctx.ids is not None:
+                if not a.trainable(wte):
+                    return None
                 if ctx.vl is not None:
                     ops.embed_bwd(ctx.ids, dx, a.G(wte), None, M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
                 else:

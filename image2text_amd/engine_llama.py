@@ -45,7 +45,9 @@ class LlamaBlocks:
             Wgu=a.span('W', gu, (2 * ls.ff, ls.d)), Ggu=a.span('G', gu, (2 * ls.ff, ls.d)),
             Wdn=a.W(f'{p}.mlp.down_proj.weight'), Gdn=a.G(f'{p}.mlp.down_proj.weight'),
             n1=a.P(f'{p}.input_layernorm.weight'), gn1=a.G(f'{p}.input_layernorm.weight'),
-            n2=a.P(f'{p}.post_attention_layernorm.weight'), gn2=a.G(f'{p}.post_attention_layernorm.weight'))
+            n2=a.P(f'{p}.post_attention_layernorm.weight'), gn2=a.G(f'{p}.post_attention_layernorm.weight'),
+            names=SimpleNamespace(qkv=qkv_w, qkv_b=qkv_b, o=f'{p}.self_attn.o_proj.weight', gu=gu, dn=f'{p}.mlp.down_proj.weight',
+                                  n1=f'{p}.input_layernorm.weight', n2=f'{p}.post_attention_layernorm.weight'))
         self._sub_cache[key] = v
         return v
 
@@ -92,18 +94,24 @@ class LlamaBlocks:
         M, d, H, G, hd, ff = (vl.total if vl is not None else B * T), ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
         cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
         v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
+        # frozen parameters (prepare_for_kbit_training, models/decoder.py): their gradient GEMMs are skipped, the input gradient is not
+        tr = (lambda names: all(self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names)))
+        nm = v.names
         # ---- MLP
-        ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if tr(nm.dn):
+            ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dh = self._empty(M, ff, dtype=BF16)
         ops.gemm(dxb, v.Wdn, dh, M, ff, d, b_kmajor=True)
         dgu = self._empty(M, 2 * ff, dtype=BF16)
         ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
-        ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if tr(nm.gu):
+            ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dn = self._empty(M, d, dtype=BF16)
         ops.gemm(dgu, v.Wgu, dn, M, d, 2 * ff, b_kmajor=True)
-        ops.rmsnorm_bwd(dn, sv.x1, v.n2, sv.r2, dx, v.gn2, M, d, dx_accumulate=True, dx_bf16=dxb)
+        ops.rmsnorm_bwd(dn, sv.x1, v.n2, sv.r2, dx, v.gn2 if tr(nm.n2) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
         # ---- attention
-        ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if tr(nm.o):
+            ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dao = self._empty(M, H * hd, dtype=BF16)
         ops.gemm(dxb, v.Wo, dao, M, H * hd, d, b_kmajor=True)
         dqkv = self._empty(M, v.nq, dtype=BF16)
@@ -113,11 +121,12 @@ class LlamaBlocks:
                              self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True,
                              cu_q=cu, cu_k=cu, total_q=M)
         ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos=rpos, pos_offset=pos_offset, T=T, inverse=True)
-        if v.gbqkv is not None:
+        if v.gbqkv is not None and tr(nm.qkv_b):
             ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
-        ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        if tr(nm.qkv):
+            ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         ops.gemm(dqkv, v.Wqkv, dn, M, d, v.nq, b_kmajor=True)
-        ops.rmsnorm_bwd(dn, sv.x, v.n1, sv.r1, dx, v.gn1, M, d, dx_accumulate=True, dx_bf16=dxb)
+        ops.rmsnorm_bwd(dn, sv.x, v.n1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
 
     # ------------------------------------------------------------------------------------------------ the decoder stack
     def llama_decode_fwd(self, B: int, T: int, save: bool, ids, embeds, pos_offset: int, vl):
@@ -150,7 +159,7 @@ class LlamaBlocks:
         M, d = ctx.M, dc.d
         dx, dxb = self._empty(M, d), self._empty(M, d, dtype=BF16)
         wn = f'{self.dp}backbone.model.norm.weight'
-        ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn), ctx.rf, dx, a.G(wn), M, d, dx_bf16=dxb)
+        ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn), ctx.rf, dx, a.Gt(wn), M, d, dx_bf16=dxb)
         for l in reversed(range(dc.L)):
             self.llama_block_bwd(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset, ctx.vl)
         return dx

@@ -24,6 +24,16 @@ from .layers import AdvancedPositionalBiasMLP, LayerNorm, TransformerBlock, init
 from .utils import mutate_transformer_config
 
 
+def _freeze_like_prepare_for_kbit_training(decoder: nn.Module):
+    """``prepare_for_kbit_training: True`` on a model that is NOT loaded in 4 bits (reference decoder.py:325-327 -> peft's
+    prepare_model_for_kbit_training; e.g. training_configs/local/llama2-7b.yaml): what remains of that call is "freeze the base model's
+    layers" -- every parameter's requires_grad goes off (the fp32 upcast of half-precision parameters is a no-op here: the arena's
+    master copy is fp32; gradient checkpointing has no counterpart on a hand-written backward).  The hot path then skips every
+    weight-gradient GEMM of the decoder and only carries the input gradient back to the soft prompt, i.e. to the encoder."""
+    for p in decoder.parameters():
+        p.requires_grad = False
+
+
 class Decoder(nn.Module, abc.ABC):
     def __init__(self):
         super().__init__()
@@ -180,8 +190,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
 
     def __init__(self, config: HuggingfaceDecoderConfig, space_for_prompt: int = 0):
         assert config.model_str.startswith('gpt2')
-        if config.load_in_4bit or config.prepare_for_kbit_training:
-            raise NotImplementedError('4-bit loading / k-bit training (bitsandbytes) is outside the HIP hot path')
+        if config.load_in_4bit:
+            raise NotImplementedError('4-bit loading (bitsandbytes) is outside the HIP hot path')
         from transformers import AutoConfig, AutoModelForCausalLM
         kwargs = {}
         if config.use_cross_attn:
@@ -226,6 +236,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
                               if not (k.endswith('.attn.masked_bias') or k.endswith('.attn.bias')
                                       or k.endswith('.crossattention.masked_bias') or k.endswith('.crossattention.bias'))})
         self.tie_weights()
+        if config.prepare_for_kbit_training:
+            _freeze_like_prepare_for_kbit_training(self)
         if config.lora_spec is not None:
             self._apply_lora(config.lora_spec)
 
@@ -376,8 +388,8 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
 
     def __init__(self, config: HuggingfaceDecoderConfig):
         super().__init__()
-        if config.load_in_4bit or config.prepare_for_kbit_training:
-            raise NotImplementedError('4-bit loading / k-bit training (bitsandbytes) is outside the HIP hot path')
+        if config.load_in_4bit:
+            raise NotImplementedError('4-bit loading (bitsandbytes) is outside the HIP hot path')
         if config.use_cross_attn:
             raise ValueError("Don't know how to use cross attention with this model. Suggest you try a different config!!!")
         from transformers import AutoModelForCausalLM
@@ -407,6 +419,8 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         if config.enable_gradient_checkpointing:
             pass            # the hot path keeps what its hand-written backward needs; nothing to switch on (decoder.py:322-323)
         self.backbone = hf
+        if config.prepare_for_kbit_training:
+            _freeze_like_prepare_for_kbit_training(self)
         self.llama_spec = SimpleNamespace(
             d=hc.hidden_size, H=hc.num_attention_heads, Hkv=hc.num_key_value_heads, hd=hd, L=hc.num_hidden_layers,
             ff=hc.intermediate_size, V=config.vocab_size + config.extra_tokens, eps=float(hc.rms_norm_eps), block=self.block_size,

@@ -345,6 +345,62 @@ def test_llama_family_decoder_forward_gradients_generate(tmp_path, monkeypatch, 
         assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
 
 
+def test_llama_decoder_frozen_by_prepare_for_kbit_training(tmp_path, monkeypatch):
+    """prepare_for_kbit_training: True without 4-bit loading (reference local/llama2-7b.yaml; peft freezes the base model): no decoder
+    parameter receives a gradient, the weight-gradient GEMMs are skipped, and the encoder's gradients -- through the soft prompt rows of
+    the frozen decoder -- still match autograd through oracle encoder + transformers"""
+    import copy
+    from oracle import reference_model as orc
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    from test_host_cpu import _local_hf_llama
+    _, name, vocab = _local_hf_llama(tmp_path, monkeypatch, 'llama')
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=0, prepare_for_kbit_training=True),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    tok = fake_tokenizer(vocab)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    keep = {k: v.detach().clone() for k, v in w.model.decoder.state_dict().items()}
+    det_init_(w.model, seed=0)
+    w.model.decoder.load_state_dict(keep)
+    hf = copy.deepcopy(w.model.decoder.backbone).float().eval()
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in w.model.state_dict().items() if not k.startswith('decoder.')}
+    w = w.to(dev()).train()
+    images, labels = synthetic_batch(3, 32, 12, vocab, seed=17)
+    from image2text_amd import ops
+    calls = []
+    orig = ops.gemm
+    monkeypatch.setattr(ops, 'gemm', lambda *a, **k: (calls.append(bool(k.get('a_kmajor'))), orig(*a, **k))[1])
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    monkeypatch.setattr(ops, 'gemm', orig)
+    ids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
+    _, sl, _ = _llama_reference(orc, esd, hf, cfg, images, ids)
+    ce = F.cross_entropy(sl.reshape(-1, vocab), labels.reshape(-1), ignore_index=-100, reduction='none')
+    oloss = (ce * orc.loss_weights(labels, -100).reshape(-1)).sum()
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * float(oloss)
+    fails = []
+    for n, p in w.model.named_parameters():
+        if n.startswith('decoder.'):
+            assert p.grad is None and not p.requires_grad, n
+            continue
+        try:
+            grad_close(f'hf_llama_frozen.{n}', p.grad, esd[n].grad.numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, '; '.join(fails[:6])
+    # weight-gradient GEMMs (k-major A operand) ran for the encoder only: none of the decoder's 2 x 4 + lm_head
+    enc_dw = sum(calls)
+    w.model.decoder.requires_grad_(True)
+    calls.clear()
+    monkeypatch.setattr(ops, 'gemm', lambda *a, **k: (calls.append(bool(k.get('a_kmajor'))), orig(*a, **k))[1])
+    w.model.zero_grad(set_to_none=True)
+    w.train_step(images.to(dev()), labels.to(dev()))[0].backward()
+    monkeypatch.setattr(ops, 'gemm', orig)
+    assert sum(calls) == enc_dw + 2 * 4 + 1, (sum(calls), enc_dw)
+
+
 def test_llama_row_kernels():
     """i2t_rmsnorm_fwd / _bwd, i2t_rope (forward, inverse, position sources) and i2t_swiglu_fwd / _bwd against torch fp32"""
     from image2text_amd import ops

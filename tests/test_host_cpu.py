@@ -392,6 +392,11 @@ def test_gpt2_huggingface_decoder_lora(tmp_path, monkeypatch):
     d3 = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec(force_enable_update_modules=None, target_modules=None)))
     assert d3.lora.sites == ('attn_c_attn', 'xattn_c_attn')                  # peft's default target for gpt2: c_attn
     assert [n for n, p in d3.named_parameters() if p.requires_grad] == [n for n, _ in d3.named_parameters() if n.startswith('lora_params.')]
+    # prepare_for_kbit_training without 4-bit loading (local/llama2-7b.yaml): peft's call freezes the base model -- and nothing else
+    d4 = Decoder.from_config(_hf_decoder_config(prepare_for_kbit_training=True))
+    assert not any(p.requires_grad for p in d4.parameters())
+    d5 = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, prepare_for_kbit_training=True, lora_spec=_lora_spec()))
+    assert {n: p.requires_grad for n, p in d5.named_parameters()} == grads
     with pytest.raises(NotImplementedError, match='target_modules'):
         Decoder.from_config(_hf_decoder_config(lora_spec=_lora_spec(target_modules=['attn.c_proj'])))
     with pytest.raises(NotImplementedError, match='splits'):
@@ -451,6 +456,8 @@ def test_llama_qwen2_huggingface_decoder_plugins(tmp_path, monkeypatch):
         tab = d.rope_table(16)
         cos, sin = hf.model.rotary_emb(torch.zeros(1, 1), torch.arange(16)[None])
         assert tab.shape == (16, ls.hd) and torch.equal(tab[:, :ls.hd // 2], cos[0, :, :ls.hd // 2]) and torch.equal(tab[:, ls.hd // 2:], sin[0, :, ls.hd // 2:])
+        frozen = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, prepare_for_kbit_training=True))
+        assert not any(p.requires_grad for p in frozen.parameters())
         with pytest.raises(ValueError, match='cross attention'):
             Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, use_cross_attn=True))
     with pytest.raises(AssertionError):

@@ -51,6 +51,8 @@ def main():
     ap.add_argument('--new-tokens', type=int, default=64)
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--freeze-decoder', action='store_true', help='prepare_for_kbit_training: True without 4-bit loading (reference '
+                    'local/llama2-7b.yaml): the decoder is frozen, only the encoder trains through the soft prompt')
     ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
                     "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
     args = ap.parse_args()
@@ -76,7 +78,7 @@ def main():
         transformers.AutoModelForCausalLM.from_config(hf_cfg, dtype=torch.bfloat16 if big else torch.float32).save_pretrained(name)
         print(f'[bench_hf_decoder] random checkpoint written in {time.perf_counter() - t_init:.0f} s', file=sys.stderr, flush=True)
         dcfg = HuggingfaceDecoderConfig(vocab_size=vocab, use_cross_attn=False, model_str=name, extra_tokens=0, load_in_4bit=False,
-                                        prepare_for_kbit_training=False)
+                                        prepare_for_kbit_training=args.freeze_decoder)
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=False, use_soft_prompting=True))
         V, eos = vocab, vocab - 1
     else:
@@ -88,7 +90,7 @@ def main():
             lora = LoraSpec(r=16, lora_alpha=64, lora_dropout=0.1, target_modules=['c_attn', 'mlp.c_fc', 'mlp.c_proj'],
                             force_enable_update_modules=['*.wpe.*', '*.wte.*', '*.crossattention.*', '*.ln_cross_attn.*'])
         dcfg = HuggingfaceDecoderConfig(vocab_size=50257, use_cross_attn=True, model_str=name, extra_tokens=2, load_in_4bit=False,
-                                        prepare_for_kbit_training=False, lora_spec=lora)
+                                        prepare_for_kbit_training=args.freeze_decoder, lora_spec=lora)
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
         V, eos = 50259, 50256
     tok = fake_tokenizer(V, eos=eos)
@@ -120,7 +122,7 @@ def main():
     kind = type(wrapper.model.decoder).__name__
     out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + {kind}({args.size}, randomly initialised checkpoint, '
                        + ('' if llama else 'cross-attention, dropout 0.1, ') +
-                       f'soft prompt of 64 + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else ', every parameter trains'),
+                       f'soft prompt of 64 + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else (', decoder frozen (prepare_for_kbit_training)' if args.freeze_decoder else ', every parameter trains')),
            'params_M': round(n_params / 1e6, 1), 'trainable_params_M': round(n_train / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
