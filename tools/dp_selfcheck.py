@@ -119,6 +119,9 @@ def main():
     wrapper.train_step(images[8:], labels[8:])[0].backward()
     acc0 = grads()
     err2 = float((acc1 - acc0).abs().max()) / float(acc0.abs().max())
+    if err2 > max(4 * floor, 1e-5):            # name the arena entries that differ (diagnostic for the assertion below)
+        worst = sorted(((float((acc1[o:o + n] - acc0[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:6]
+        print('DP_SELFCHECK accumulation mismatch, worst entries:', worst, 'max |g| =', float(acc0.abs().max()), flush=True)
     assert err2 <= max(4 * floor, 1e-5), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
     torch.cuda.synchronize()
     print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
