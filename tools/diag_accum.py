@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""diagnostic: gradient accumulation over two micro-batches, repeated under different conditions (tiny model, VALU conv path)"""
+import os, sys, tempfile
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from image2text_amd import ops
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import det_init_, fake_tokenizer, synthetic_batch, tiny_config
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    dev = torch.device('cuda:0')
+    which = sys.argv[1] if len(sys.argv) > 1 else 'plain'
+    if which == 'gpt2_lora':
+        from transformers import GPT2Config, GPT2LMHeadModel
+        from image2text_amd.configs.models import HuggingfaceDecoderConfig, LoraSpec
+        os.chdir(tempfile.mkdtemp(prefix='i2t_dp_'))
+        torch.manual_seed(0)
+        GPT2LMHeadModel(GPT2Config(n_layer=2, n_head=4, n_embd=256, n_positions=128, vocab_size=1000, resid_pdrop=0.0, embd_pdrop=0.0,
+                                   attn_pdrop=0.0)).save_pretrained('gpt2-dp')
+        lora = LoraSpec(r=8, lora_alpha=16, lora_dropout=0.0, target_modules=['c_attn', 'mlp.c_fc', 'mlp.c_proj'],
+                        force_enable_update_modules=['*.wte.*', '*.crossattention.*'])
+        dcfg = HuggingfaceDecoderConfig(vocab_size=1000, use_cross_attn=True, model_str='gpt2-dp', extra_tokens=0, load_in_4bit=False,
+                                        prepare_for_kbit_training=False, lora_spec=lora)
+        cfg = tiny_config(dec_d=256, dec_heads=4).model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
+        V = 1000
+    else:
+        cfg = tiny_config()
+        V = cfg.decoder_config.vocab_size
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100)
+    if which != 'gpt2_lora':
+        det_init_(w.model, seed=3)
+    w = w.to(dev).train()
+    images, labels = synthetic_batch(16, 32, 24, V, seed=5)
+    images, labels = images.to(dev), labels.to(dev)
+    eng = w.model._engine
+
+    def accum(reserve_second=False, whole=False):
+        for p in w.model.parameters():
+            p.grad = None
+        if whole:
+            w.train_step(images, labels)[0].backward()
+        else:
+            w.train_step(images[:8], labels[:8])[0].backward()
+            if reserve_second:
+                ops.gemm_reserve_cus(16)
+            w.train_step(images[8:], labels[8:])[0].backward()
+            ops.gemm_reserve_cus(0)
+        torch.cuda.synchronize()
+        return eng.arena.g32.clone()
+
+    def cmp(tag, x, y):
+        worst = sorted(((float((x[o:o + n] - y[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:3]
+        print(tag, 'rel', float((x - y).abs().max()) / float(y.abs().max()), worst, flush=True)
+
+    a0 = accum()
+    a1 = accum()
+    a2 = accum(reserve_second=True)
+    a3 = accum()
+    cmp('plain vs plain      ', a1, a0)
+    cmp('reserved vs plain   ', a2, a0)
+    cmp('plain again vs plain', a3, a0)
+    b0, b1 = accum(whole=True), accum(whole=True)
+    cmp('whole vs whole      ', b1, b0)
+
+
+if __name__ == '__main__':
+    main()
