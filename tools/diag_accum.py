@@ -63,6 +63,10 @@ def main():
     cmp('plain again vs plain', a3, a0)
     b0, b1 = accum(whole=True), accum(whole=True)
     cmp('whole vs whole      ', b1, b0)
+    cmp('first accum vs whole', a0, b0)
+    cmp('later accum vs whole', a1, b0)
+    c0 = accum()
+    cmp('accum after whole   ', c0, b0)
 
 
 if __name__ == '__main__':
