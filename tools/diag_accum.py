@@ -69,5 +69,53 @@ def main():
     cmp('accum after whole   ', c0, b0)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 1 and sys.argv[1] == 'poison'):
     main()
+
+
+def poison():
+    """run one whole-batch pass on NaN-poisoned allocator blocks and report which gradients pick up NaNs"""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import det_init_, fake_tokenizer, synthetic_batch, tiny_config
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    dev = torch.device('cuda:0')
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    w = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100)
+    det_init_(w.model, seed=3)
+    w = w.to(dev).train()
+    images, labels = synthetic_batch(16, 32, 24, V, seed=5)
+    images, labels = images.to(dev), labels.to(dev)
+    eng = w.model._engine
+    w.train_step(images, labels)[0].backward()          # builds the arena and the persistent buffers
+    for p in w.model.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
+    for val in (float('nan'), 1e4):
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 26,), val, device=dev) for _ in range(4)]          # 1 GiB of poison, then back to the allocator
+        del junk
+        loss = w.train_step(images, labels)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        g = eng.arena.g32
+        bad = [name for name, (o, n, _) in eng.arena.entries.items() if not torch.isfinite(g[o:o + n]).all()]
+        print('poison', val, 'loss', float(loss), 'non-finite grads in', len(bad), 'entries:', bad[:12], flush=True)
+        ref = g.clone()
+        for p in w.model.parameters():
+            p.grad = None
+        if val != val:
+            continue
+        torch.cuda.empty_cache()
+        junk = [torch.zeros((1 << 26,), device=dev) for _ in range(4)]
+        del junk
+        w.train_step(images, labels)[0].backward()
+        torch.cuda.synchronize()
+        worst = sorted(((float((g[o:o + n] - ref[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:6]
+        print('1e4-poisoned vs zero-poisoned:', worst, flush=True)
+        for p in w.model.parameters():
+            p.grad = None
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'poison':
+    poison()
