@@ -113,6 +113,14 @@ def poison():
         torch.cuda.synchronize()
         worst = sorted(((float((g[o:o + n] - ref[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:6]
         print('1e4-poisoned vs zero-poisoned:', worst, flush=True)
+        for name, (o, n, _) in eng.arena.entries.items():
+            x, y = g[o:o + n].double(), ref[o:o + n].double()
+            if float(y.abs().max()) == 0:
+                continue
+            ratio = float((x * y).sum() / (y * y).sum())
+            resid = float((x - ratio * y).norm() / y.norm())
+            if abs(ratio - 1) > 1e-5 or resid > 1e-5:
+                print(f'   {name:60s} scale {ratio - 1:+.3e}  residual after scaling {resid:.2e}', flush=True)
         for p in w.model.parameters():
             p.grad = None
 
