@@ -50,6 +50,16 @@ def main():
         torch.cuda.synchronize()
         return eng.arena.g32.clone()
 
+    def scales(x, y):
+        for name, (o, n, _) in eng.arena.entries.items():
+            u, v = x[o:o + n].double(), y[o:o + n].double()
+            if float(v.abs().max()) == 0:
+                continue
+            ratio = float((u * v).sum() / (v * v).sum())
+            resid = float((u - ratio * v).norm() / v.norm())
+            if abs(ratio - 1) > 1e-5 or resid > 1e-5:
+                print(f'   {name:58s} scale {ratio - 1:+.3e}  residual after scaling {resid:.2e}', flush=True)
+
     def cmp(tag, x, y):
         worst = sorted(((float((x[o:o + n] - y[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:3]
         print(tag, 'rel', float((x - y).abs().max()) / float(y.abs().max()), worst, flush=True)
@@ -59,6 +69,7 @@ def main():
     a2 = accum(reserve_second=True)
     a3 = accum()
     cmp('plain vs plain      ', a1, a0)
+    scales(a1, a0)
     cmp('reserved vs plain   ', a2, a0)
     cmp('plain again vs plain', a3, a0)
     b0, b1 = accum(whole=True), accum(whole=True)
