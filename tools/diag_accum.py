@@ -1,5 +1,14 @@
 #!/usr/bin/env python3
-"""diagnostic: gradient accumulation over two micro-batches, repeated under different conditions (tiny model, VALU conv path)"""
+"""Diagnostic: how far two backward passes of the SAME data differ, and where the difference enters (tiny model).
+
+    python tools/diag_accum.py [plain | gpt2_lora | poison]
+
+Finding (round 2): passes usually agree to 1e-7 (fp32 atomics order in the gradient normaliser's sums and the dW slices), but now and
+then one differs by 3e-4 .. 1e-3 in the gradients at the bottom of a tower (convolutions, embeddings).  The per-entry analysis shows the
+perturbation entering where the normalised gradient is re-quantised to bf16 and growing by sqrt(eps x 2^-8) at every further bf16 stage
+(1e-7 -> 1e-5 -> 2e-4 -> 1e-3); poisoning the allocator's free blocks with NaN / 1e4 changes nothing, i.e. no kernel reads memory it
+did not write.  bf16 intermediates make the backward pass chaotic at the 1e-3 level; nothing to fix, but bit-level or 1e-5-level
+reproducibility checks between passes must not be asserted."""
 import os, sys, tempfile
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

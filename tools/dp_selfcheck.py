@@ -21,6 +21,15 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+# Two backward passes of the SAME step are not bit-identical: the gradient normaliser's sum and the dW slices are reduced with fp32
+# atomics (order-dependent in the last bit), and every bf16 re-quantisation of the gradient stream turns a relative perturbation eps
+# into rounding noise of about sqrt(eps x 2^-8) -- 1e-7 -> 2e-5 -> 3e-4 -> 1e-3 over three stages, saturating at bf16 precision
+# (tools/diag_accum.py shows the growth entry by entry on the tiny model).  Two identical steps often DO agree to 1e-7 (same launch
+# order), so a measured floor can be far below what a third pass shows; the bound below is therefore bf16-level.  The defects this
+# check exists for are O(1): a slice reduced twice or not at all, a mean applied twice, a micro-batch lost.
+TOL = 5e-3
+
+
 def main():
     from image2text_amd.training.dp import RCCL_CUS, DataParallelGrads, configure_rccl_env
     configure_rccl_env()
@@ -104,7 +113,7 @@ def main():
     got = grads()
     zero()
     err = float((got - ref[0]).abs().max()) / scale
-    assert err <= max(4 * floor, 1e-5), f'hooked vs un-hooked gradients: {err:.3e} (noise floor {floor:.3e})'
+    assert err <= max(4 * floor, TOL), f'hooked vs un-hooked gradients: {err:.3e} (noise floor {floor:.3e})'
 
     # accumulation window: micro-batch 1 under no_sync, micro-batch 2 exchanges; equals the un-hooked accumulation
     with dp1.no_sync():
@@ -119,10 +128,10 @@ def main():
     wrapper.train_step(images[8:], labels[8:])[0].backward()
     acc0 = grads()
     err2 = float((acc1 - acc0).abs().max()) / float(acc0.abs().max())
-    if err2 > max(4 * floor, 1e-5):            # name the arena entries that differ (diagnostic for the assertion below)
+    if err2 > max(4 * floor, TOL):            # name the arena entries that differ (diagnostic for the assertion below)
         worst = sorted(((float((acc1[o:o + n] - acc0[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:6]
         print('DP_SELFCHECK accumulation mismatch, worst entries:', worst, 'max |g| =', float(acc0.abs().max()), flush=True)
-    assert err2 <= max(4 * floor, 1e-5), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
+    assert err2 <= max(4 * floor, TOL), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
     torch.cuda.synchronize()
     print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
     dist.destroy_process_group()
