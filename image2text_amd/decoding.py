@@ -340,15 +340,7 @@ class GreedyDecoder:
                 enc_out[i:i + ENC_CHUNK].copy_(part)
                 del part
         S = enc_out.shape[1]
-        if getattr(dc, 'lora', None) is not None:              # merged adapter weights follow the current parameters
-            for l in range(dc.L):
-                p = f'{eng.dp}transformer.h.{l}'
-                for site, name, rows in (('attn_c_attn', f'{p}.attn.c_attn.weight', None), ('mlp_c_fc', f'{p}.mlp.c_fc.weight', None),
-                                         ('mlp_c_proj', f'{p}.mlp.c_proj.weight', None),
-                                         ('xattn_c_attn', f'{p}.cross_attn.in_proj_weight', slice(dc.d, 3 * dc.d))):
-                    if site != 'xattn_c_attn' or l in st.cross_kv:
-                        self._w(l, site, name, rows)
-            eng.refresh_lora_merged()
+        eng.prepare_lora_merged()                               # merged adapter weights follow the current parameters
         if st.cross_kv:
             assert S == next(iter(st.cross_kv.values()))[1]
             mem = eng._mem_bf16(enc_out)
@@ -480,6 +472,7 @@ class ConcurrentGreedyDecoder:
         # lanes' own prepare() calls then find nothing to do.  Per-lane state (KV caches, graphs, the encoder's conv weight
         # workspace -- keyed by stream in the engine) is private.
         self.model._engine.prepare(False)
+        self.model._engine.prepare_lora_merged()
         outs = []
         for (dec, stream), images, prompt in zip(self.lanes, image_batches, prompt_batches):
             stream.wait_stream(cur)

@@ -194,6 +194,7 @@ class ParamArena:
                 view.copy_(p.data.to(device=device, dtype=F32))
                 p.data = view
         self._versions = None
+        self.generation = 0             # bumped whenever parameter VALUES change (torch-side writes seen by refresh_shadow, fused optimizer steps)
         self.grads_attached = False
 
     def valid(self) -> bool:
@@ -209,6 +210,7 @@ class ParamArena:
         if v != self._versions:
             ops.cast_f32_bf16(self.p32, self.pbf, self.total)
             self._versions = v
+            self.generation += 1
 
     def P(self, name: str) -> Optional[torch.Tensor]:
         e = self.entries.get(name)

@@ -84,7 +84,7 @@ class LoraAdapters:
     # ------------------------------------------------------------------------------------------------ generation: merged weights
     def lora_merged(self, l: int, site: str, W_name: str, rows=None):
         """bf16 W + s B A of one adapted linear in a persistent buffer (same address on every call: captured decode graphs read it);
-        ``refresh_lora_merged`` recomputes the contents from the current parameters."""
+        ``prepare_lora_merged`` recomputes the contents from the current parameters."""
         key = ('lora_merged', l, site, id(self.arena))
         buf = self._sub_cache.get(key)
         if buf is None:
@@ -93,8 +93,25 @@ class LoraAdapters:
             self._lora_merge_list.append((buf, l, site, W_name, rows))
         return buf
 
-    def refresh_lora_merged(self):
-        a = self.arena
+    def prepare_lora_merged(self):
+        """Create every adapted linear's merged-weight buffer and bring the contents up to date with the parameters (skipped when
+        nothing changed since the last call).  Called before a decode -- by ConcurrentGreedyDecoder on the parent stream, before it
+        fans out: the buffers are shared by its lanes."""
+        lo = getattr(self.dec, 'lora', None)
+        if lo is None:
+            return
+        a, d = self.arena, self.dec.d
+        for l in range(self.dec.L):
+            p = f'{self.dp}transformer.h.{l}'
+            for site, name, rows in (('attn_c_attn', f'{p}.attn.c_attn.weight', None), ('mlp_c_fc', f'{p}.mlp.c_fc.weight', None),
+                                     ('mlp_c_proj', f'{p}.mlp.c_proj.weight', None),
+                                     ('xattn_c_attn', f'{p}.cross_attn.in_proj_weight', slice(d, 3 * d))):
+                if site in lo.sites and name in a.entries:
+                    self.lora_merged(l, site, name, rows)
+        ver = (id(a), len(self._lora_merge_list), a.generation)       # (prepare() has run refresh_shadow: torch-side writes are counted)
+        if ver == getattr(self, '_lora_merged_ver', None):
+            return
+        self._lora_merged_ver = ver
         for buf, l, site, W_name, rows in self._lora_merge_list:
             ls = self._lora_site(l, site)
             W = a.P(W_name)

@@ -91,6 +91,7 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         type(self)._kernel(arena.p32, arena.g32, self._m, self._v, arena.pbf, arena.total, ends, lrs, wds, nseg,
                            g0['betas'][0], g0['betas'][1], g0['eps'], self._step, self.grad_scale)
+        arena.generation += 1           # values changed behind torch's version counters (e.g. merged LoRA weights must be rebuilt)
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

@@ -294,6 +294,7 @@ class ModelTrainerWrapper(nn.Module):
             raise RuntimeError('momentum update before both models ran on the GPU, or their parameter layouts differ')
         am.refresh_shadow()                                   # (a torch-side edit of model_m since the last cast is honoured first)
         ops.ema_update(am.p32, a.p32, am.pbf, a.total, self.momentum)
+        am.generation += 1
 
     def forward(self, images, input_ids, attn_msk=None) -> Tuple[torch.Tensor, torch.Tensor]:
         out = self.model(images=images, ids=input_ids, attn_msk=attn_msk)
