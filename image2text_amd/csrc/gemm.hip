@@ -1573,10 +1573,12 @@ bool launch_g256_dw(hipStream_t s, GemmParams p) {
     const int n_cu = g256_cus();
     p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
     const int tiles = p.tiles_m * p.tiles_n, nk_all = (p.K + 63) >> 6;
-    if (tiles >= n_cu) {
+    if (tiles >= n_cu || n_cu / tiles < 2) {
+        // (more than half a round of tiles but less than one -- a Qwen2-1.5B down_proj dW, 1536 x 8960 = 210 tiles -- cannot be split:
+        // one tile per workgroup on the persistent kernel still beats the 128^2 fallback it used to take, 711 TF)
         if (g256_epilogue_class(p) != 5) return false;
         p.g2_splits = 1; p.g2_nk = (nk_all + 1) & ~1;
-        hipLaunchKernelGGL((gemm256_kernel<true, true, 5>), dim3(n_cu), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((gemm256_kernel<true, true, 5>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, p);
         return true;
     }
     int splits = n_cu / tiles;

@@ -489,6 +489,18 @@ def test_grad_normalize(ops):
 
 
 # ------------------------------------------------------------------------------------------------------ conv stack
+def test_dw_gemm_between_half_and_one_round_of_tiles(ops):
+    """dW = dY^T X with 129 .. 255 output tiles of 256^2 (a Qwen2-1.5B down_proj: 1536 x 8960 = 210 tiles): too many to split K,
+    too few for a full round -- one tile per workgroup of the persistent kernel (it used to fall back to the 128^2 kernel)"""
+    M, N, K = 4096 + 40, 1536, 8960                      # rows (the reduction), output rows, output columns
+    dy = rnd(M, N, seed=301, dtype=BF16)
+    x = rnd(M, K, seed=302, dtype=BF16)
+    g = torch.full((N, K), 0.25, device=dev())
+    ops.gemm(dy, x, g, N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+    ref = 0.25 + dy.double().t() @ x.double()
+    check('dW 210 tiles', g, ref, 2e-2, 2e-3)
+
+
 @pytest.mark.parametrize('M,N,K,kind', [(256, 1536, 8960, 'res'), (200, 768, 3072, 'gelu'), (1000, 130, 1024, 'bias_f32'), (96, 2304, 768, 'bias'),
                                         (2048, 768, 3072, 'res'), (64, 768, 3072, 'res'), (300, 50264, 768, 'bias_f32'), (4096, 768, 3072, 'res')])
 def test_gemm_deterministic_splitk(ops, M, N, K, kind):
