@@ -54,12 +54,12 @@ class _ArenaOptimizer(torch.optim.Optimizer):
                 if arena_of(p) is not arena:
                     raise RuntimeError(f'{type(self).__name__}: a parameter of shape {tuple(p.shape)} lives outside the arena')
                 # (a frozen parameter -- LoRA's base weights -- keeps its value whatever group it was handed over in)
-                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p) if p.requires_grad else (0.0, 0.0, p)
+                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p) if p.requires_grad else (-1.0, 0.0, p)      # lr < 0: skipped by the kernels
         ends, lrs, wds, self._params = [], [], [], []
         items = sorted(arena.entries.items(), key=lambda kv: kv[1][0])
         for i, (name, (off, n, _)) in enumerate(items):
             end = items[i + 1][1][0] if i + 1 < len(items) else arena.total
-            lr, wd, p = by_ptr.get(arena.p32.data_ptr() + 4 * off, (0.0, 0.0, None))      # params outside every group stay frozen
+            lr, wd, p = by_ptr.get(arena.p32.data_ptr() + 4 * off, (-1.0, 0.0, None))     # params outside every group stay frozen (lr < 0: skipped)
             ends.append(end); lrs.append(lr); wds.append(wd)
             if p is not None:
                 self._params.append((name, p))

@@ -255,7 +255,8 @@ int i2t_nchw_to_nhwc_bf16(void* stream, const void* src, void* dst, int B, int C
  *   cast:  dst bf16[n] = src f32[n]                     (bf16 weight shadows after an optimizer step)
  *   adamw: torch.optim.AdamW semantics (decoupled decay, bias correction from `step`), one launch over a flat
  *          f32 arena; also refreshes the bf16 shadow of every parameter.  lr/wd are per-element-range tables:
- *          seg_end[i] = exclusive end of segment i, seg_lr[i], seg_wd[i] (nseg small; device arrays).
+ *          seg_end[i] = exclusive end of segment i, seg_lr[i], seg_wd[i] (nseg small; device arrays).  A segment with
+ *          seg_lr < 0 is FROZEN (requires_grad off, or in no parameter group): skipped entirely -- no state, no update, no traffic.
  *   add_rows / cls concat helpers for the encoder token buffer.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n);
@@ -268,7 +269,7 @@ int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, v
                    const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                    float beta1, float beta2, float eps, int step, float grad_scale);
 /* SNRAdam (reference models/optimizer.py:56-113; trainer.py:169 `use_snr_optim`): Adam with the gradient's running VARIANCE
- * in the denominator.  Same contract as i2t_adamw_step; segments with lr == 0 and wd == 0 are left untouched (no state). */
+ * in the denominator.  Same contract as i2t_adamw_step (frozen segments: lr < 0); segments with lr == 0 and wd == 0 are left untouched too (no state). */
 int i2t_snradam_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                      const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                      float beta1, float beta2, float eps, int step, float grad_scale);
