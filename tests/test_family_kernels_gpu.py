@@ -46,7 +46,9 @@ def ref_gq_attention(q, k, v, H, Hkv, hd, causal, mask=None, sc=1.0):
     (2, 4, 2, 32, 37, 37, True, True),
     (1, 2, 1, 64, 200, 200, True, False),
     (2, 2, 1, 128, 1, 50, True, False),           # a decode-shaped call
-    (2, 3, 3, 16, 33, 131, False, True)])
+    (2, 3, 3, 16, 33, 131, False, True),
+    (2, 12, 2, 128, 300, 300, True, False),       # Qwen2-1.5B heads: 12 query heads of 128 on 2 K/V heads (engine_llama.py)
+    (1, 8, 4, 64, 257, 257, True, False)])        # grouped 64-wide heads, a ragged last tile
 def test_gq_attention_fwd_bwd(ops, B, H, Hkv, hd, Tq, Tk, causal, drop):
     from image2text_amd import rng
     dq_, dk_ = H * hd, Hkv * hd
