@@ -345,6 +345,26 @@ def test_llama_family_decoder_forward_gradients_generate(tmp_path, monkeypatch, 
         assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
 
 
+@pytest.mark.parametrize('kind', ['llama', 'qwen'])
+def test_llama_family_long_sequence_forward(tmp_path, monkeypatch, kind):
+    """8 prompt rows + 110 text rows (the checkpoints' 128 positions): several key tiles per head in the grouped attention kernels, rotary
+    angles far from zero -- logits and hidden state of forward() against the transformers module"""
+    from oracle import reference_model as orc
+    cfg, m, hf, V = _llama_model(tmp_path, monkeypatch, kind)
+    esd = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    m = m.to(dev()).eval()
+    images, labels = synthetic_batch(2, 32, 110, V, seed=29, min_len=100)
+    ids = labels.clamp(min=0)
+    with torch.no_grad():
+        out = m(images=images.to(dev()), ids=ids.to(dev()))
+        _, ologits, ohid = _llama_reference(orc, esd, hf, cfg, images, ids)
+    for name, got, ref, tol in (('logits', out.logits, ologits, 1e-2), ('hidden', out.hidden_state, ohid, 1.5e-2)):
+        err, scale = float((got.float().cpu() - ref).abs().max()), max(1.0, float(ref.abs().max()))
+        REPORT[f'hf_{kind}.long.{name}'] = {'max_abs_err': err, 'tol': tol * scale}
+        assert err <= tol * scale, (name, err, tol * scale)
+    assert (out.logits.argmax(-1).cpu() == ologits.argmax(-1)).float().mean() > 0.9
+
+
 def test_llama_decoder_frozen_by_prepare_for_kbit_training(tmp_path, monkeypatch):
     """prepare_for_kbit_training: True without 4-bit loading (reference local/llama2-7b.yaml; peft freezes the base model): no decoder
     parameter receives a gradient, the weight-gradient GEMMs are skipped, and the encoder's gradients -- through the soft prompt rows of
