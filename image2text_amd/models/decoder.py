@@ -240,6 +240,8 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
             _freeze_like_prepare_for_kbit_training(self)
         if config.lora_spec is not None:
             self._apply_lora(config.lora_spec)
+        from .utils import register_decoder_name_aliases
+        register_decoder_name_aliases(self.reference_parameter_names())        # fnmatch patterns over the reference's parameter names
 
     # -- LoRA (reference models/utils.py:46-65 -> peft LoraModel over the transformers module) -----------------------------------
     _LORA_SITES = {'attn.c_attn': 'attn_c_attn', 'crossattention.c_attn': 'xattn_c_attn', 'mlp.c_fc': 'mlp_c_fc', 'mlp.c_proj': 'mlp_c_proj'}
@@ -292,6 +294,22 @@ class GPT2HuggingfaceDecoder(TransformerDecoder):
         if pats is not None and len(pats) == 0:          # PatternMatcher: an empty list matches everything (models/utils.py:22-23)
             for p in self.parameters():
                 p.requires_grad = True
+
+    def reference_parameter_names(self):
+        """{name under ``named_parameters()`` here: [the reference's name(s) for the same numbers]}.  State-dict keys already ARE the
+        reference's (hooks below); parameter NAMES cannot be (nn.Module walks its own attribute tree), so fnmatch patterns written
+        against the reference's names -- optimizer ``target_modules``, the checkpoint matchers of training/utils.py -- are translated
+        through this table (``training/utils.py::parameter_name_matches``)."""
+        out = {}
+        for name, _ in self.named_parameters():
+            if name.startswith('lora_params.'):
+                l, rest = name[len('lora_params.h'):].split('_', 1)
+                site, ab = rest.rsplit('_', 1)
+                hf_mod = {v: k for k, v in self._LORA_SITES.items()}[site]
+                out[name] = [f'backbone.model.transformer.h.{l}.{hf_mod}.lora_{ab}.default.weight']
+            else:
+                out[name] = ['backbone.' + self._decorate(k) for k, _, _ in self._hf_entries(name)]
+        return out
 
     def _peft_names(self, internal: str):
         """the LoraModel parameter name(s) of one parameter of this module: ``model.<transformers name>``, ``base_layer`` inside adapted

@@ -145,7 +145,10 @@ def save_checkpoint(model: nn.Module, chckpt_fname: str, accelerator, matchers: 
     large model stores just what was trained; reference :111-123).  Loadable by ``update_state_dict_from_partial_checkpoint``."""
     sd = model.state_dict()
     if len(matchers) > 0:
-        sd = {k: sd[k] for k, _ in model.named_parameters() if any(m.match(k) for m in matchers)}
+        # (a parameter's state-dict key(s) are its reference name(s): the same string except under a GPT2HuggingfaceDecoder)
+        from ..models.utils import state_dict_keys_of_parameters
+        keys = state_dict_keys_of_parameters(model)
+        sd = {r: sd[r] for k, _ in model.named_parameters() if any(m.match(k) for m in matchers) for r in keys[k]}
     with _open(chckpt_fname, mode='wb') as fh:
         accelerator.save(sd, fh)
 

@@ -388,6 +388,40 @@ def test_gpt2_huggingface_decoder_lora(tmp_path, monkeypatch):
     plain = Decoder.from_config(_hf_decoder_config(use_cross_attn=True)).state_dict()
     missing, unexpected = d2.load_state_dict(plain, strict=False)
     assert not unexpected and all('lora_params' in k for k in missing)
+    # fnmatch patterns written against the reference's parameter names select the hot path's parameters (optimizer target_modules,
+    # checkpoint matchers): the plugin registers the translation, PatternMatcher tries both names
+    from image2text_amd.models.utils import PatternMatcher, reference_names
+    names = ['model.decoder.' + n for n, _ in d.named_parameters()]
+    pick = lambda pats: [n for n in names if PatternMatcher(pats).match(n)]
+    assert pick(['*.crossattention.*']) == [n for n in names if '.cross_attn.' in n or 'xattn_c_attn' in n]
+    assert pick(['*decoder*lora*']) == [n for n in names if 'lora_params' in n] and len(pick(['*lora_A*'])) == 8
+    assert pick(['*.ln_cross_attn.*']) == [n for n in names if '.ln_3.' in n] and pick(['*.attn.c_attn.base_layer.weight']) == [
+        'model.decoder.transformer.h.0.attn.c_attn.weight', 'model.decoder.transformer.h.1.attn.c_attn.weight']
+    assert {'model.decoder.backbone.model.transformer.h.0.crossattention.q_attn.weight',
+            'model.decoder.backbone.model.transformer.h.0.crossattention.c_attn.base_layer.weight'} <= set(
+        reference_names('model.decoder.transformer.h.0.cross_attn.in_proj_weight'))
+    from image2text_amd.models.utils import state_dict_keys_of_parameters
+    holder = torch.nn.Module()
+    holder.decoder = d
+    keys = state_dict_keys_of_parameters(holder)
+    assert sorted(r for refs in keys.values() for r in refs) == sorted(k for k in holder.state_dict() if k != 'decoder.backbone.model.lm_head.weight')
+    # partial checkpoint of what the patterns select (training/utils.py::save_checkpoint): stored under the reference's keys, loadable
+    from types import SimpleNamespace
+    from image2text_amd.training.utils import save_checkpoint
+    from image2text_amd.models.utils import update_state_dict_from_partial_checkpoint
+    ck = str(tmp_path / 'partial.pt')
+    save_checkpoint(holder, ck, SimpleNamespace(save=torch.save), matchers=[PatternMatcher(['*lora_B*', '*.crossattention.q_attn.*'])])
+    part = torch.load(ck, weights_only=True)
+    assert sorted(part) == sorted(k for k in holder.state_dict() if 'lora_B' in k or '.crossattention.' in k and '.lora_' not in k and '.c_proj.' not in k)
+    holder2 = torch.nn.Module()
+    holder2.decoder = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec()))
+    with torch.no_grad():
+        for n_, p_ in d.named_parameters():
+            if 'lora_params' in n_ and n_.endswith('_B'):
+                p_.fill_(0.5)
+        save_checkpoint(holder, ck, SimpleNamespace(save=torch.save), matchers=[PatternMatcher(['*lora_B*'])])
+    update_state_dict_from_partial_checkpoint(holder2, ck)
+    assert all(float(p_.min()) == 0.5 for n_, p_ in holder2.decoder.named_parameters() if 'lora_params' in n_ and n_.endswith('_B'))
     # no force-enable list: adapters only
     d3 = Decoder.from_config(_hf_decoder_config(use_cross_attn=True, lora_spec=_lora_spec(force_enable_update_modules=None, target_modules=None)))
     assert d3.lora.sites == ('attn_c_attn', 'xattn_c_attn')                  # peft's default target for gpt2: c_attn
