@@ -112,73 +112,6 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
     }
 }
 
-// The same backward for d <= 64 * 4 * RMS_MAXC = 2048 (Qwen2-1.5B: 1536): the row's x and dy stay in registers between the reduction and
-// the output pass, so every operand is read from memory once (the two-pass form above re-reads both, mostly from L2).
-template <bool DY_F32>
-__global__ __launch_bounds__(256) void rms_bwd_small_kernel(const void* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ w, const float* __restrict__ rstd,
-                                                            float* __restrict__ dx, int dx_accumulate, bf16_t* __restrict__ dx_bf16,
-                                                            float* __restrict__ dw, int M, int d) {
-    __shared__ float red[4][RMS_MAXC * 256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nc = d >> 2;
-    const int row0 = blockIdx.x * RMS_BWD_ROWS, row_end = min(M, row0 + RMS_BWD_ROWS);
-    f32x4 pg[RMS_MAXC], g[RMS_MAXC];
-#pragma unroll
-    for (int j = 0; j < RMS_MAXC; ++j) {
-        pg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g[j] = (lane + 64 * j < nc) ? reinterpret_cast<const f32x4*>(w)[lane + 64 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int row = row0 + wv; row < row_end; row += 4) {
-        const float rs = rstd[row];
-        f32x4 xh[RMS_MAXC], dyv[RMS_MAXC];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < RMS_MAXC; ++j) {
-            const int c = lane + 64 * j;
-            xh[j] = dyv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < nc) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
-                if (DY_F32) {
-                    dyv[j] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + (size_t)row * d)[c];
-                } else {
-                    const u32x2 pk = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * d)[c];
-                    dyv[j] = f32x4{bf16lo(pk[0]), bf16hi(pk[0]), bf16lo(pk[1]), bf16hi(pk[1])};
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[j][e] = v[e] * rs;
-                    s += dyv[j][e] * g[j][e] * xh[j][e];
-                }
-            }
-        }
-        const float c2 = wave_sum(s) / d;
-#pragma unroll
-        for (int j = 0; j < RMS_MAXC; ++j) {
-            const int c = lane + 64 * j;
-            if (c >= nc) continue;
-            f32x4* dxp = reinterpret_cast<f32x4*>(dx + (size_t)row * d) + c;
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = rs * (dyv[j][e] * g[j][e] - xh[j][e] * c2);
-                pg[j][e] += dyv[j][e] * xh[j][e];
-            }
-            if (dx_accumulate) o += *dxp;
-            *dxp = o;
-            if (dx_bf16) reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * d)[c] = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-        }
-    }
-    if (!dw) return;
-#pragma unroll
-    for (int j = 0; j < RMS_MAXC; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wv][(lane + 64 * j) * 4 + e] = pg[j][e];
-    __syncthreads();
-    for (int t = threadIdx.x; t < RMS_MAXC * 256; t += 256)
-        if (t < d) atomicAdd(dw + t, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
-}
-
 // rotary embedding in place on `nh` heads of width hd starting at column col0 of the bf16 rows x [M][rs]; position of row m:
 // pos[m] (packed rows) | *pos_ptr (decode step) | pos_offset + m % T.  cs = [positions][hd] fp32: cos in [0, hd/2), sin in [hd/2, hd).
 // A thread owns 8 consecutive dims i and their partners i + hd/2.  inverse: rotate by -angle (the backward of the forward).
@@ -268,16 +201,6 @@ extern "C" int i2t_rmsnorm_bwd(void* stream, const void* dy, int dy_is_f32, cons
                                float* dx, int dx_accumulate, void* dx_bf16, float* dw, int M, int d) {
     I2T_REQUIRE(dy && x && w && rstd && dx && M > 0 && d > 0 && d % 4 == 0, "i2t_rmsnorm_bwd: bad args (d=%d must be a multiple of 4)", d);
     const int grid = (M + RMS_BWD_ROWS - 1) / RMS_BWD_ROWS;
-    if (d <= 64 * 4 * RMS_MAXC) {       // the row fits the registers of one wave: every operand read once
-        if (dy_is_f32)
-            hipLaunchKernelGGL(rms_bwd_small_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
-                               (bf16_t*)dx_bf16, dw, M, d);
-        else
-            hipLaunchKernelGGL(rms_bwd_small_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
-                               (bf16_t*)dx_bf16, dw, M, d);
-        I2T_CHECK_LAUNCH("i2t_rmsnorm_bwd");
-        return I2T_OK;
-    }
     if (dy_is_f32)
         hipLaunchKernelGGL(rms_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
                            (bf16_t*)dx_bf16, dw, M, d);
