@@ -425,7 +425,12 @@ def test_llama_row_kernels():
     """i2t_rmsnorm_fwd / _bwd, i2t_rope (forward, inverse, position sources) and i2t_swiglu_fwd / _bwd against torch fp32"""
     from image2text_amd import ops
     g = torch.Generator().manual_seed(0)
-    M, d = 70, 2304                                         # more than one column panel (2048) in the backward, a ragged last row group
+    for M, d in ((70, 2304), (70, 1536), (33, 256)):        # two column panels (> 2048) and one; ragged row groups
+        _rmsnorm_case(ops, g, M, d)
+    _rope_swiglu_cases(ops, g)
+
+
+def _rmsnorm_case(ops, g, M, d):
     x = torch.randn(M, d, generator=g).to(dev())
     w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
     dy = torch.randn(M, d, generator=g).to(dev())
@@ -442,6 +447,9 @@ def test_llama_row_kernels():
         assert float((dx - 0.5 - xr.grad).abs().max()) < tol * max(1.0, float(xr.grad.abs().max()))
         assert float((dw - wr.grad).abs().max()) < tol * float(wr.grad.abs().max()) + 1e-3
         assert float((dxb.float() - dx).abs().max()) < 2e-2 * float(dx.abs().max())
+
+
+def _rope_swiglu_cases(ops, g):
     # rotary embedding
     B, T, H, hd = 2, 9, 3, 64
     rsz = H * hd + 32
