@@ -56,7 +56,8 @@ class LoraAdapters:
         wcat[:, :K].copy_(W)
         wcat[:, K:K + ls.r].copy_(ls.B * ls.scale)
         ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
-        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous()) if save else None
+        # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
+        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd if drop_l is not None else None) if save else None
 
     def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
         """dY bf16 [M, N]: gradient w.r.t. the adapted linear's pre-epilogue output.  gW / gb: gradient views of the base weight /
@@ -71,10 +72,7 @@ class LoraAdapters:
         ls.GB.add_(tmp[:, :ls.r], alpha=ls.scale)
         du = torch.empty(M, LPAD, dtype=BF16, device=dY.device)
         ops.gemm(dY, sv_l.sB, du, M, LPAD, N, b_kmajor=True)
-        xd = x
-        if drop_l is not None:
-            xd = x.clone()
-            ops.dropout_apply(xd, M, K, drop_l)
+        xd = sv_l.xd if sv_l.xd is not None else x
         ops.gemm(du, xd, ls.GA, LPAD, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dx = torch.empty(M, K, dtype=F32, device=dY.device)
         ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)
