@@ -18,6 +18,30 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const float* __restrict_
     }
 }
 
+// One pass over the adapted layer's input x [M][K] (bf16): copy it into the first K columns of the K-concatenated operand
+// xcat [M][ldc] and, when the adapter has input dropout, write the masked copy xd [M][K] next to it (mask index r * K + c: the index
+// space of i2t_dropout_apply and of the residual + dropout GEMM epilogue that applies the same mask in backward).
+__global__ __launch_bounds__(256) void lora_stage_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xcat, int ldc,
+                                                         bf16_t* __restrict__ xd, long n8, int k8, unsigned key, unsigned thr, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long r = i / k8;
+        const int c = (int)(i - r * k8) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+        *reinterpret_cast<u32x4*>(xcat + (size_t)r * ldc + c) = v;
+        if (xd) {
+            bool k0[4], k1[4];
+            dropout_keep4(key, (unsigned)(i * 8), thr, k0);
+            dropout_keep4(key, (unsigned)(i * 8 + 4), thr, k1);
+            u32x4 o;
+            o[0] = pack_bf16x2(k0[0] ? bf16lo(v[0]) * scale : 0.f, k0[1] ? bf16hi(v[0]) * scale : 0.f);
+            o[1] = pack_bf16x2(k0[2] ? bf16lo(v[1]) * scale : 0.f, k0[3] ? bf16hi(v[1]) * scale : 0.f);
+            o[2] = pack_bf16x2(k1[0] ? bf16lo(v[2]) * scale : 0.f, k1[1] ? bf16hi(v[2]) * scale : 0.f);
+            o[3] = pack_bf16x2(k1[2] ? bf16lo(v[3]) * scale : 0.f, k1[3] ? bf16hi(v[3]) * scale : 0.f);
+            *reinterpret_cast<u32x4*>(xd + i * 8) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, void* out, long n) {
@@ -27,5 +51,18 @@ extern "C" int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, voi
     hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, dh,
                        (const bf16_t*)pre, (bf16_t*)out, n4);
     I2T_CHECK_LAUNCH("i2t_dgelu_mul");
+    return I2T_OK;
+}
+
+extern "C" int i2t_lora_stage(void* stream, const void* x, void* xcat, int ldc, void* xd, long M, int K, unsigned drop_key,
+                              unsigned drop_thr, float drop_scale) {
+    I2T_REQUIRE(x && xcat && M > 0 && K > 0 && K % 8 == 0 && ldc % 8 == 0 && ldc >= K && ALIGNED16(x) && ALIGNED16(xcat) &&
+                    (!xd || ALIGNED16(xd)) && M * K < (1L << 32),
+                "i2t_lora_stage: bad args (K=%d and ldc=%d must be multiples of 8, M*K < 2^32)", K, ldc);
+    const long n8 = M * (K / 8);
+    const long blocks = (n8 + 255) / 256;
+    hipLaunchKernelGGL(lora_stage_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)xcat, ldc, (bf16_t*)xd, n8, K / 8, drop_key, drop_thr, drop_scale);
+    I2T_CHECK_LAUNCH("i2t_lora_stage");
     return I2T_OK;
 }

@@ -45,19 +45,16 @@ class LoraAdapters:
         """out = epilogue([x | u] . [W | s B | 0]^T), u = dropout(x) . A^T.  x bf16 [M, K] contiguous, W bf16 [N, K].  Returns what
         the backward needs (u and s B, both [*, LPAD] bf16) when save."""
         K, N = ls.K, ls.N
-        xd = x
-        if drop_l is not None:
-            xd = x.clone()
-            ops.dropout_apply(xd, M, K, drop_l)
         xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
-        xcat[:, :K].copy_(x)
-        ops.gemm(xd, ls.A, xcat[:, K:], M, LPAD, K)
+        xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
+        ops.lora_stage(x, xcat, xd, M, K, drop_l)                    # one pass: x into the concatenated operand + its masked copy
+        ops.gemm(xd if xd is not None else x, ls.A, xcat[:, K:], M, LPAD, K)
         wcat = torch.zeros(N, K + LPAD, dtype=BF16, device=x.device)
         wcat[:, :K].copy_(W)
         wcat[:, K:K + ls.r].copy_(ls.B * ls.scale)
         ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
-        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd if drop_l is not None else None) if save else None
+        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd) if save else None
 
     def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
         """dY bf16 [M, N]: gradient w.r.t. the adapted linear's pre-epilogue output.  gW / gb: gradient views of the base weight /

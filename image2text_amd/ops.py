@@ -367,6 +367,13 @@ def dgelu_mul(dh, pre, out):
     return out
 
 
+def lora_stage(x, xcat, xd, M, K, drop):
+    """xcat[:, :K] = x and (xd not None) xd = dropout(x): include/i2t.h::i2t_lora_stage; drop = (1, key, thr, scale) | None"""
+    _need_cuda(x, xcat)
+    assert x.is_contiguous() and (drop is None) == (xd is None) and (drop is None or int(drop[0]) == 1)
+    _l.check(_lib().i2t_lora_stage(_stream(), _p(x), _p(xcat), xcat.stride(0), _p(xd), M, K, *_drop(drop)[1:]), 'i2t_lora_stage')
+
+
 def sumsq(g: torch.Tensor, ws: torch.Tensor, accumulate=False):
     """ws[0] (+)= sum(g^2)  (include/i2t.h::i2t_sumsq)"""
     _need_cuda(g, ws)
