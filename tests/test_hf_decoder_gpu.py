@@ -608,6 +608,15 @@ def test_gpt2_hf_decoder_lora(tmp_path, monkeypatch, p_lora):
         err, scale_ = float((got.float().cpu() - ref.detach()).abs().max()), max(1.0, float(ref.detach().abs().max()))
         REPORT[f'{tag}.{name}'] = {'max_abs_err': err, 'tol': tol * scale_}
         assert err <= tol * scale_, (name, err, tol * scale_)
+    # the oracle's own restatement of GPT-2 + peft's LoRA layer (oracle/hf_decoders.py) says the same as the wrapped transformers twin
+    from oracle import hf_decoders as hfo
+    with torch.no_grad():
+        psd = {k.replace('.base.', '.'): v for k, v in hf.named_parameters() if not (k.endswith('.A') or k.endswith('.B'))}
+        psd['lm_head.weight'] = psd['transformer.wte.weight']
+        lmap = {f'transformer.h.{l}.{".".join(_LORA_MODS[site])}': (w.A, w.B, w.scale, w.mask) for (l, site), w in wraps.items()}
+        rl, rh = hfo.soft_prompt_forward(lambda e_, m_: hfo.gpt2_decoder(psd, 2, 2, e_, m_, lora=lmap), psd['transformer.wte.weight'],
+                                         enc.detach(), ids, 64, True)
+        assert float((rl - ologits).abs().max()) < 1e-4 and float((rh - ohid).abs().max()) < 1e-4
     ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
     ((ohid * wh).sum() + (ologits * wl).sum()).backward()
     from image2text_amd.models.decoder import Decoder
