@@ -344,6 +344,9 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
         self._logits_cache: Dict[int, torch.Tensor] = {}
         self._ws = None
         self.grad_ready_hooks = []      # callables(which: 'begin' | 'decoder' | 'encoder'), e.g. the data-parallel exchange
+        # mixed into every training forward's dropout seed: a second model stepped at the same cadence (the momentum twin,
+        # reference wrapper.py:68-71,197-198: forward_m draws fresh torch RNG) must not repeat this model's masks
+        self.seed_salt = 0
 
     def _refresh_sparse_sets(self):
         """(Re-)read the sparse layers' position sets when their buffers changed (they are part of the state dict: a checkpoint
@@ -401,14 +404,15 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
                 self._seed_base = base
                 self._seed_state = (base ^ (0x9E3779B97F4A7C15 * _dp_rank())) & (2 ** 64 - 1)      # rank 0: torch's seed itself
             self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+            step_seed = self._seed_state ^ self.seed_salt
             if self.enc.dropout > 0 or self.enc.attn_dropout > 0:
-                self.enc_drop = DropPlan(self._seed_state, 0, self.enc.dropout, self.enc.attn_dropout,
+                self.enc_drop = DropPlan(step_seed, 0, self.enc.dropout, self.enc.attn_dropout,
                                          compact_layer=self.enc.L - 1 if self.cls_only_last else -1, live_rows=self.enc.ncls)
             p_lora = self.dec.lora.p if getattr(self.dec, 'lora', None) is not None else 0.0
             if self.dec.dropout > 0 or self.dec.attn_dropout > 0 or p_lora > 0:
                 hf_sites = hasattr(self.model.decoder, 'hot_config')          # transformers' GPT-2: resid_dropout after crossattention.c_proj
-                self.dec_drop = DropPlan(self._seed_state, 1, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
-                self.dec_drop_prompt = DropPlan(self._seed_state, 2, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
+                self.dec_drop = DropPlan(step_seed, 1, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
+                self.dec_drop_prompt = DropPlan(step_seed, 2, self.dec.dropout, self.dec.attn_dropout, xresid=hf_sites, p_lora=p_lora)
         return self.arena
 
     @property

@@ -242,6 +242,8 @@ class ModelTrainerWrapper(nn.Module):
                                       'text rows, which the two-segment backward does not cover')
         self.is_momentum = tc.moco_momentum is not None and tc.moco_alpha is not None
         self.model_m = VisionEncoderDecoder(config=model_config) if self.is_momentum else None
+        if self.model_m is not None:        # the teacher's dropout masks are independent of the student's (reference wrapper.py:68-71)
+            self.model_m._engine.seed_salt = 0xA5A5F00DC0FFEE11
         self.tokenizer = tokenizer
         self.ignore_index = ignore_index
         self.temperature = tc.training_temperature

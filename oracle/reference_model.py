@@ -573,6 +573,61 @@ def inverse_cdf_token(dist, u):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# BeamSearchTokenGenerator (models/generation_utils.py:10-148)
+# --------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def beam_search(sd: SD, cfg, images, prompt_ids, beam_width=3, temperature=1.0, top_k=None, max_new_tokens=64, no_repeat_n_grams=(2, 3, 4),
+                beam_expansion_factor=4, eos_token_id=None, consolidation_temperature=1.0, length_boost=1.0, draw=None):
+    """-> (ids (B, W, L), cumulative log scores (B, W)).  ``draw(probs, n)`` stands in for torch.multinomial (the tests replay the
+    draws the reference recorded).  Rows are kept beam-major (W, B) as the reference keeps them (:38-42), so that replayed draws
+    line up call by call: per step one draw of E candidates per (beam, caption) row (:72) and one of W survivors per caption (:143).
+
+    Step (:56-93): last-position logits -> n-gram ban -> top-k crop (strictly below the k-th value) -> candidates: temperature <= 0
+    the E largest raw scores with log_softmax(scores), else E draws without replacement from softmax(scores / temperature);
+    a beam whose LAST token is EOS re-emits EOS at log-score 0 for every candidate whose boosted log-score is negative, all
+    other candidates get + log(length_boost).  Consolidation (:95-148): of the W x E candidates of a caption (beam-major) keep W --
+    the top-W cumulative scores, sorted (consolidation temperature <= 0), or W draws from softmax(cumulative / temperature).
+    Loop test (:46-47): stop at max_new_tokens + provided - 1 ... tokens or when EVERY beam contains EOS anywhere (prompt included)."""
+    draw = draw or torch.multinomial
+    W, E, lb = beam_width, beam_expansion_factor, math.log(length_boost)
+    B = images.shape[0]
+    enc = encode(sd, cfg, images)                                            # (B, n_cls, d)
+    mem = enc.repeat(W, 1, 1)                                                # beam-major rows w * B + b
+    provided = prompt_ids.size(-1) - 1
+    beams = prompt_ids.unsqueeze(0).expand(W, -1, -1)                        # (W, B, L)
+    cum = torch.zeros(W, B)
+    while not (beams.size(-1) >= max_new_tokens + provided or bool(((beams == eos_token_id).sum(dim=-1) > 0).all())):
+        flat = beams.reshape(W * B, -1)
+        ended = (flat[:, -1:] == eos_token_id)
+        _, logits, _ = forward(sd, cfg, None, flat, None, encoder_output=mem)
+        scores = apply_ngram_ban(flat, logits[:, -1, :].clone(), no_repeat_n_grams)
+        if top_k is not None:
+            kth = torch.topk(scores, min(top_k, scores.size(-1)), dim=-1).values[:, -1:]
+            scores[scores < kth] = NEG_INF
+        if temperature <= 0:
+            logp = scores.log_softmax(dim=-1)
+            nxt = scores.topk(k=E, dim=-1).indices
+        else:
+            logp = (scores / temperature).log_softmax(dim=-1)
+            nxt = draw(logp.exp(), E)
+        lp = logp.gather(-1, nxt)
+        stay = ended & (lp + lb < 0)
+        nxt = torch.where(stay, torch.full_like(nxt, eos_token_id), nxt)
+        lp = torch.where(stay, torch.zeros_like(lp), lp + lb)
+        nxt, lp = nxt.view(W, B, E), lp.view(W, B, E)
+        total = (cum.unsqueeze(2) + lp).permute(1, 0, 2).reshape(B, W * E)   # candidate w * E + e of caption b
+        if consolidation_temperature <= 0:
+            pick = total.topk(k=W, dim=-1).indices
+        else:
+            pick = draw((total / consolidation_temperature).softmax(dim=-1), W)
+        bw, ce = pick // E, pick % E                                         # (B, W): surviving beam / its candidate
+        ar = torch.arange(B).unsqueeze(1)
+        beams = torch.cat((beams.permute(1, 0, 2)[ar, bw], nxt.permute(1, 0, 2)[ar, bw, ce].unsqueeze(-1)), dim=-1).permute(1, 0, 2)
+        cum = (cum.t()[ar, bw] + lp.permute(1, 0, 2)[ar, bw, ce]).t()
+    return beams.permute(1, 0, 2), cum.t()
+
+
+# --------------------------------------------------------------------------------------------------------------
 # SNRAdam (models/optimizer.py:56-113)
 # --------------------------------------------------------------------------------------------------------------
 def snradam_step(param, grad, state, lr, betas, weight_decay, eps):

@@ -270,3 +270,42 @@ def test_contrastive_loss_and_every_gradient(tag, kw):
         _, _, vc = orc.lm_step({k: v.detach() for k, v in sd.items()}, cfg, images, labels, tok, training=False, contrastive_temperature=0.7,
                                return_parts=True)
     assert abs(vc.item() - float(g[f'{tag}.val_loss_contrastive'])) <= 2e-5
+
+
+BEAM_RUNS = {     # tools/gen_goldens_r3.py::gen_beam (the reference's BeamSearchTokenGenerator arguments of each recorded run)
+    'det': dict(beam_width=3, temperature=0.0, top_k=None, max_new_tokens=12, no_repeat_n_grams=(2, 3, 4), beam_expansion_factor=4,
+                eos_token_id='rare', consolidation_temperature=0.0, length_boost=1.0),
+    'det_eos': dict(beam_width=3, temperature=0.0, top_k=5, max_new_tokens=14, no_repeat_n_grams=(2, 3), beam_expansion_factor=4,
+                    eos_token_id='eos', consolidation_temperature=0.0, length_boost=1.5),
+    'smp': dict(beam_width=3, temperature=2.5, top_k=None, max_new_tokens=10, no_repeat_n_grams=(2, 3, 4), beam_expansion_factor=4,
+                eos_token_id='rare', consolidation_temperature=6.0, length_boost=1.0),
+    'smp_eos': dict(beam_width=4, temperature=1.0, top_k=None, max_new_tokens=14, no_repeat_n_grams=(2, 3), beam_expansion_factor=3,
+                    eos_token_id='eos', consolidation_temperature=1.0, length_boost=2.0),
+}
+
+
+def beam_replay(gold, tag):
+    """-> draw(probs, n): hands back the reference's recorded torch.multinomial results call by call (rows in ITS order)."""
+    state = {'i': 0}
+
+    def draw(probs, n, *a, **k):
+        r = torch.from_numpy(gold[f'{tag}.draw.{state["i"]}']).to(probs.device)
+        state['i'] += 1
+        assert r.shape == (probs.shape[0], n), (r.shape, probs.shape, n)
+        assert bool((probs.gather(1, r) > 0).all()), 'a replayed draw has zero probability here'
+        return r
+    draw.state = state
+    return draw
+
+
+@pytest.mark.parametrize('tag', list(BEAM_RUNS))
+def test_beam_search_replays_the_reference(tiny_weights, tag):
+    from conftest import load_golden
+    g = load_golden('tiny_beam.npz')
+    kw = dict(BEAM_RUNS[tag])
+    kw['eos_token_id'] = int(g[kw['eos_token_id']])
+    draw = beam_replay(g, tag)
+    ids, scores = orc.beam_search(tiny_weights, tiny_config(), torch.from_numpy(g['images']), torch.from_numpy(g['prompt']), draw=draw, **kw)
+    assert draw.state['i'] == int(g[f'{tag}.n_draws'])
+    assert np.array_equal(ids.numpy(), g[f'{tag}.ids'])
+    close(scores, g[f'{tag}.scores'], 2e-4)
