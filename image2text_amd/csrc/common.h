@@ -67,6 +67,26 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {               // s + 
     return s + (x * s) * (1.0f - s) * (d0 + d1 * x2);
 }
 
+// ---- exact GELU (torch nn.GELU() default, torchvision's ViT MLP): x Phi(x), Phi(x) = (1 + erf(x / sqrt 2)) / 2; derivative
+// Phi(x) + x phi(x).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, branch-free: one v_rcp_f32 + one v_exp_f32 -- libm's
+// erff inlined sixteen times per thread spilled 341 registers in the generic epilogue); exp(-x^2/2) serves erf and phi alike.
+__device__ __forceinline__ float erf_sqrt2_(float x, float& e) {       // erf(x / sqrt 2); e = exp(-x^2 / 2)
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    e = __builtin_amdgcn_exp2f(-0.7213475204444817f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return copysignf(1.0f - poly * e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float e;
+    return 0.5f * x * (1.0f + erf_sqrt2_(x, e));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    float e;
+    const float phi_cdf = 0.5f * (1.0f + erf_sqrt2_(x, e));
+    return phi_cdf + x * 0.3989422804014327f * e;
+}
+
 // ---- counter-based dropout: one lowbias32 hash of (site key, idx >> 2) yields FOUR 8-bit uniforms; element idx of site
 // `key` is kept iff byte (idx & 3) of the hash is >= thr8 (thr8 = round(p * 256), so the effective p is thr8 / 256 -- 0.1016
 // for p = 0.1 -- and the host scales by 256 / (256 - thr8): the mask stays mean-preserving at the rate actually realised).

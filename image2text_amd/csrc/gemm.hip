@@ -240,6 +240,14 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, const f32x4 a
     if (p.act == I2T_ACT_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+    } else if (p.act == I2T_ACT_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    } else if (p.act == I2T_ACT_DGELU_ERF) {
+        const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] *= gelu_erf_grad(bf16_to_f32(ai[r]));
     } else if (p.act == I2T_ACT_DGELU) {
         const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
         if (nv == 4 && (p.ld_aux_in & 3) == 0) {      // one 8-byte load of the 4 pre-activations
@@ -336,8 +344,8 @@ struct EpiFlags {
     bool f_bias, f_gelu, f_dgelu, f_auxout, f_drop1, f_drop2, f_res, f_acc, f_f32;
     __device__ __forceinline__ explicit EpiFlags(const GemmParams& p) {
         f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : false;
-        f_gelu = GEN ? (p.act == I2T_ACT_GELU) : (EPI == 2);
-        f_dgelu = GEN ? (p.act == I2T_ACT_DGELU) : (EPI == 4);
+        f_gelu = GEN ? (p.act == I2T_ACT_GELU || p.act == I2T_ACT_GELU_ERF) : (EPI == 2);        // (the erf flavours: generic class only)
+        f_dgelu = GEN ? (p.act == I2T_ACT_DGELU || p.act == I2T_ACT_DGELU_ERF) : (EPI == 4);
         f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
         f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
         f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
@@ -407,7 +415,18 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
                 G2_STORE(reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]), pk);
             }
     }
-    if (F.f_gelu) {
+    if (F.GEN && (p.act == I2T_ACT_GELU_ERF || p.act == I2T_ACT_DGELU_ERF)) {      // torchvision's ViT MLP: exact (erf) GELU
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (p.act == I2T_ACT_GELU_ERF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q][r] = gelu_erf(v[q][r]);
+            } else {
+                v[q][0] *= gelu_erf_grad(bf16lo(L.ax[q][0])); v[q][1] *= gelu_erf_grad(bf16hi(L.ax[q][0]));
+                v[q][2] *= gelu_erf_grad(bf16lo(L.ax[q][1])); v[q][3] *= gelu_erf_grad(bf16hi(L.ax[q][1]));
+            }
+        }
+    } else if (F.f_gelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1757,7 +1776,8 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     I2T_REQUIRE(ldb >= (b_kmajor ? ((N + 7) & ~7) : ((K + 7) & ~7)), "i2t_gemm_bf16: ldb=%d too small", ldb);
     I2T_REQUIRE(ldc >= N, "i2t_gemm_bf16: ldc=%d < N=%d", ldc, N);
     I2T_REQUIRE(!accumulate || c_is_f32, "i2t_gemm_bf16: accumulate needs an f32 C");
-    I2T_REQUIRE(act != I2T_ACT_DGELU || aux_in, "i2t_gemm_bf16: DGELU needs aux_in");
+    I2T_REQUIRE((act != I2T_ACT_DGELU && act != I2T_ACT_DGELU_ERF) || aux_in, "i2t_gemm_bf16: DGELU needs aux_in");
+    I2T_REQUIRE(act >= I2T_ACT_NONE && act <= I2T_ACT_DGELU_ERF, "i2t_gemm_bf16: unknown act %d", act);
     I2T_REQUIRE(((uintptr_t)C & (c_is_f32 ? 15 : 7)) == 0, "i2t_gemm_bf16: C misaligned");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
@@ -1782,7 +1802,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
                 "i2t_gemm_bf16: dropout mode %d unsupported for M=%d N=%d", drop_mode, M, N);
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act != I2T_ACT_DGELU && !accumulate && !drop_mode) {
+    if (M <= 64 && !a_kmajor && !b_kmajor && !aux_out && act <= I2T_ACT_GELU && !accumulate && !drop_mode) {
         // decode-step shape: weight-streaming kernel.  In-place residual form (C is fp32 and IS the residual) may also
         // split K across workgroups when there are too few column tiles to pull HBM bandwidth from every CU.
         int ksplit = 1;

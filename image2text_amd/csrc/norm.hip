@@ -12,7 +12,7 @@ template <bool Y_F32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int M, int d) {
+                                                     int M, int d, float eps) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = d >> 2;
     for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 }
             }
         }
-        const float rstd = rsqrtf(wave_sum(q) / d + LN_EPS);
+        const float rstd = rsqrtf(wave_sum(q) / d + eps);
         if (lane == 0) {
             if (mean_out) mean_out[row] = mean;
             if (rstd_out) rstd_out[row] = rstd;
@@ -348,13 +348,18 @@ __global__ __launch_bounds__(256) void lnnd_bwd_apply_kernel(const float* __rest
 
 extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta, void* y,
                                  int y_is_f32, float* mean, float* rstd, int M, int d) {
-    I2T_REQUIRE(x && gamma && y && M > 0, "i2t_layernorm_fwd: bad args");
+    return i2t_layernorm_fwd_eps(stream, x, gamma, beta, y, y_is_f32, mean, rstd, M, d, LN_EPS);
+}
+
+extern "C" int i2t_layernorm_fwd_eps(void* stream, const float* x, const float* gamma, const float* beta, void* y,
+                                     int y_is_f32, float* mean, float* rstd, int M, int d, float eps) {
+    I2T_REQUIRE(x && gamma && y && M > 0 && eps > 0.f, "i2t_layernorm_fwd: bad args");
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
     int grid = (M + 3) / 4;
     if (grid > 8192) grid = 8192;
     hipStream_t s = (hipStream_t)stream;
-    if (y_is_f32) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d);
-    else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d);
+    if (y_is_f32) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
     I2T_CHECK_LAUNCH("i2t_layernorm_fwd");
     return I2T_OK;
 }

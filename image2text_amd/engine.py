@@ -41,6 +41,7 @@ from . import ops, rng
 from .engine_family import FamilyBlocks, family_spec
 from .engine_llama import LlamaBlocks
 from .engine_lora import LPAD, LoraAdapters
+from .engine_vit import ViTEncoder
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -193,6 +194,7 @@ class ParamArena:
                 view = self.p32[o:o + n].view(shape)
                 view.copy_(p.data.to(device=device, dtype=F32))
                 p.data = view
+        self.skip_grad = set()          # names no backward ever writes (a backbone the reference runs under no_grad): their .grad stays None
         self._versions = None
         self.generation = 0             # bumped whenever parameter VALUES change (torch-side writes seen by refresh_shadow, fused optimizer steps)
         self.grads_attached = False
@@ -227,7 +229,7 @@ class ParamArena:
     def trainable(self, name: str) -> bool:
         """False for a frozen parameter (requires_grad off, e.g. LoRA's base weights): backward skips its gradient GEMM"""
         p = self.params.get(name)
-        return p is None or p.requires_grad
+        return (p is None or p.requires_grad) and name not in self.skip_grad
 
     def Gt(self, name: str) -> Optional[torch.Tensor]:
         """the gradient view of a TRAINABLE parameter, else None (kernels skip null gradient outputs)"""
@@ -259,7 +261,7 @@ class ParamArena:
 
     def attach_grads(self):
         for name, p in self.params.items():
-            if p.requires_grad and p.grad is None:
+            if p.requires_grad and p.grad is None and name not in self.skip_grad:
                 p.grad = self.G(name)
 
 
@@ -271,7 +273,7 @@ def decoder_hot_config(model):
     return getattr(model.decoder, 'hot_config', None) or model.config.decoder_config
 
 
-class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
+class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
     """Forward/backward of one VisionEncoderDecoder over the HIP kernels."""
 
     def __init__(self, model: torch.nn.Module):
@@ -286,13 +288,17 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
         self.has_bridge = model.has_bridge
         self.ep = 'encoder.0.' if self.has_bridge else 'encoder.'
         self.dp = 'decoder.'
-        eac = ecfg.transformer_config.attn_config
-        self.enc = SimpleNamespace(d=eac.n_embd, H=eac.n_head, L=ecfg.n_layer, ncls=ecfg.n_cls,
-                                   P2=ecfg.num_patches ** 2, causal=ecfg.transformer_config.is_causal,
-                                   ff=int(_ff_mult(ecfg.transformer_config.rotator_config) * eac.n_embd),
-                                   dropout=eac.dropout, attn_dropout=eac.attn_dropout,
-                                   k=ecfg.feature_extractor_kernel_size[0])
-        self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
+        self.vit = not hasattr(ecfg, 'transformer_config')         # PretrainedViTConfig: torchvision backbone + head (engine_vit.ViTEncoder)
+        if self.vit:
+            self.vit_setup(model, ecfg)
+        else:
+            eac = ecfg.transformer_config.attn_config
+            self.enc = SimpleNamespace(kind='scratch', d=eac.n_embd, H=eac.n_head, L=ecfg.n_layer, ncls=ecfg.n_cls,
+                                       P2=ecfg.num_patches ** 2, causal=ecfg.transformer_config.is_causal,
+                                       ff=int(_ff_mult(ecfg.transformer_config.rotator_config) * eac.n_embd),
+                                       dropout=eac.dropout, attn_dropout=eac.attn_dropout,
+                                       k=ecfg.feature_extractor_kernel_size[0])
+            self.enc.fam = family_spec(ecfg.transformer_config, ecfg.n_layer)
         ls = getattr(model.decoder, 'llama_spec', None)
         if ls is not None:
             # Llama-2 / Qwen2 blocks (engine_llama.LlamaBlocks): RMSNorm, rotary embedding, grouped K/V heads, SwiGLU; no learned
@@ -325,18 +331,19 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
         self._moe_cache, self._sub_cache = {}, {}
         self._lora_merge_list = []
         self.moe_trace = None           # tests set a dict: site -> [(gate values, routing weights), ...] of every MoELinear forward
-        gates = list(ecfg.feature_extractor_gate_sizes or [])
-        chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
-        self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]
-        # MFMA (channels-last) convolutions when the kernel is 6x6 and every intermediate width is 8/16/32 channels
-        self.conv_mfma = (ecfg.feature_extractor_kernel_size[0] == 6 and all(c in (8, 16, 32) for c in chans[1:-1])
-                          and chans[0] <= 8 and chans[-1] <= 32 and all(c <= 16 for c in chans[:-1]))
-        # non-causal encoder: its output reads only the CLS rows, so the last block runs on those rows (block_fwd_cls);
-        # I2T_FULL_LAST_BLOCK=1 keeps the full-row form (A/B runs)
-        self.cls_only_last = ((not self.enc.causal) and self.enc.L >= 1 and os.environ.get('I2T_FULL_LAST_BLOCK') != '1'
-                              and self.enc.fam is None)
-        self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
-        self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
+        if not self.vit:
+            gates = list(ecfg.feature_extractor_gate_sizes or [])
+            chans = [ecfg.input.n_channels] + gates + [ecfg.n_channels]
+            self.conv = [(f'{self.ep}feature_extractor.model.{2 * i}', chans[i], chans[i + 1]) for i in range(len(chans) - 1)]
+            # MFMA (channels-last) convolutions when the kernel is 6x6 and every intermediate width is 8/16/32 channels
+            self.conv_mfma = (ecfg.feature_extractor_kernel_size[0] == 6 and all(c in (8, 16, 32) for c in chans[1:-1])
+                              and chans[0] <= 8 and chans[-1] <= 32 and all(c <= 16 for c in chans[:-1]))
+            # non-causal encoder: its output reads only the CLS rows, so the last block runs on those rows (block_fwd_cls);
+            # I2T_FULL_LAST_BLOCK=1 keeps the full-row form (A/B runs)
+            self.cls_only_last = ((not self.enc.causal) and self.enc.L >= 1 and os.environ.get('I2T_FULL_LAST_BLOCK') != '1'
+                                  and self.enc.fam is None)
+            self.patch = (ecfg.input.width // ecfg.num_patches, ecfg.input.height // ecfg.num_patches)
+            self.input_d = ecfg.n_channels * self.patch[0] * self.patch[1]
         self.dec_cross = [dcfg.transformer_config.is_cross_attn and not (dcfg.skip_alternate_cross_attn and l % 2)
                           for l in range(dcfg.n_layer)]
         # fused cross-attention forward (K/V projection + attention in one launch) when the shapes allow; I2T_XATTN_FUSED=0: A/B runs
@@ -385,6 +392,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
             raise I2TError('the image2text_amd hot path runs on the MI355X only: move the model to cuda (no CPU path)')
         if self.arena is None or self.arena.device != dev or not self.arena.valid():
             self.arena = ParamArena(self.model, dev)
+            if self.vit:
+                self.arena.skip_grad = self.vit_skip_grad()
             self._ws = torch.zeros(4, dtype=F32, device=dev)
             self._conv_ws_pool = {}
             self._conv_scratch = torch.empty(32 * 36 * 16, dtype=F32, device=dev)
@@ -699,6 +708,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
 
     # ------------------------------------------------------------------------------------------------ encoder
     def encode(self, images: torch.Tensor, save: bool):
+        if self.vit:
+            return self.vit_encode(images, save)
         a, e = self.arena, self.enc
         images = images.to(device=a.device, dtype=F32).contiguous()
         B, C, Hh, Ww = images.shape
@@ -766,6 +777,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters):
 
     def encode_backward(self, ctx, denc: torch.Tensor):
         """denc: fp32 [B*ncls, d_out] gradient w.r.t. the encoder output (bridge output when there is one)."""
+        if self.vit:
+            return self.vit_encode_backward(ctx, denc)
         a, e = self.arena, self.enc
         B, d, T, Mc = ctx.B, e.d, e.ncls + e.P2, ctx.B * e.ncls
         gf = a.P(f'{self.ep}transformer.ln_f.weight')

@@ -19,6 +19,7 @@ SIGNATURES = {
     'i2t_xattn_kv_fused': [P, P, I, P, I, P, P, L, I, P, I, P, I, P, L, I, P, I, I, I, I, U, U, F],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
+    'i2t_layernorm_fwd_eps': [P, P, P, P, P, I, P, P, I, I, F],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
@@ -79,6 +80,16 @@ SIGNATURES = {
     'i2t_dgelu_mul': [P, P, P, P, L],
     'i2t_lora_stage': [P, P, P, I, P, L, I, U, U, F],
     'i2t_gemm_bf16_ws': [P, P, I, P, I, P, I, I, I, I, I, P, I, P, I, P, L],
+    'i2t_patchify': [P, P, P, I, I, I, I, I],
+    'i2t_vit_tokens': [P, P, P, P, P, I, I, I],
+    'i2t_l2norm_fwd': [P, P, P, P, P, I, I],
+    'i2t_l2norm_bwd': [P, P, P, P, P, I, I, I],
+    'i2t_transpose_last2': [P, P, P, P, L, I, I],
+    'i2t_peer_lookup_fwd': [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I],
+    'i2t_peer_lookup_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I],
+    'i2t_gemm_f32': [P, P, P, P, I, I, I],
+    'i2t_lsh_embed_fwd': [P, P, P, L, P, P, P, P, P, P, I, I, I, I, I],
+    'i2t_lsh_embed_bwd': [P, P, P, P, L, P, I, I, I, I, I],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

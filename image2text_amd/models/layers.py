@@ -106,9 +106,9 @@ class MLP(_Container):
         blocks.append(nn.Linear(prev, out_features, bias=bias))
         self.add_residual_connection = add_residual_connection
         self.model = nn.Sequential(*blocks)
-        if add_residual_connection and in_features != out_features:
-            raise NotImplementedError('MLP residual connector with in_features != out_features is outside the HIP hot path')
-        self.residual_connector = nn.Identity()
+        # a Linear when the widths differ (reference layers.py:246-250): only the PretrainedViT slot heads use that form
+        self.residual_connector = nn.Linear(in_features, out_features) if (add_residual_connection and in_features != out_features) \
+            else nn.Identity()
 
 
 class AdvancedPositionalBiasMLP(_Container):
@@ -120,6 +120,59 @@ class AdvancedPositionalBiasMLP(_Container):
         super().__init__()
         self.models = nn.ModuleList([MLP(in_features, out_features, gate_sizes, bias=True, add_residual_connection=add_residual_connection)
                                      for _ in range(context_width)])
+
+
+class PeerLookupQueryUnit(_Container):
+    """One half of the product key: Linear(query_dim -> sqrt(num_units)), top-k of its scores (reference layers.py:20-34)."""
+
+    def __init__(self, num_embed: int, emb_dim: int, topk: int):
+        super().__init__()
+        self.linear = nn.Linear(emb_dim, num_embed, bias=False)
+        self.topk = topk
+
+
+class PeerLookup(_Container):
+    """Parameters of the product-key expert lookup (reference layers.py:37-109; arithmetic: engine_vit / csrc/vit.hip)."""
+
+    def __init__(self, in_features: int, out_features: int, num_units: int, topk: int, nhead: int = 1, query_dim: Optional[int] = None):
+        super().__init__()
+        self.query_dim = query_dim or (in_features // 2)
+        self.residual = nn.Linear(in_features, out_features, bias=False)
+        self.query_linear = nn.Linear(in_features, self.query_dim * nhead, bias=False)
+        self.key_linear = nn.Linear(in_features, in_features * nhead, bias=False)
+        self.nhead, self.topk = nhead, topk
+        self.num_query_units = int(math.sqrt(num_units))
+        if self.num_query_units * self.num_query_units != num_units:
+            raise ValueError(f"num_units must be a perfect square but {num_units} was not")
+        self.query_left = PeerLookupQueryUnit(self.num_query_units, self.query_dim, topk)
+        self.query_right = PeerLookupQueryUnit(self.num_query_units, self.query_dim, topk)
+        self.emb_in = nn.Embedding(num_units, in_features)
+        self.emb_out = nn.Embedding(num_units, out_features)
+
+
+class CosineVectorEmbedding(_Container):
+    """Fixed random cosine projections -> bucket ids -> EmbeddingBag(mean) (reference layers.py:112-143).  The three buffers are
+    persistent (they are part of the state dict: a checkpoint carries its own projections)."""
+
+    def __init__(self, inp_dim: int, emb_dim: int, n_proj: int = 16, num_bins: int = 20):
+        super().__init__()
+        self.register_buffer('projection_mat', torch.nn.functional.normalize(torch.randn((inp_dim, n_proj)), p=2.0, dim=0), persistent=True)
+        resolution = 2.0 / num_bins
+        self.register_buffer('grid', torch.linspace(-1, 1, num_bins + 1)[:-1] + 0.5 * resolution, persistent=True)
+        self.register_buffer('pos_offset', ((num_bins + 1) * torch.arange(0, n_proj, dtype=torch.long)).long().reshape(-1, 1, 1), persistent=True)
+        self.emb = nn.EmbeddingBag((num_bins + 1) * n_proj, emb_dim)
+        self.emb_dim, self.n_proj, self.num_bins = emb_dim, n_proj, num_bins
+
+
+class CompositeCosineVectorEmbedding(_Container):
+    """Sum of CosineVectorEmbeddings at several bin resolutions (reference layers.py:190-219)."""
+
+    def __init__(self, inp_dim: int, emb_dim: int, num_bins: Tuple[int, ...], n_proj: int, learnable: bool):
+        super().__init__()
+        if learnable:
+            raise NotImplementedError('LearnableCosineVectorEmbedding (lsh_config.learnable: True; no shipped yaml uses it) is outside '
+                                      'the HIP hot path')
+        self.emb = nn.ModuleList([CosineVectorEmbedding(inp_dim=inp_dim, emb_dim=emb_dim, n_proj=n_proj, num_bins=k) for k in num_bins])
 
 
 class _MoEUnit(_Container):

@@ -77,8 +77,13 @@ def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumula
     return out
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=None):
+    """eps None: the reference's LayerNorm (1e-5); torchvision's ViT blocks pass 1e-6."""
     _need_cuda(x, y)
+    if eps is not None:
+        _l.check(_lib().i2t_layernorm_fwd_eps(_stream(), _p(x), _p(gamma), _p(beta), _p(y), int(y.dtype == F32), _p(mean), _p(rstd),
+                                              M, d, float(eps)), 'i2t_layernorm_fwd_eps')
+        return y
     _l.check(_lib().i2t_layernorm_fwd(_stream(), _p(x), _p(gamma), _p(beta), _p(y), int(y.dtype == F32), _p(mean), _p(rstd),
                                       M, d), 'i2t_layernorm_fwd')
     return y
@@ -535,3 +540,74 @@ class Graph:
                 _lib().i2t_graph_destroy(self._exec)
             except Exception:
                 pass
+
+
+# ---- PretrainedViT pieces (csrc/vit.hip)
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_ERF, ACT_DGELU_ERF = 0, 1, 2, 3, 4
+
+
+def patchify(images, out, B, C, H, W, p):
+    _need_cuda(images, out)
+    assert images.dtype == F32 and out.dtype == BF16 and images.is_contiguous()
+    _l.check(_lib().i2t_patchify(_stream(), _p(images), _p(out), B, C, H, W, p), 'i2t_patchify')
+    return out
+
+
+def vit_tokens(proj, cls, pos, x, B, T, d):
+    _need_cuda(proj, cls, pos, x)
+    _l.check(_lib().i2t_vit_tokens(_stream(), _p(proj), _p(cls), _p(pos), _p(x), B, T, d), 'i2t_vit_tokens')
+    return x
+
+
+def l2norm_fwd(x, y, y_bf16, inv_norm, M, d):
+    _need_cuda(x, y, y_bf16, inv_norm)
+    _l.check(_lib().i2t_l2norm_fwd(_stream(), _p(x), _p(y), _p(y_bf16), _p(inv_norm), M, d), 'i2t_l2norm_fwd')
+
+
+def l2norm_bwd(dy, x, inv_norm, dx, M, d, accumulate=False):
+    _need_cuda(dy, x, inv_norm, dx)
+    _l.check(_lib().i2t_l2norm_bwd(_stream(), _p(dy), _p(x), _p(inv_norm), _p(dx), int(accumulate), M, d), 'i2t_l2norm_bwd')
+    return dx
+
+
+def transpose_last2(src, dst, dst_bf16, B, R, C):
+    _need_cuda(src, dst, dst_bf16)
+    assert src.dtype == F32 and src.is_contiguous()
+    _l.check(_lib().i2t_transpose_last2(_stream(), _p(src), _p(dst), _p(dst_bf16), B, R, C), 'i2t_transpose_last2')
+
+
+def peer_lookup_fwd(scores, inp_proj, residual, emb_in, emb_out, out, sv, M, nhead, nq, topk, din, dout):
+    """sv: namespace(unit int32 [M, nhead, topk], lr int32 [M, nhead, topk, 2], score f32, dot f32)."""
+    _need_cuda(scores, inp_proj, residual, emb_in, emb_out, out)
+    assert scores.dtype == F32 and inp_proj.dtype == BF16 and emb_in.dtype == BF16 and emb_out.dtype == BF16 and residual.dtype == F32
+    _l.check(_lib().i2t_peer_lookup_fwd(_stream(), _p(scores), _p(inp_proj), _p(residual), _p(emb_in), _p(emb_out), _p(out), _p(sv.unit),
+                                        _p(sv.lr), _p(sv.score), _p(sv.dot), M, nhead, nq, topk, din, dout), 'i2t_peer_lookup_fwd')
+    return out
+
+
+def peer_lookup_bwd(dout, inp_proj, emb_in, emb_out, sv, dscores, dinp_proj, g_emb_in, g_emb_out, M, nhead, nq, topk, din, dout_w):
+    _need_cuda(dout, inp_proj, emb_in, emb_out, dscores, dinp_proj)
+    _l.check(_lib().i2t_peer_lookup_bwd(_stream(), _p(dout), _p(inp_proj), _p(emb_in), _p(emb_out), _p(sv.unit), _p(sv.lr), _p(sv.score),
+                                        _p(sv.dot), _p(dscores), _p(dinp_proj), _p(g_emb_in), _p(g_emb_out), M, nhead, nq, topk, din, dout_w),
+             'i2t_peer_lookup_bwd')
+
+
+def gemm_f32(x, P, z, M, N, K):
+    _need_cuda(x, P, z)
+    assert x.dtype == F32 and P.dtype == F32 and z.dtype == F32 and x.is_contiguous() and P.is_contiguous() and z.is_contiguous()
+    _l.check(_lib().i2t_gemm_f32(_stream(), _p(x), _p(P), _p(z), M, N, K), 'i2t_gemm_f32')
+    return z
+
+
+def lsh_embed_fwd(z, tables, slot_stride, tab_off, nbins, grids, grid_off, out, rows, B, n_cls, nK, n_proj, dout):
+    _need_cuda(z, tables, tab_off, nbins, grids, grid_off, out, rows)
+    assert tab_off.dtype == torch.int64 and nbins.dtype == torch.int32 and grid_off.dtype == torch.int32 and rows.dtype == torch.int32
+    _l.check(_lib().i2t_lsh_embed_fwd(_stream(), _p(z), _p(tables), int(slot_stride), _p(tab_off), _p(nbins), _p(grids), _p(grid_off), _p(out),
+                                      _p(rows), B, n_cls, nK, n_proj, dout), 'i2t_lsh_embed_fwd')
+    return out
+
+
+def lsh_embed_bwd(dy, rows, g_tables, slot_stride, tab_off, B, n_cls, nK, n_proj, dout):
+    _need_cuda(dy, rows, g_tables, tab_off)
+    _l.check(_lib().i2t_lsh_embed_bwd(_stream(), _p(dy), _p(rows), _p(g_tables), int(slot_stride), _p(tab_off), B, n_cls, nK, n_proj, dout),
+             'i2t_lsh_embed_bwd')

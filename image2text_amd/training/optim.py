@@ -49,12 +49,16 @@ class _ArenaOptimizer(torch.optim.Optimizer):
 
     def _build(self, arena):
         by_ptr = {}
+        # parameters no backward ever writes (a backbone run under no_grad: their .grad stays None and torch's optimizers skip them)
+        skipped = {arena.p32.data_ptr() + 4 * arena.entries[n][0] for n in getattr(arena, 'skip_grad', ())}
+        self._skipped = skipped
         for g in self.param_groups:
             for p in g['params']:
                 if arena_of(p) is not arena:
                     raise RuntimeError(f'{type(self).__name__}: a parameter of shape {tuple(p.shape)} lives outside the arena')
                 # (a frozen parameter -- LoRA's base weights -- keeps its value whatever group it was handed over in)
-                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p) if p.requires_grad else (-1.0, 0.0, p)      # lr < 0: skipped by the kernels
+                by_ptr[p.data_ptr()] = (g['lr'], g['weight_decay'], p) if (p.requires_grad and p.data_ptr() not in skipped) \
+                    else (-1.0, 0.0, p)      # lr < 0: skipped by the kernels
         ends, lrs, wds, self._params = [], [], [], []
         items = sorted(arena.entries.items(), key=lambda kv: kv[1][0])
         for i, (name, (off, n, _)) in enumerate(items):
@@ -82,7 +86,7 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         if self._tables is None or self._arena is not arena or \
                 self._tables[4] != tuple((g['lr'], g['weight_decay']) for g in self.param_groups):      # lr schedulers edit the groups
             self._build(arena)
-        missing = [n for n, p in self._params if p.requires_grad and p.grad is None]
+        missing = [n for n, p in self._params if p.requires_grad and p.grad is None and p.data_ptr() not in self._skipped]
         if missing:
             raise RuntimeError(f'{type(self).__name__}.step: {len(missing)} parameters have no gradient (first: {missing[0]}); the '
                                'fused step updates the whole arena at once')

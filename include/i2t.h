@@ -52,6 +52,8 @@ int i2t_last_error(char* buf, size_t n);
 #define I2T_ACT_NONE 0
 #define I2T_ACT_GELU 1
 #define I2T_ACT_DGELU 2
+#define I2T_ACT_GELU_ERF 3  /* exact GELU x Phi(x) (torchvision ViT MLP); generic epilogue class only */
+#define I2T_ACT_DGELU_ERF 4 /* v *= gelu_erf'(aux_in[m][n]) */
 int i2t_gemm_bf16(void* stream,
                   const void* A, int lda, int a_kmajor,
                   const void* B, int ldb, int b_kmajor,
@@ -108,6 +110,9 @@ int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* ou
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_layernorm_fwd(void* stream, const float* x, const float* gamma, const float* beta,
                       void* y, int y_is_f32, float* mean, float* rstd, int M, int d);
+/* the same forward with an explicit eps (torchvision's ViT blocks: 1e-6); the backward only needs the saved rstd */
+int i2t_layernorm_fwd_eps(void* stream, const float* x, const float* gamma, const float* beta,
+                          void* y, int y_is_f32, float* mean, float* rstd, int M, int d, float eps);
 int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                       const float* mean, const float* rstd,
                       float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
@@ -439,6 +444,43 @@ int i2t_graph_capture_begin(void* stream);
 int i2t_graph_capture_end(void* stream, void** graph_exec_out);
 int i2t_graph_launch(void* graph_exec, void* stream);
 int i2t_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * PretrainedViT (reference models/encoder.py:56-127): torchvision ViT-B/16 backbone + three heads.  The backbone's blocks run on
+ * i2t_gemm_bf16 (I2T_ACT_GELU_ERF), i2t_attention_* and i2t_layernorm_fwd_eps; these are the pieces around them (csrc/vit.hip).
+ *   i2t_patchify: conv_proj (p x p, stride p; encoder.py:60 -> torchvision VisionTransformer._process_input) as a GEMM: images f32
+ *     [B][C][H][W] -> out bf16 [B (H/p) (W/p)][C p p], column order (c, ky, kx) = the flattened conv weight's.
+ *   i2t_vit_tokens: x f32 [B][T][d] = [class_token | proj rows of the image] + pos_embedding (T = P^2 + 1).
+ *   i2t_l2norm_fwd / _bwd: F.normalize(p = 2, eps 1e-12) over the last dim of M rows (encoder.py:118-119); y f32 and / or bf16,
+ *     inv_norm f32 [M] saved; bwd: dx (+)= (dy - y <y, dy>) inv_norm.
+ *   i2t_transpose_last2: dst[b][c][r] = src[b][r][c] (the (e, s) <-> (s, e) exchange around the peer_proj_wt GEMM, encoder.py:116).
+ *   i2t_peer_lookup_fwd / _bwd: PeerLookup.forward after its linear maps (models/layers.py:78-109), one workgroup per row:
+ *     scores f32 [M nhead][2 nq] = [query_left | query_right] scores, inp_proj bf16 [M][nhead din], residual f32 [M][dout],
+ *     emb_in bf16 [units][din], emb_out bf16 [units][dout] -> out f32 [M][dout]; saved per (row, head, j < topk): expert unit,
+ *     (left, right) query-unit indices, softmax score, pre-GELU dot.  bwd: dscores f32 (PRE-ZEROED by the caller), dinp_proj
+ *     bf16, expert-table gradients accumulated with fp32 atomics (null = frozen).
+ *   i2t_gemm_f32: z[M][N] = x[M][K] . P[K][N], fp32 FMA (the LSH projections: bucket decisions must not see bf16 rounding).
+ *   i2t_lsh_embed_fwd / _bwd: CompositeCosineVectorEmbedding per slot (models/layers.py:112-143,190-219): z f32 [B][n_cls nK n_proj]
+ *     -> bucket = #(grid points < z) -> mean over projections of table rows, summed over the nK resolutions; table k of slot s =
+ *     tables + s slot_stride + tab_off[k] (f32 [(nbins[k] + 1) n_proj][dout]); grid k = grids + grid_off[k]; rows int [B][n_cls][nK][n_proj]
+ *     saved; bwd scatters dy / n_proj into the tables' gradients (atomics).
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_patchify(void* stream, const float* images, void* out, int B, int C, int H, int W, int p);
+int i2t_vit_tokens(void* stream, const float* proj, const float* cls, const float* pos, float* x, int B, int T, int d);
+int i2t_l2norm_fwd(void* stream, const float* x, float* y, void* y_bf16, float* inv_norm, int M, int d);
+int i2t_l2norm_bwd(void* stream, const float* dy, const float* x, const float* inv_norm, float* dx, int accumulate, int M, int d);
+int i2t_transpose_last2(void* stream, const float* src, float* dst, void* dst_bf16, long B, int R, int C);
+int i2t_peer_lookup_fwd(void* stream, const float* scores, const void* inp_proj, const float* residual, const void* emb_in,
+                        const void* emb_out, float* out, int* sv_unit, int* sv_lr, float* sv_score, float* sv_dot, int M, int nhead,
+                        int nq, int topk, int din, int dout);
+int i2t_peer_lookup_bwd(void* stream, const float* dout, const void* inp_proj, const void* emb_in, const void* emb_out,
+                        const int* sv_unit, const int* sv_lr, const float* sv_score, const float* sv_dot, float* dscores,
+                        void* dinp_proj, float* g_emb_in, float* g_emb_out, int M, int nhead, int nq, int topk, int din, int dout_w);
+int i2t_gemm_f32(void* stream, const float* x, const float* P, float* z, int M, int N, int K);
+int i2t_lsh_embed_fwd(void* stream, const float* z, const float* tables, long slot_stride, const long* tab_off, const int* nbins,
+                      const float* grids, const int* grid_off, float* out, int* rows, int B, int n_cls, int nK, int n_proj, int dout);
+int i2t_lsh_embed_bwd(void* stream, const float* dy, const int* rows, float* g_tables, long slot_stride, const long* tab_off, int B,
+                      int n_cls, int nK, int n_proj, int dout);
 
 #ifdef __cplusplus
 }

@@ -324,6 +324,11 @@ def vit_encoder(sd: SD, cfg, images, training=False, plan=None, moe_io=None):
 def encode(sd: SD, cfg, images, training=False, plan=None, moe_io=None):
     """vision_encoder_decoder.py:26-39,58-59: encoder, then the bias-free bridge Linear when the widths differ
     (state-dict keys then carry the nn.Sequential prefixes ``encoder.0.`` / ``encoder.1.``)."""
+    if not hasattr(cfg.vision_encoder_config, 'transformer_config'):      # PretrainedViTConfig: oracle/vit.py (encoder.py:56-127)
+        from . import vit
+        if 'encoder.1.weight' in sd:
+            return F.linear(vit.pretrained_vit(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images), sd['encoder.1.weight'])
+        return vit.pretrained_vit(_sub(sd, 'encoder.'), cfg.vision_encoder_config, images)
     if 'encoder.1.weight' in sd:
         y = vit_encoder(_sub(sd, 'encoder.0.'), cfg.vision_encoder_config, images, training, plan, _moe_sub(moe_io, 'encoder.0.'))
         return F.linear(y, sd['encoder.1.weight'])
