@@ -65,7 +65,7 @@ class GemmTimer:
                     (2 if kw.get('aux_in') is not None else 0) + (2 if kw.get('aux_out') is not None else 0)
             kind = ('A^T' if kw.get('a_kmajor') else 'A') + ('.B' if kw.get('b_kmajor') else '.B^T') + \
                    (' f32' if c_bytes == 4 else ' bf16') + ('+res' if kw.get('residual') is not None else '') + \
-                   ('+acc' if kw.get('accumulate') else '') + {0: '', 1: '+gelu', 2: '+dgelu'}[int(kw.get('act', 0))] + \
+                   ('+acc' if kw.get('accumulate') else '') + {0: '', 1: '+gelu', 2: '+dgelu', 3: '+gelu_erf', 4: '+dgelu_erf'}[int(kw.get('act', 0))] + \
                    ('+drop' if kw.get('drop') is not None else '')
             self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + (c_bytes + extra) * M * N, (M, N, K, kind)))
             return r

@@ -53,6 +53,9 @@ def main():
     ap.add_argument('--cpu', action='store_true')
     ap.add_argument('--freeze-decoder', action='store_true', help='prepare_for_kbit_training: True without 4-bit loading (reference '
                     'local/llama2-7b.yaml): the decoder is frozen, only the encoder trains through the soft prompt')
+    ap.add_argument('--vit', default='none', choices=['none', 'frozen', 'refine'], help="encoder = the reference's PretrainedViT (torchvision ViT-B/16 "
+                    "shape, randomly initialised: the SWAG checkpoint is not in the image) with the slot-MLP head of local/gpt2.yaml (n_cls 16, "
+                    "gate_sizes [1024], n_embd_out_vit 768): BASELINE.json configs[2].  frozen = refine_base_model: False")
     ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
                     "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
     args = ap.parse_args()
@@ -68,6 +71,11 @@ def main():
     os.chdir(scratch)
     torch.manual_seed(0)
     base = nano224_config(dropout=0.1)
+    if args.vit != 'none':
+        from image2text_amd.configs.models import PretrainedViTConfig
+        os.environ.setdefault('I2T_VIT_B16_CHECKPOINT', 'random')
+        base = base.model_copy(update=dict(vision_encoder_config=PretrainedViTConfig(
+            n_cls=16, n_embd_out_vit=768, gate_sizes=(1024,), refine_base_model=args.vit == 'refine')))
     llama = args.size in LLAMA_SIZES
     if llama:
         import transformers
@@ -120,9 +128,12 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     kind = type(wrapper.model.decoder).__name__
-    out = {'workload': f'nano-224 ViT (6x512, 224x224x3, 64 CLS) + {kind}({args.size}, randomly initialised checkpoint, '
+    enc_name = 'nano-224 ViT (6x512, 224x224x3, 64 CLS)' if args.vit == 'none' else \
+        f'PretrainedViT (ViT-B/16 shape 12x768, 224x224x3, random init, backbone {"trains" if args.vit == "refine" else "frozen"}, 16 slot MLPs 768-1024-768)'
+    n_prompt = eng.enc.ncls
+    out = {'workload': f'{enc_name} + {kind}({args.size}, randomly initialised checkpoint, '
                        + ('' if llama else 'cross-attention, dropout 0.1, ') +
-                       f'soft prompt of 64 + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else (', decoder frozen (prepare_for_kbit_training)' if args.freeze_decoder else ', every parameter trains')),
+                       f'soft prompt of {n_prompt} + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else (', decoder frozen (prepare_for_kbit_training)' if args.freeze_decoder else ', every parameter trains')),
            'params_M': round(n_params / 1e6, 1), 'trainable_params_M': round(n_train / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
