@@ -17,6 +17,7 @@
 // (O^T[d][q] = V^T[d][key] . P^T[key][q]) with the key order permuted identically on the V^T side (the transposed
 // LDS read takes any 4-row set) -- cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand".
 #include "attention_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -528,6 +529,276 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     }
 }
 
+// ================================================================================================== v2: resident operands
+// The kernels above pay per workgroup ITERATION (two barriers + a staged tile each): at T = 260 a (sequence, head) pair costs 5 x 5
+// of them for 3 % more work than T = 256, every wave re-reads the whole K and V tile from LDS for only 16 query rows (the LDS
+// array, not the VALU, sets the pace), and each pair's K / V are fetched 5 times.  v2 (dense, non-causal, up to 288 keys / 304
+// queries: the encoders): ONE workgroup per pair, its K and V (or Q and dO) staged ONCE into LDS and resident -- 128-byte rows,
+// 16-byte chunks XOR-swizzled by (row & 7): conflict-free for the row reads and for the transposed reads, 2 x 288 rows = 72 KiB,
+// two workgroups per CU -- no barrier after the staging one.  A wave owns up to 4 sixteen-row blocks of the other operand and
+// walks the resident one in 64-row steps, so an LDS fragment serves 4 MFMAs instead of 1.  The row blocks that do not divide by
+// the 4 waves (T = 260: block 17 holds 4 rows) are shared by all waves ACROSS the resident operand -- every wave takes a quarter
+// of its rows -- and combined through LDS (split softmax: (m, l, O) partials), so no wave carries a fifth block.
+constexpr int V2_MAXROWS = 288, V2_RB = 128, V2_NQB = 4;
+constexpr int V2_MAX_OTHER = 16 * (4 * V2_NQB + 3);                    // 304 rows of the per-wave operand
+
+__device__ __forceinline__ void v2_stage2(unsigned char* la, unsigned char* lb, const bf16_t* a, int a_rs, const bf16_t* b, int b_rs,
+                                          int nrows, int rows_pad, int tid) {
+    const int total = rows_pad * 8;
+    for (int c0 = tid; c0 < total; c0 += 1024) {
+        u32x4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 256 * u, r = c >> 3, kc = c & 7;
+            va[u] = vb[u] = u32x4{0u, 0u, 0u, 0u};
+            if (c < total && r < nrows) {
+                va[u] = *reinterpret_cast<const u32x4*>(a + (size_t)r * a_rs + kc * 8);
+                vb[u] = *reinterpret_cast<const u32x4*>(b + (size_t)r * b_rs + kc * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 256 * u, r = c >> 3, kc = c & 7;
+            if (c < total) {
+                const int off = r * V2_RB + ((kc ^ (r & 7)) << 4);
+                *reinterpret_cast<u32x4*>(la + off) = va[u];
+                *reinterpret_cast<u32x4*>(lb + off) = vb[u];
+            }
+        }
+    }
+}
+// row fragment: lane (g, i) <- rows r0 + i, elements 32 ks + 8 g .. + 7
+__device__ __forceinline__ bf16x8 v2_row_frag(const unsigned char* lds, int r0, int ks, int lane) {
+    const int g = lane >> 4, r = r0 + (lane & 15);
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + r * V2_RB + (((ks * 4 + g) ^ (r & 7)) << 4)));
+}
+// transposed fragment: lane (g, i) <- column c0 + i of rows rbase + 16 (j >> 2) + 4 g + (j & 3), j = 0 .. 7
+__device__ __forceinline__ bf16x8 v2_tr_frag(const unsigned char* lds, int rbase, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int r = rbase + 4 * g + (i >> 2), cb = (c0 + 4 * (i & 3)) * 2;
+    const unsigned char* a = lds + r * V2_RB + (((cb >> 4) ^ (r & 7)) << 4) + (cb & 15);
+    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 16 * V2_RB);       // (r + 16) & 7 == r & 7
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// One step of CNT query blocks against NKJ (2 or 4) 16-key blocks starting at block cb, everything a compile-time constant: one
+// basic block the scheduler can interleave (runtime `qb < cnt` / `kj < nkj` tests compiled into ~160 scalar branches and cost 40 %).
+// MASK: keys >= Tk get -inf (the last step of a range; an odd block count is rounded up to the next even one: rows exist to a
+// multiple of 32 and V's are zero there).
+template <bool DROP, int CNT, int NKJ, bool MASK, int NA>
+__device__ __forceinline__ void v2_fwd_step(const unsigned char* k_lds, const unsigned char* v_lds, const bf16x8 (&qf)[NA][2], int cb, int Tk,
+                                            const unsigned (&drow)[NA], unsigned drop_key, unsigned drop_thr, f32x4 (&o)[NA][4],
+                                            float (&m)[NA], float (&l)[NA], int lane) {
+    const int g = lane >> 4;
+    f32x4 s[CNT][NKJ];
+#pragma unroll
+    for (int kj = 0; kj < NKJ; ++kj) {
+        const bf16x8 k0 = v2_row_frag(k_lds, (cb + kj) * 16, 0, lane), k1 = v2_row_frag(k_lds, (cb + kj) * 16, 1, lane);
+#pragma unroll
+        for (int qb = 0; qb < CNT; ++qb) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], a, 0, 0, 0);
+            s[qb][kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
+        }
+    }
+    bf16x8 pf[CNT][NKJ / 2];
+#pragma unroll
+    for (int qb = 0; qb < CNT; ++qb) {
+        if constexpr (MASK) {
+#pragma unroll
+            for (int kj = 0; kj < NKJ; ++kj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((cb + kj) * 16 + 4 * g + r >= Tk) s[qb][kj][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), fmaxf(s[qb][0][2], s[qb][0][3]));
+#pragma unroll
+        for (int kj = 1; kj < NKJ; ++kj) mx = fmaxf(fmaxf(mx, fmaxf(s[qb][kj][0], s[qb][kj][1])), fmaxf(s[qb][kj][2], s[qb][kj][3]));
+        mx = quad_max(mx) * (SCALE * LOG2E);
+        float m_new = fmaxf(m[qb], mx);
+        const float m_ref = (MASK && m_new == -INFINITY) ? 0.f : m_new;   // (only a fully masked step with no history can be -inf)
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_ref);
+        float rs = 0.f;
+#pragma unroll
+        for (int kj = 0; kj < NKJ; ++kj) {
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP) dropout_keep4_even(drop_key, drow[qb] + (cb + kj) * 16 + 4 * g, drop_thr, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = __builtin_amdgcn_exp2f(s[qb][kj][r] * (SCALE * LOG2E) - m_ref);
+                rs += pr;
+                if constexpr (DROP) pr = keep[r] ? pr : 0.f;
+                s[qb][kj][r] = pr;
+            }
+        }
+        l[qb] = l[qb] * alpha + rs;
+        m[qb] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qb][dt] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < NKJ / 2; ++s2) pf[qb][s2] = pack_frag(s[qb][2 * s2], s[qb][2 * s2 + 1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int s2 = 0; s2 < NKJ / 2; ++s2) {
+            const bf16x8 vf = v2_tr_frag(v_lds, cb * 16 + 32 * s2, dt * 16, lane);
+#pragma unroll
+            for (int qb = 0; qb < CNT; ++qb) o[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][s2], o[qb][dt], 0, 0, 0);
+        }
+    }
+}
+
+// CNT query blocks against the resident keys of blocks [kb0, kb1) (kb0 even): unmasked 64-key steps while every key is valid, then
+// at most two masked ones.  FAST = false (the remainder phase): masked steps only, fewer instantiations.
+template <bool DROP, int CNT, bool FAST, int NA>
+__device__ __forceinline__ void v2_fwd_walk(const unsigned char* k_lds, const unsigned char* v_lds, const bf16x8 (&qf)[NA][2], int kb0, int kb1,
+                                            int Tk, const unsigned (&drow)[NA], unsigned drop_key, unsigned drop_thr, f32x4 (&o)[NA][4],
+                                            float (&m)[NA], float (&l)[NA], int lane) {
+    int cb = kb0;
+    if constexpr (FAST)
+        for (; cb + 4 <= kb1 && (cb + 4) * 16 <= Tk; cb += 4)
+            v2_fwd_step<DROP, CNT, 4, false, NA>(k_lds, v_lds, qf, cb, Tk, drow, drop_key, drop_thr, o, m, l, lane);
+    for (; cb + 2 < kb1; cb += 4) v2_fwd_step<DROP, CNT, 4, true, NA>(k_lds, v_lds, qf, cb, Tk, drow, drop_key, drop_thr, o, m, l, lane);
+    if (cb < kb1) v2_fwd_step<DROP, CNT, 2, true, NA>(k_lds, v_lds, qf, cb, Tk, drow, drop_key, drop_thr, o, m, l, lane);
+}
+
+template <bool DROP, int PER>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, bf16_t* __restrict__ O, long o_bs, int o_rs,
+                                                           float* __restrict__ lse, int H, int Tq, int Tk, unsigned drop_key,
+                                                           unsigned drop_thr, float drop_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * V2_MAXROWS * V2_RB];
+    unsigned char* k_lds = smem;
+    unsigned char* v_lds = smem + V2_MAXROWS * V2_RB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const bf16_t* qb_ = Q.p + (size_t)b * Q.bs + h * 64;
+    bf16_t* ob = O + (size_t)b * o_bs + h * 64;
+    const size_t stat_base = ((size_t)b * H + h) * Tq;
+    const int rows_pad = (Tk + 31) & ~31, nkb = (Tk + 15) >> 4;
+    const int nqb = (Tq + 15) >> 4, rem = nqb & 3;
+    constexpr int per = PER;                                             // == nqb >> 2 (the host picks the instantiation)
+    // this wave's query fragments travel while the workgroup stages K and V
+    bf16x8 qf[V2_NQB][2];
+    unsigned drow[V2_NQB];
+#pragma unroll
+    for (int qb = 0; qb < V2_NQB; ++qb) {
+        const int q0 = (w * per + qb) * 16;
+        if (qb < per) {
+            qf[qb][0] = global_row_frag(qb_, Q.rs, q0, Tq, 0, lane);
+            qf[qb][1] = global_row_frag(qb_, Q.rs, q0, Tq, 1, lane);
+        }
+        drow[qb] = (((unsigned)b * H + h) * Tq + min(q0 + li, Tq - 1)) * (unsigned)Tk;
+    }
+    v2_stage2(k_lds, v_lds, K.p + (size_t)b * K.bs + h * 64, K.rs, V.p + (size_t)b * V.bs + h * 64, V.rs, Tk, rows_pad, tid);
+    __syncthreads();
+    f32x4 o[V2_NQB][4];
+    float m[V2_NQB], l[V2_NQB];
+#pragma unroll
+    for (int qb = 0; qb < V2_NQB; ++qb) {
+        m[qb] = -INFINITY; l[qb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    v2_fwd_walk<DROP, PER, true, V2_NQB>(k_lds, v_lds, qf, 0, nkb, Tk, drow, drop_key, drop_thr, o, m, l, lane);
+#pragma unroll
+    for (int qb = 0; qb < V2_NQB; ++qb) {
+        if (qb >= per) continue;
+        const int qrow = (w * per + qb) * 16 + li;
+        const float lt = quad_sum(l[qb]);
+        const float inv = lt > 0.f ? (DROP ? drop_scale : 1.0f) / lt : 0.f;
+        if (qrow < Tq) {
+            bf16_t* op = ob + (size_t)qrow * o_rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = u32x2{pack_bf16x2(o[qb][dt][0] * inv, o[qb][dt][1] * inv),
+                                                                       pack_bf16x2(o[qb][dt][2] * inv, o[qb][dt][3] * inv)};
+            if (g == 0 && lse) lse[stat_base + qrow] = (m[qb] + log2f(lt)) * LN2;
+        }
+    }
+    if (rem == 0) return;                                               // workgroup-uniform
+    // ---- the remaining 1-3 query blocks: every wave runs them against its quarter of the keys, partials combined through LDS
+    bf16x8 rq[3][2];
+    unsigned rdrow[3];
+    f32x4 ro[3][4];
+    float rm[3], rl[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int q0 = (4 * per + r) * 16;
+        if (r < rem) {
+            rq[r][0] = global_row_frag(qb_, Q.rs, q0, Tq, 0, lane);
+            rq[r][1] = global_row_frag(qb_, Q.rs, q0, Tq, 1, lane);
+        }
+        rdrow[r] = (((unsigned)b * H + h) * Tq + min(q0 + li, Tq - 1)) * (unsigned)Tk;
+        rm[r] = -INFINITY; rl[r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ro[r][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int kq = 2 * ((nkb + 7) >> 3);       // quarters in units of 32 rows: the transposed V reads take 32-row groups from the step's base
+    {
+        const int k0 = min(w * kq, nkb), k1 = min((w + 1) * kq, nkb);
+        if (rem == 1) v2_fwd_walk<DROP, 1, false, 3>(k_lds, v_lds, rq, k0, k1, Tk, rdrow, drop_key, drop_thr, ro, rm, rl, lane);
+        else if (rem == 2) v2_fwd_walk<DROP, 2, false, 3>(k_lds, v_lds, rq, k0, k1, Tk, rdrow, drop_key, drop_thr, ro, rm, rl, lane);
+        else v2_fwd_walk<DROP, 3, false, 3>(k_lds, v_lds, rq, k0, k1, Tk, rdrow, drop_key, drop_thr, ro, rm, rl, lane);
+    }
+    __syncthreads();                                                    // every wave is done with K and V: the region becomes scratch
+    float* part = reinterpret_cast<float*>(smem);                       // [rem][4 waves][16 q x 64 d | m[16] | l[16]]
+    constexpr int PSZ = 16 * 64 + 32;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r >= rem) continue;
+        float* pp = part + (size_t)(r * 4 + w) * PSZ;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(pp + li * 64 + dt * 16 + 4 * g) = ro[r][dt];
+        const float lt = quad_sum(rl[r]);
+        if (g == 0) {
+            pp[1024 + li] = rm[r];
+            pp[1040 + li] = lt;
+        }
+    }
+    __syncthreads();
+    if (w < rem) {
+        const int r = w, qrow = (4 * per + r) * 16 + li;
+        float mw[4], M = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mw[u] = part[(size_t)(r * 4 + u) * PSZ + 1024 + li];
+            M = fmaxf(M, mw[u]);
+        }
+        const float Ms = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* pp = part + (size_t)(r * 4 + u) * PSZ;
+            const float f = __builtin_amdgcn_exp2f(mw[u] - Ms);
+            L += pp[1040 + li] * f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] += *reinterpret_cast<const f32x4*>(pp + li * 64 + dt * 16 + 4 * g) * f;
+        }
+        const float inv = L > 0.f ? (DROP ? drop_scale : 1.0f) / L : 0.f;
+        if (qrow < Tq) {
+            bf16_t* op = ob + (size_t)qrow * o_rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = u32x2{pack_bf16x2(acc[dt][0] * inv, acc[dt][1] * inv),
+                                                                       pack_bf16x2(acc[dt][2] * inv, acc[dt][3] * inv)};
+            if (g == 0 && lse) lse[stat_base + qrow] = (M + log2f(L)) * LN2;
+        }
+    }
+}
+
+// the resident-operand kernels cover dense, non-causal calls whose operands fit (the encoders); I2T_ATTN_V2=0 keeps the tiled ones
+bool v2_applies(int Tq, int Tk, int causal, const int* cu_q, const int* cu_k, unsigned drop_thr) {
+    const char* e = getenv("I2T_ATTN_V2");                               // read per call: tests switch it inside one process
+    const bool on = !(e && e[0] == '0');
+    // (with dropout the 4 consecutive keys of a lane must be the 4 bytes of one hash: Tk % 4 == 0)
+    return on && !causal && !cu_q && !cu_k && Tk <= V2_MAXROWS && Tq >= 64 && Tq <= V2_MAX_OTHER && (!drop_thr || (Tk & 3) == 0);
+}
+
 // variant of a kernel template <bool DROP, bool EVEN> for this call (EVEN = Tk % 4 == 0; only matters with dropout)
 #define ATTN_DISPATCH(KERNEL, drop_thr, Tk, ...)                                   \
     do {                                                                           \
@@ -553,6 +824,21 @@ extern "C" int i2t_attention_fwd(void* stream, const void* q, long q_bs, int q_r
     I2T_REQUIRE(!causal || Tk >= Tq, "i2t_attention_fwd: causal needs Tk >= Tq");
     I2T_REQUIRE((double)((Tq + 63) / 64) * H * B < 2147483647.0, "i2t_attention_fwd: grid too large");
     AttnPtr Q{(const bf16_t*)q, q_bs, q_rs}, K{(const bf16_t*)k, k_bs, k_rs}, V{(const bf16_t*)v, v_bs, v_rs};
+    if (v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr)) {
+#define V2_FWD(PER)                                                                                                                  \
+    case PER:                                                                                                                        \
+        if (!drop_thr) hipLaunchKernelGGL((attn_fwd2_kernel<false, PER>), dim3(H * B), dim3(256), 0, (hipStream_t)stream, Q, K, V,   \
+                                          (bf16_t*)o, o_bs, o_rs, lse, H, Tq, Tk, drop_key, drop_thr, drop_scale);                   \
+        else hipLaunchKernelGGL((attn_fwd2_kernel<true, PER>), dim3(H * B), dim3(256), 0, (hipStream_t)stream, Q, K, V,              \
+                                (bf16_t*)o, o_bs, o_rs, lse, H, Tq, Tk, drop_key, drop_thr, drop_scale);                             \
+        break;
+        switch (((Tq + 15) >> 4) >> 2) {
+            V2_FWD(1) V2_FWD(2) V2_FWD(3) V2_FWD(4)
+        }
+#undef V2_FWD
+        I2T_CHECK_LAUNCH("i2t_attention_fwd(v2)");
+        return I2T_OK;
+    }
     dim3 grid(((Tq + 63) / 64) * H * B);
     ATTN_DISPATCH(attn_fwd_kernel, drop_thr, Tk, grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, (bf16_t*)o, o_bs, o_rs, lse, H,
                   Tq, Tk, causal, drop_key, drop_thr, drop_scale, VarLen{cu_q, cu_k, total_q, B});

@@ -646,8 +646,15 @@ __device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)
             qf[s2] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
-    u32x4 qf[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-    if (Tq > 0) load_q(0, qf);
+    // ALL query blocks of the pair (<= 4 x 16 rows) are requested here, ahead of the K / V store phase: the K loop's fragment
+    // registers are dead by now, and the attention below then never waits on a global load (one block ahead was not enough: a
+    // block's math is ~600 cycles, a load under this kernel's own store traffic 1-2k -- 3.7 us per tile, r02 profile)
+    u32x4 qfa[4][2];
+#pragma unroll
+    for (int qb_ = 0; qb_ < 4; ++qb_) {
+        qfa[qb_][0] = qfa[qb_][1] = u32x4{0u, 0u, 0u, 0u};
+        if (16 * qb_ < Tq) load_q(qb_, qfa[qb_]);
+    }
     // ---- bias (in_proj_bias rows d + 64 h .. for K, 2 d + 64 h .. for V; p.bias points at the K part)
     {
         const float* bk = p.bias + h * 64;
@@ -700,9 +707,17 @@ __device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)
     constexpr float kScale = 0.125f * 1.4426950408889634f;             // 1 / sqrt(64) x log2(e)
     const bool drop = p.drop_thr != 0;
     const int nqb = (Tq + 15) >> 4;
-    for (int qblk = 0; qblk < nqb; ++qblk) {
-        const bf16x8 q0 = __builtin_bit_cast(bf16x8, qf[0]), q1 = __builtin_bit_cast(bf16x8, qf[1]);
-        if (qblk + 1 < nqb) load_q(qblk + 1, qf);                      // next block's queries travel during this block's math
+    for (int qg = 0; qg < nqb; qg += 4) {                              // groups of 4 query blocks (one group unless Tq > 64)
+    if (qg > 0) {
+#pragma unroll
+        for (int qb_ = 0; qb_ < 4; ++qb_)
+            if (16 * (qg + qb_) < Tq) load_q(qg + qb_, qfa[qb_]);
+    }
+#pragma unroll
+    for (int qb4 = 0; qb4 < 4; ++qb4) {
+        const int qblk = qg + qb4;
+        if (qblk >= nqb) break;                                         // wave-uniform
+        const bf16x8 q0 = __builtin_bit_cast(bf16x8, qfa[qb4][0]), q1 = __builtin_bit_cast(bf16x8, qfa[qb4][1]);
         const int qrow = 16 * qblk + li;
         f32x4 sc[4];
         float mx = -INFINITY;
@@ -745,6 +760,7 @@ __device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x2*>(op + 16 * i) = ob[i];
             if (g == 0 && p.xlse) p.xlse[stat + qrow] = (mx + log2f(l)) * 0.6931471805599453f;
         }
+    }
     }
 }
 

@@ -375,7 +375,9 @@ def ref_attention(q, k, v, causal):
 
 @pytest.mark.parametrize('B,H,Tq,Tk,causal,packed', [
     (2, 3, 64, 64, True, True), (2, 8, 260, 260, False, True), (3, 12, 128, 64, False, False), (2, 2, 37, 37, True, True),
-    (1, 4, 200, 200, True, True), (2, 2, 16, 16, True, True), (2, 1, 24, 24, False, True), (2, 2, 1, 50, True, False)])
+    (1, 4, 200, 200, True, True), (2, 2, 16, 16, True, True), (2, 1, 24, 24, False, True), (2, 2, 1, 50, True, False),
+    # the resident-operand (v2) kernels: ViT-B/16 rows, the encoder's CLS-only last block, their size limits, a single short block
+    (2, 12, 197, 197, False, True), (2, 2, 64, 260, False, False), (1, 2, 304, 288, False, False), (2, 1, 5, 9, False, False)])
 def test_attention_fwd_bwd(ops, B, H, Tq, Tk, causal, packed):
     d = 64 * H
     if packed:
@@ -825,7 +827,8 @@ def test_gemm_epilogue_dropout(ops):
 
 @pytest.mark.parametrize('B,H,Tq,Tk,causal', [(2, 2, 64, 64, True), (2, 3, 100, 40, False), (1, 2, 70, 37, False),
                                                 (2, 1, 33, 131, True),       # Tk % 4 != 0: the per-lane alignment variant
-                                                (2, 2, 260, 260, False), (1, 2, 200, 200, True)])   # 64 n + r rows: 5-wave tail workgroups
+                                                (2, 2, 260, 260, False), (1, 2, 200, 200, True),     # 64 n + r rows: 5-wave tail workgroups
+                                                (1, 3, 197, 197, False), (2, 2, 64, 260, False)])     # v2 kernels, odd / even key counts
 def test_attention_dropout_fwd_bwd(ops, B, H, Tq, Tk, causal):
     from image2text_amd import rng
     d = 64 * H
@@ -888,8 +891,11 @@ def test_fused_backward_dropout_outputs(ops):
     check('attention_bwd token multipliers', g1.view(B * T, 3, dd), ref, 1e-6, 1 / 128)
 
 
-def test_attention_packed_varlen(ops):
-    """Packed variable-length self-attention (causal) and packed-query cross-attention == per-sequence dense calls."""
+def test_attention_packed_varlen(ops, monkeypatch):
+    """Packed variable-length self-attention (causal) and packed-query cross-attention == per-sequence dense calls (bit for bit:
+    both sides on the tiled kernels -- a dense 64-row call would otherwise take the resident-operand kernels, whose summation
+    order differs)."""
+    monkeypatch.setenv('I2T_ATTN_V2', '0')
     H, d = 2, 128
     lens = [5, 64, 0, 37, 16]
     B, total, Tmax = len(lens), sum(lens), 64
