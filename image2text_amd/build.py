@@ -5,7 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libi2t_hip.so')
-SOURCES = ['abi.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip',
+SOURCES = ['abi.cpp', 'comm.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip',
            'attention_g.hip', 'family.hip', 'grouped.hip', 'llama.hip', 'lora.hip', 'vit.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 # per-file additions.  attention: keep MFMA accumulators in VGPRs -- the softmax rescales them every key tile, and the
@@ -54,7 +54,7 @@ def _build(verbose: bool, force_all: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {s}:\n{out.decode()}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-o', LIB] + objs + ['-ldl']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout.decode()}')

@@ -90,6 +90,12 @@ SIGNATURES = {
     'i2t_gemm_f32': [P, P, P, P, I, I, I],
     'i2t_lsh_embed_fwd': [P, P, P, L, P, P, P, P, P, P, I, I, I, I, I],
     'i2t_lsh_embed_bwd': [P, P, P, P, L, P, I, I, I, I, I],
+    'i2t_comm_available': [],
+    'i2t_comm_unique_id': [P, I],
+    'i2t_comm_init': [P, I, I, C.POINTER(C.c_void_p)],
+    'i2t_comm_allreduce': [P, P, P, L, I, P],
+    'i2t_comm_destroy': [P],
+    'i2t_workspace_bytes': [P, L, L, L, P],
     'i2t_graph_capture_begin': [P],
     'i2t_graph_capture_end': [P, C.POINTER(C.c_void_p)],
     'i2t_graph_launch': [P, P],

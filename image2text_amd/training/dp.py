@@ -8,8 +8,11 @@ local batch), then parameters see the MEAN over ranks of the per-shard gradients
 MI355X mapping: gradients live in ONE contiguous fp32 arena, so the exchange is two large collectives instead of
 DDP's 25 MB buckets: the decoder slice (80 % of the bytes) is reduced on RCCL's stream as soon as the decoder backward
 has finished, overlapped with the whole encoder backward; the encoder slice follows.  xGMI is point-to-point, large
-messages keep every link busy; RCCL picks the rings/trees.  ``torch.distributed`` (backend "nccl" = RCCL) is the
-transport; on CPU the same code runs over gloo (tests).
+messages keep every link busy; RCCL picks the rings/trees.  Transport: on the GPU the package's own RCCL communicator behind
+the C ABI (``i2t_comm_*``, csrc/comm.cpp; its unique id travels over the existing ``torch.distributed`` group, the collectives run
+on a side HIP stream; ``I2T_DP_COMM=torch`` keeps ``torch.distributed.all_reduce`` instead, ``I2T_DP_WIRE=bf16`` sends bf16); on CPU
+the same code runs over gloo (tests).  Frozen parameters (LoRA's base weights, a ``prepare_for_kbit_training`` decoder, a backbone
+run under no_grad) are not exchanged: the reduce ranges are the coalesced spans of trainable arena entries.
 
 Protocol (what a training loop does; ``training/utils.train_loop`` and ``bench.py`` follow it):
 
@@ -44,12 +47,76 @@ def configure_rccl_env():
         os.environ.setdefault('NCCL_MAX_NCHANNELS', str(RCCL_CUS))
 
 
+GAP_FLOATS = 1 << 18        # frozen gaps up to 1 MB between two trainable spans travel with them (cheaper than one more collective)
+
+
+class _Done:
+    """What ``dist.all_reduce(async_op=True)`` returns, for a collective issued on the communicator's side stream."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class RcclComm:
+    """The C-ABI communicator (include/i2t.h ``i2t_comm_*``): created collectively by all ranks of ``group``."""
+
+    def __init__(self, group, device):
+        import ctypes as C
+        from .. import lib as _l
+        self._l, self._lib = _l, _l.load()
+        if not self._lib.i2t_comm_available():
+            raise RuntimeError('RCCL is not available in this process')
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _l.check(self._lib.i2t_comm_unique_id(buf, 128), 'i2t_comm_unique_id')
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(device)
+        dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _l.check(self._lib.i2t_comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank, C.byref(handle)), 'i2t_comm_init')
+        self.handle, self.world, self.device = handle, world, device
+        self.stream = torch.cuda.Stream(device=device)
+        self.wire_bf16 = os.environ.get('I2T_DP_WIRE', 'f32') == 'bf16'
+        self._staging = None
+
+    def all_reduce_mean_async(self, t: torch.Tensor):
+        """Mean over ranks of the fp32 tensor ``t`` (contiguous view of the arena), in place, on the side stream."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        n = t.numel()
+        staging = None
+        if self.wire_bf16 and n % 4 == 0:
+            if self._staging is None or self._staging.numel() < n:
+                self._staging = torch.empty(n, dtype=torch.bfloat16, device=t.device)
+            staging = self._staging
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)                      # the gradients being sent are final on the compute stream
+        self._l.check(self._lib.i2t_comm_allreduce(self.handle, self.stream.cuda_stream, t.data_ptr(), n, 1,
+                                                   staging.data_ptr() if staging is not None else None), 'i2t_comm_allreduce')
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _Done(done)
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.i2t_comm_destroy(self.handle)
+            self.handle = None
+
+
 class DataParallelGrads:
     def __init__(self, model, group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group)
         self.overlap = overlap
+        self.comm = None                # RcclComm, created with the first exchange on a GPU arena (see _transport)
+        self._comm_tried = False
         self._pending = []              # (work, tensor view, needs division by world)
         self._reduced_upto = None       # arena offset from which the current window's gradients are already in flight/reduced
         self._reserved = False
@@ -87,8 +154,37 @@ class DataParallelGrads:
             raise RuntimeError('decoder parameters are not contiguous in the arena: the overlapped gradient exchange needs them to be')
         return lo, min(hi, arena.total)
 
+    def _transport(self, t: torch.Tensor):
+        """The package's RCCL communicator for GPU arenas under the nccl backend (created once, collectively: every rank reaches
+        its first exchange together); None = torch.distributed (gloo on CPU, I2T_DP_COMM=torch, or RCCL not bindable)."""
+        if not self._comm_tried:
+            self._comm_tried = True
+            if t.is_cuda and dist.get_backend(self.group) == 'nccl' and os.environ.get('I2T_DP_COMM', 'rccl') != 'torch':
+                try:
+                    self.comm = RcclComm(self.group, t.device)
+                except Exception as e:      # (every rank fails alike: the library is the same on all of them)
+                    import warnings
+                    warnings.warn(f'image2text_amd: C-ABI RCCL communicator unavailable ({e}); using torch.distributed.all_reduce')
+        return self.comm
+
+    def _spans(self, arena, lo: int, hi: int):
+        """Coalesced [a, b) ranges of TRAINABLE arena entries inside [lo, hi): frozen parameters have no gradient to exchange."""
+        spans = []
+        for name, (off, n, _) in sorted(arena.entries.items(), key=lambda kv: kv[1][0]):
+            a, b = max(off, lo), min(off + ((n + 7) // 8) * 8, hi, arena.total)
+            if b <= a or name not in arena.params or not arena.trainable(name):
+                continue
+            if spans and a - spans[-1][1] <= GAP_FLOATS:
+                spans[-1][1] = b
+            else:
+                spans.append([a, b])
+        return [(a, b) for a, b in spans]
+
     def _reduce(self, t: torch.Tensor, async_op: bool):
         backend = dist.get_backend(self.group)
+        comm = self._transport(t)
+        if comm is not None:
+            return comm.all_reduce_mean_async(t), False
         if backend == 'nccl':
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
@@ -122,16 +218,17 @@ class DataParallelGrads:
             from .. import ops
             ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
             self._reserved = True
-        work, need_div = self._reduce(arena.g32[lo:hi], async_op=True)
-        self._pending.append((work, arena.g32[lo:hi], need_div))
+        for a, b in self._spans(arena, lo, hi):
+            work, need_div = self._reduce(arena.g32[a:b], async_op=True)
+            self._pending.append((work, arena.g32[a:b], need_div))
         self._reduced_upto = (lo, hi)
 
     def all_reduce_mean(self):
         """Finish the exchange: after this every rank holds mean-over-ranks gradients in its arena / p.grad."""
         arena = self._arena()
         lo, hi = self._reduced_upto if self._reduced_upto is not None else (0, 0)
-        for a, b in ((0, lo), (hi, arena.total)):        # everything the 'decoder' hook has not already put on the wire
-            if b > a:
+        for a0, b0 in ((0, lo), (hi, arena.total)):      # everything the 'decoder' hook has not already put on the wire
+            for a, b in self._spans(arena, a0, b0):
                 work, need_div = self._reduce(arena.g32[a:b], async_op=True)
                 self._pending.append((work, arena.g32[a:b], need_div))
         self._drain()

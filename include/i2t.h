@@ -482,6 +482,23 @@ int i2t_lsh_embed_fwd(void* stream, const float* z, const float* tables, long sl
 int i2t_lsh_embed_bwd(void* stream, const float* dy, const int* rows, float* g_tables, long slot_stride, const long* tab_off, int B,
                       int n_cls, int nK, int n_proj, int dout);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (replaces accelerate's DDP wrap, reference trainer.py:108-114,173-174):
+ * one RCCL communicator per process (one process per GPU), all-reduce of the flat fp32 gradient arena in place over xGMI.
+ * RCCL is bound at run time (the copy torch already loaded, else librccl.so.1); i2t_comm_available() = 0 means none was found.
+ *   i2t_comm_unique_id: rank 0 fills a 128-byte id, the caller ships it to the other ranks (any out-of-band channel)
+ *   i2t_comm_init: collective over all ranks (current HIP device of the calling thread); *comm_out = opaque handle
+ *   i2t_comm_allreduce: buf[count] fp32 <- sum (mean != 0: mean) over ranks, asynchronous on `stream`; bf16_staging non-null
+ *     (count bf16 elements, count % 4 == 0): the values travel as bf16 (half the bytes, one extra rounding per element)
+ *   i2t_workspace_bytes: *bytes_out = scratch bytes the named entry point needs for a problem (M, N, K); 0 = none
+ * --------------------------------------------------------------------------------------------------------- */
+int i2t_comm_available(void);
+int i2t_comm_unique_id(void* id_out, int bytes);
+int i2t_comm_init(const void* id, int world, int rank, void** comm_out);
+int i2t_comm_allreduce(void* comm, void* stream, float* buf, long count, int mean, void* bf16_staging);
+int i2t_comm_destroy(void* comm);
+int i2t_workspace_bytes(const char* entry, long M, long N, long K, long* bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

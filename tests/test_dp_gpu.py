@@ -25,3 +25,4 @@ def test_one_rank_rccl_hooked_exchange_matches_unhooked(model):
     out = r.stdout.decode(errors='replace')
     assert r.returncode == 0 and 'DP_SELFCHECK_OK' in out, out[-4000:]
     assert 'nchannels=16' in out or os.environ.get('I2T_RCCL_CUS'), out[-500:]
+    assert 'transport=rccl-abi' in out, out[-800:]        # the exchange ran on the C-ABI communicator (include/i2t.h i2t_comm_*)

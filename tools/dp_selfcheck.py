@@ -132,7 +132,24 @@ def main():
         worst = sorted(((float((acc1[o:o + n] - acc0[o:o + n]).abs().max()), name) for name, (o, n, _) in eng.arena.entries.items()), reverse=True)[:6]
         print('DP_SELFCHECK accumulation mismatch, worst entries:', worst, 'max |g| =', float(acc0.abs().max()), flush=True)
     assert err2 <= max(4 * floor, TOL), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
+    # transport: the package's own RCCL communicator behind the C ABI (i2t_comm_*), fp32 on the wire; its bf16 wire form rounds once
+    assert dp1.comm is not None, 'the C-ABI RCCL communicator was not created (torch.distributed fallback in use)'
+    t = torch.randn(1 << 16, device=dev)
+    want32, want16 = t.clone(), t.bfloat16().float()
+    dp1.comm.all_reduce_mean_async(t).wait()
     torch.cuda.synchronize()
+    assert torch.equal(t, want32), 'fp32 wire: a 1-rank mean must be the identity'
+    dp1.comm.wire_bf16 = True
+    dp1.comm.all_reduce_mean_async(t).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(t, want16), 'bf16 wire: a 1-rank mean must be the bf16 rounding'
+    dp1.comm.wire_bf16 = False
+    spans = dp1._spans(eng.arena, 0, eng.arena.total)
+    frozen = sum(n for name, (o, n, _) in eng.arena.entries.items() if name in eng.arena.params and not eng.arena.trainable(name))
+    sent = sum(b - a for a, b in spans)
+    assert sent <= eng.arena.total and (frozen == 0 or sent < eng.arena.total), (sent, frozen, eng.arena.total)
+    torch.cuda.synchronize()
+    print(f'DP_SELFCHECK transport=rccl-abi spans={len(spans)} floats_sent={sent} of {eng.arena.total} (frozen {frozen})', flush=True)
     print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
     dist.destroy_process_group()
 
