@@ -84,3 +84,53 @@ def test_momentum_twin_draws_its_own_dropout_masks():
                 assert a[1] != b[1], kind                                   # different site keys ...
                 ma, mb = rng.keep_mask(a[1], 4096, a[2]), rng.keep_mask(b[1], 4096, b[2])
                 assert 0.02 < float((ma != mb).float().mean()) < 0.5, kind   # ... and masks that differ like independent draws (2 p (1 - p) = 0.18)
+
+
+def test_train_loop_under_a_real_accelerate_accelerator():
+    """SURVEY 8 a15 with the caller the reference actually uses: a single-process ``accelerate.Accelerator`` built as trainer.py:108-114
+    builds it (bf16 mixed precision, gradient accumulation 2), the wrapper and a torch AdamW passed through ``accelerator.prepare``
+    (trainer.py:173-174), then ``train_loop`` / ``val_loop``.  Under ``accelerator.autocast()`` the HIP path is unchanged (it computes
+    in bf16 with fp32 accumulation whatever torch's autocast state): the three optimizer steps equal the same steps written by hand."""
+    from accelerate import Accelerator
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.utils import train_loop, val_loop
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    batches = [synthetic_batch(4, 32, 16, V, seed=70 + i) for i in range(6)]
+
+    def build():
+        w = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100).to(dev())
+        det_init_(w.model, seed=0)
+        return w, torch.optim.AdamW(w.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
+
+    w0, o0 = build()
+    w0.train()
+    for i in range(0, 6, 2):
+        for im, lb in batches[i:i + 2]:
+            (w0.train_step(im.to(dev()), lb.to(dev()))[0] / 2).backward()
+        o0.step()
+        o0.zero_grad()
+    accelerator = Accelerator(device_placement=True, split_batches=True, mixed_precision='bf16', gradient_accumulation_steps=2)
+    w1, o1 = build()
+    w1, o1 = accelerator.prepare(w1, o1, device_placement=[False, True])
+    seen = []
+    stop = train_loop(w1, o1, iter(batches), epoch=0, num_steps=6, accelerator=accelerator, disable_flash=True,
+                      logging_callback=lambda m, batch, epoch: seen.append((batch, m['train_loss_lm'])), chckpt_fname=None)
+    assert stop is False and [b for b, _ in seen] == list(range(6)) and all(np.isfinite(v) for _, v in seen)
+    inner = accelerator.unwrap_model(w1)
+    worst = 0.0
+    for (n, p0), (_, p1) in zip(w0.model.named_parameters(), inner.model.named_parameters()):
+        diff = (p0 - p1).abs()
+        tol = 2e-5 * max(1.0, float(p0.abs().max()))
+        # (Adam turns the sign of a gradient that is zero up to atomics jitter into a full +-lr step: see the fake-accelerator
+        # twin of this test, tests/test_round2_gpu.py, for the same two allowances)
+        frac_ok = 0.4 if n.endswith(('.attn.c_attn.bias', '.cross_attn.in_proj_bias')) else 5e-3
+        assert float((diff > tol).float().mean()) <= frac_ok and float(diff.max()) <= 3.2e-3, (n, float(diff.max()))
+        worst = max(worst, float(diff.max()))
+    vloss, _ = val_loop(w1, iter(batches), 0, 3, accelerator)
+    inner.eval()
+    with torch.no_grad():
+        ref = np.mean([float(inner.val_step(im.to(dev()), lb.to(dev()))[0]) for im, lb in batches[:3]])
+    assert abs(float(vloss) - ref) <= 1e-4 * max(1.0, abs(ref))
+    REPORT['accelerate.train_loop'] = {'max_param_diff_vs_hand_written_steps': worst, 'val_loss': float(vloss)}
