@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void snradam_kernel(float* __restrict__ p, con
             if (seg_end[mid] > e0) hi = mid; else lo = mid + 1;
         }
         const float lr = seg_lr[lo], wd = seg_wd[lo];
-        if (lr < 0.f || (lr == 0.f && wd == 0.f)) continue;      // frozen / outside every group (lr = -1): no state, no update (as the reference)
+        if (lr < 0.f) continue;      // frozen / outside every group (lr = -1): no state, no update.  lr == 0 (a warm-up from 0) still tracks the
+                                     // moments, as the reference's SNRAdam does (models/optimizer.py:98-108: exp_avg / exp_avg_sq / iter_ advance at any lr)
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
         f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll

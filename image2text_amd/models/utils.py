@@ -57,7 +57,11 @@ class PatternMatcher:
 def update_state_dict_from_partial_checkpoint(model: nn.Module, chkpt_path: str, map_location=None) -> nn.Module:
     """Overlay a (possibly partial) checkpoint keyed by state-dict names (reference utils.py:31-36)."""
     merged = model.state_dict()
-    with open(chkpt_path, 'rb') as fh:
+    try:                                          # the same opener the checkpoint was written with (training/utils.save_checkpoint):
+        from smart_open import open as _open      # local paths and URLs; absent from the image -> plain files
+    except ImportError:
+        _open = open
+    with _open(chkpt_path, 'rb') as fh:
         merged.update(torch.load(fh, map_location=map_location))
     model.load_state_dict(merged)
     return model

@@ -47,6 +47,52 @@ class _ArenaOptimizer(torch.optim.Optimizer):
                                'forward/backward of the VisionEncoderDecoder on the GPU first (there is no per-tensor CPU path)')
         return arena
 
+    def _frozen_signature(self):
+        return tuple(p.requires_grad for g in self.param_groups for p in g['params'])
+
+    def _refresh_hyper(self, arena, hyper):
+        lrs, wds = self._seg_host
+        for (lr, wd), g in zip(hyper, self.param_groups):
+            for p in g['params']:
+                i = self._seg_of.get(p.data_ptr())
+                if i is not None and lrs[i] >= 0.0:
+                    lrs[i], wds[i] = lr, wd
+        ends, dl, dw, n, _ = self._tables
+        dl.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=True)
+        dw.copy_(torch.tensor(wds, dtype=torch.float32), non_blocking=True)
+        self._tables = (ends, dl, dw, n, hyper)
+
+    def state_dict(self):
+        """torch's layout plus the flat moments: ``state`` maps an arena entry name to its (exp_avg, exp_avg_sq) slices, ``step`` is
+        the launch-wide step count -- so ``accelerator.save_state`` / a resumed run keep the moments and the bias correction."""
+        sd = super().state_dict()
+        sd['i2t_step'] = self._step
+        if self._arena is not None:
+            a = self._arena
+            sd['i2t_moments'] = {name: (self._m[o:o + n].detach().clone(), self._v[o:o + n].detach().clone())
+                                 for name, (o, n, _) in a.entries.items() if name in a.params}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        self._step = int(state_dict.pop('i2t_step', 0))
+        self._pending_moments = state_dict.pop('i2t_moments', None)        # applied once the arena exists (first step)
+        super().load_state_dict(state_dict)
+        self._tables = None
+        if self._arena is not None:
+            self._apply_pending_moments(self._arena)
+
+    def _apply_pending_moments(self, arena):
+        pm = getattr(self, '_pending_moments', None)
+        if not pm:
+            return
+        for name, (m, v) in pm.items():
+            e = arena.entries.get(name)
+            if e is not None and e[1] == m.numel():
+                self._m[e[0]:e[0] + e[1]].copy_(m)
+                self._v[e[0]:e[0] + e[1]].copy_(v)
+        self._pending_moments = None
+
     def _build(self, arena):
         by_ptr = {}
         # parameters no backward ever writes (a backbone run under no_grad: their .grad stays None and torch's optimizers skip them)
@@ -75,6 +121,10 @@ class _ArenaOptimizer(torch.optim.Optimizer):
             self._m = torch.zeros_like(arena.p32)
             self._v = torch.zeros_like(arena.p32)
         self._arena = arena
+        self._seg_host = (list(lrs), list(wds))
+        self._seg_of = {arena.p32.data_ptr() + 4 * off: i for i, (name, (off, n, _)) in enumerate(items)}
+        self._frozen_sig = self._frozen_signature()
+        self._apply_pending_moments(arena)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -83,9 +133,11 @@ class _ArenaOptimizer(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         arena = self._find_arena()
-        if self._tables is None or self._arena is not arena or \
-                self._tables[4] != tuple((g['lr'], g['weight_decay']) for g in self.param_groups):      # lr schedulers edit the groups
+        hyper = tuple((g['lr'], g['weight_decay']) for g in self.param_groups)
+        if self._tables is None or self._arena is not arena or self._frozen_sig != self._frozen_signature():
             self._build(arena)
+        elif self._tables[4] != hyper:                                   # an lr scheduler edited the groups: same segments, new values --
+            self._refresh_hyper(arena, hyper)                            # two small in-place uploads instead of rebuilding three tables
         missing = [n for n, p in self._params if p.requires_grad and p.grad is None and p.data_ptr() not in self._skipped]
         if missing:
             raise RuntimeError(f'{type(self).__name__}.step: {len(missing)} parameters have no gradient (first: {missing[0]}); the '

@@ -180,7 +180,7 @@ def _contrastive_forward(wrapper, eng, enc_out, mem, hid, labels, B, T, ncls, vl
     keep = lab_c != wrapper.ignore_index
     ids0 = torch.where(keep, lab_c, torch.zeros_like(lab_c))
     E = torch.empty(N, d, dtype=F32, device=dev)
-    ops.embed_fwd(ids0, a.P(f'{eng.dp}transformer.wte.weight'), None, E, N, 1, d, 0, eng.dec.V)
+    ops.embed_fwd(ids0, a.P(eng.n_wte), None, E, N, 1, d, 0, eng.dec.V)
     Eb = torch.empty(N, d, dtype=BF16, device=dev)
     ops.cast_f32_bf16(E, Eb)
     Np = (N + 7) // 8 * 8
@@ -209,7 +209,7 @@ def _contrastive_backward(wrapper, eng, con, g_c, M):
     ops.gemm(con.P, con.Eb, dH, N, d, N, b_kmajor=True)
     dE = torch.zeros(N, d, dtype=F32, device=dev)
     ops.gemm(con.P, con.Hb, dE, N, d, N, a_kmajor=True, b_kmajor=True, accumulate=True)
-    ops.embed_bwd(con.ids0, dE, a.G(f'{eng.dp}transformer.wte.weight'), None, N, 1, d, 0, eng.dec.V)
+    ops.embed_bwd(con.ids0, dE, a.G(eng.n_wte), None, N, 1, d, 0, eng.dec.V)
     src, dst, psrc, pdst = con.rows
     tmp = torch.empty(max(src.numel(), psrc.numel(), 1), d, dtype=F32, device=dev)
     dhid = torch.zeros(M, d, dtype=F32, device=dev)

@@ -274,7 +274,7 @@ int i2t_adamw_step(void* stream, float* p, const float* g, float* m, float* v, v
                    const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                    float beta1, float beta2, float eps, int step, float grad_scale);
 /* SNRAdam (reference models/optimizer.py:56-113; trainer.py:169 `use_snr_optim`): Adam with the gradient's running VARIANCE
- * in the denominator.  Same contract as i2t_adamw_step (frozen segments: lr < 0); segments with lr == 0 and wd == 0 are left untouched too (no state). */
+ * in the denominator.  Same contract as i2t_adamw_step (frozen segments: lr < 0); a segment at lr == 0 (warm-up from 0) still advances its moments, as the reference does. */
 int i2t_snradam_step(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                      const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                      float beta1, float beta2, float eps, int step, float grad_scale);

@@ -134,3 +134,61 @@ def test_train_loop_under_a_real_accelerate_accelerator():
         ref = np.mean([float(inner.val_step(im.to(dev()), lb.to(dev()))[0]) for im, lb in batches[:3]])
     assert abs(float(vloss) - ref) <= 1e-4 * max(1.0, abs(ref))
     REPORT['accelerate.train_loop'] = {'max_param_diff_vs_hand_written_steps': worst, 'val_loss': float(vloss)}
+
+
+def test_fused_optimizer_state_round_trip_scheduler_and_zero_lr():
+    """the fused optimizers' moments and step count travel through state_dict / load_state_dict (a resumed run continues
+    exactly), an lr scheduler's edits reach the device tables in place, and SNRAdam at lr = 0 still advances its moments (reference
+    models/optimizer.py:98-108: a warm-up from 0 must not stall exp_avg / exp_avg_sq)."""
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.training.optim import FusedAdamW, SNRAdam
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    cfg = tiny_config()
+    V = cfg.decoder_config.vocab_size
+    batches = [synthetic_batch(4, 32, 16, V, seed=90 + i) for i in range(4)]
+
+    def build(opt_cls, **kw):
+        w = ModelTrainerWrapper(cfg, fake_tokenizer(V), TrainerWrapperConfig(), ignore_index=-100).to(dev()).train()
+        det_init_(w.model, seed=0)
+        return w, opt_cls(w.model.parameters(), **kw)
+
+    def step(w, o, i):
+        w.train_step(batches[i][0].to(dev()), batches[i][1].to(dev()))[0].backward()
+        o.step()
+        o.zero_grad()
+
+    # (a) resume: 4 steps straight == 2 steps, state_dict round trip into a fresh optimizer, 2 more steps
+    wa, oa = build(FusedAdamW, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(oa, lambda s: 1.0 / (1 + s))
+    for i in range(4):
+        step(wa, oa, i)
+        sched.step()
+    wb, ob = build(FusedAdamW, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    sb = torch.optim.lr_scheduler.LambdaLR(ob, lambda s: 1.0 / (1 + s))
+    for i in range(2):
+        step(wb, ob, i)
+        sb.step()
+    state = ob.state_dict()
+    assert state['i2t_step'] == 2 and len(state['i2t_moments']) >= 50
+    wc, oc = build(FusedAdamW, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    wc.model.load_state_dict(wb.model.state_dict())
+    oc.load_state_dict(state)
+    sc = torch.optim.lr_scheduler.LambdaLR(oc, lambda s: 1.0 / (1 + s), last_epoch=1)
+    for i in range(2, 4):
+        step(wc, oc, i)
+        sc.step()
+    worst = max(float((pa - pc).abs().max()) for pa, pc in zip(wa.model.parameters(), wc.model.parameters()))
+    REPORT['optimizer.resume_max_param_diff'] = worst
+    assert worst <= 3.2e-3            # (sign flips of zero-up-to-jitter gradients: +-lr per step, see the train-loop tests)
+    frac = np.mean([float(((pa - pc).abs() > 2e-5).float().mean()) for pa, pc in zip(wa.model.parameters(), wc.model.parameters())])
+    assert frac <= 5e-3
+    # (b) SNRAdam at lr = 0: parameters stay, moments move
+    ws, os_ = build(SNRAdam, lr=1e-3, betas=(0.9, 0.95))
+    step(ws, os_, 0)
+    before = [p.detach().clone() for p in ws.model.parameters()]
+    for g in os_.param_groups:
+        g['lr'] = 0.0
+    m0 = os_._m.clone()
+    step(ws, os_, 1)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, ws.model.parameters()))
+    assert float((os_._m - m0).abs().max()) > 0.0
