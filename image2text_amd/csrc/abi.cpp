@@ -1,6 +1,7 @@
 // C-ABI plumbing that is not a kernel: version, per-thread error text, hipGraph capture/replay.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,6 +13,20 @@ void i2t_set_error(const char* fmt, ...) {
 }
 
 extern "C" int i2t_abi_version(void) { return I2T_ABI_VERSION; }
+
+static int g_det = -1;                       // -1: not decided yet -> the environment decides at the first query
+bool i2t_det() {
+    if (g_det < 0) {
+        const char* e = getenv("I2T_DETERMINISTIC");
+        g_det = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_det != 0;
+}
+extern "C" int i2t_set_deterministic(int on) {
+    g_det = on ? 1 : 0;
+    return I2T_OK;
+}
+extern "C" int i2t_deterministic(void) { return i2t_det() ? 1 : 0; }
 
 extern "C" int i2t_last_error(char* buf, size_t n) {
     if (buf && n) {

@@ -34,6 +34,11 @@ void i2t_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 #define ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+// Deterministic mode (i2t_set_deterministic / I2T_DETERMINISTIC=1): every reduction on the gradient path that normally combines
+// workgroup partials with fp32 atomics (order-dependent in the last bit) runs in ONE fixed order instead -- a single workgroup for
+// the grid-stride reductions, one K slice for the dW GEMMs, one launch per tile for the convolution weight gradients.  Slow, bit-
+// reproducible: two backward passes of the same step are bit-equal (tests/test_round3_gpu.py).
+bool i2t_det();
 
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const void* __restrict
 template <int COUT, int K, bool IN_F32, bool IN_GELU>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ xin,
                                                               float* __restrict__ dw, float* __restrict__ db, int Cin,
-                                                              int H, int W, int pad_before) {
+                                                              int H, int W, int pad_before, int bx0, int by0, int bz0) {
     constexpr int PW = TILE + K - 1;
     __shared__ float patch[CI_CHUNK][PW][PW + 1];
     __shared__ __attribute__((aligned(16))) float dyt[TILE * TILE][COUT];   // channel-fastest: 4 channels per LDS broadcast read
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE, b = blockIdx.z;
+    const int x0 = (blockIdx.x + bx0) * TILE, y0 = (blockIdx.y + by0) * TILE, b = blockIdx.z + bz0;      // (offsets: deterministic mode)
     const size_t plane = (size_t)H * W;
     const int taps_per_chunk = CI_CHUNK * K * K;             // 144 for k=6
     // stage dY tile (all COUT channels) once
@@ -246,14 +246,14 @@ extern "C" int i2t_conv_bwd_data(void* stream, const void* dy, const float* w, c
 #define BWD_W_CASE(CO, KK)                                                                                              \
     if (Cout == CO && k == KK) {                                                                                        \
         if (in_is_f32 && !in_gelu)                                                                                      \
-            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, true, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
-                               db, Cin, H, W, pad);                                                                     \
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, true, false>), g1, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
+                               db, Cin, H, W, pad, bx, by, bz);                                                         \
         else if (!in_is_f32 && in_gelu)                                                                                 \
-            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, false, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
-                               db, Cin, H, W, pad);                                                                     \
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, false, true>), g1, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
+                               db, Cin, H, W, pad, bx, by, bz);                                                         \
         else                                                                                                            \
-            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, false, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
-                               db, Cin, H, W, pad);                                                                     \
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<CO, KK, false, false>), g1, dim3(256), 0, s, (const bf16_t*)dy, x, dw, \
+                               db, Cin, H, W, pad, bx, by, bz);                                                         \
         launched = true;                                                                                                \
     }
 
@@ -265,8 +265,15 @@ extern "C" int i2t_conv_bwd_weight(void* stream, const void* dy, const void* x, 
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     const int pad = (k - 1) / 2;
     bool launched = false;
-    BWD_W_CASE(4, 6) BWD_W_CASE(8, 6) BWD_W_CASE(16, 6) BWD_W_CASE(32, 6)
-    BWD_W_CASE(4, 4) BWD_W_CASE(8, 4) BWD_W_CASE(16, 4) BWD_W_CASE(32, 4)
+    // deterministic mode: the workgroups' atomics onto dw / db land in (image, tile row, tile column) order -- one launch each
+    const bool det = i2t_det();
+    const dim3 g1 = det ? dim3(1, 1, 1) : grid;
+    for (int bz = 0; bz < (det ? (int)grid.z : 1); ++bz)
+        for (int by = 0; by < (det ? (int)grid.y : 1); ++by)
+            for (int bx = 0; bx < (det ? (int)grid.x : 1); ++bx) {
+                BWD_W_CASE(4, 6) BWD_W_CASE(8, 6) BWD_W_CASE(16, 6) BWD_W_CASE(32, 6)
+                BWD_W_CASE(4, 4) BWD_W_CASE(8, 4) BWD_W_CASE(16, 4) BWD_W_CASE(32, 4)
+            }
     I2T_REQUIRE(launched, "i2t_conv_bwd_weight: Cout=%d k=%d unsupported (Cout in {4,8,16,32}, k in {4,6})", Cout, k);
     I2T_CHECK_LAUNCH("i2t_conv_bwd_weight");
     return I2T_OK;

@@ -283,24 +283,24 @@ template <int CP, int COP, int DY_SRC, int ACT_SRC, bool ACT_GELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_mfma_bwd_weight_kernel(const void* __restrict__ dy, const void* __restrict__ act,
                                                                    float* __restrict__ scratch, float* __restrict__ db,
                                                                    int Cin, int Cout, int H, int W, int pad_before,
-                                                                   int tiles_x) {
+                                                                   int tiles_x, int by0, int bz0) {
     constexpr int NT = COP / 16;                              // co tiles
     constexpr int NN = (CP == 16) ? NTAP : NTAP / 2;           // n-tiles of 16 (tap x ci) columns
     constexpr int NPW = (NN + 3) / 4;                          // n-tiles per wave
     __shared__ __attribute__((aligned(16))) bf16_t dl[TS * TS * COP];     // dY tile  [pixel][co]
     __shared__ __attribute__((aligned(16))) bf16_t pl[PW * PW * CP];      // act patch [py][px][ci]
-    __shared__ float dbs[COP];
+    __shared__ float dbs[4][COP];                             // per-wave bias partials, summed in wave order (no LDS atomics: fixed order)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int q = li >> 2, p = li & 3;
-    const int b = blockIdx.y, ty = blockIdx.x;               // one workgroup sweeps the tile row ty of image b
+    const int b = blockIdx.y + bz0, ty = blockIdx.x + by0;   // one workgroup sweeps the tile row ty of image b (offsets: deterministic mode)
     const int y0 = ty * TS;
     f32x4 acc[NPW][NT];
 #pragma unroll
     for (int n = 0; n < NPW; ++n)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < COP) dbs[tid] = 0.f;
+    if (tid < COP) dbs[0][tid] = dbs[1][tid] = dbs[2][tid] = dbs[3][tid] = 0.f;
     float dbp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) dbp[t] = 0.f;
@@ -400,11 +400,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             float v = dbp[t];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (g == 0) atomicAdd(&dbs[16 * t + li], v);      // LDS: 4 waves x NT x 16 adds per workgroup
+            if (g == 0) dbs[w][16 * t + li] = v;               // this wave's slot
         }
     }
     __syncthreads();
-    if (db && tid < Cout) atomicAdd(db + tid, dbs[tid]);
+    if (db && tid < Cout) atomicAdd(db + tid, (dbs[0][tid] + dbs[1][tid]) + (dbs[2][tid] + dbs[3][tid]));
 }
 
 // dw[co][ci][ky][kx] += scratch[co][tap][ci]
@@ -556,8 +556,10 @@ extern "C" int i2t_conv6_bwd_data(void* stream, const void* dy, int dy_layout, c
 }
 
 #define LAUNCH_BW(CP_, COP_, DS_, AS_, G_)                                                                              \
-    hipLaunchKernelGGL((conv_mfma_bwd_weight_kernel<CP_, COP_, DS_, AS_, G_>), grid, dim3(256), 0, s, dy, x, scratch, db, \
-                       Cin, Cout, H, W, (KS - 1) / 2, tiles_x)
+    for (int bz = 0; bz < (det ? B : 1); ++bz)                                                                         \
+        for (int by = 0; by < (det ? tiles_y : 1); ++by)                                                               \
+            hipLaunchKernelGGL((conv_mfma_bwd_weight_kernel<CP_, COP_, DS_, AS_, G_>), (det ? dim3(1, 1) : grid), dim3(256), 0, s, dy, x, \
+                               scratch, db, Cin, Cout, H, W, (KS - 1) / 2, tiles_x, by, bz)
 
 extern "C" int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout, const void* x, int x_layout, int in_gelu,
                                     float* dw, float* db, float* scratch, int B, int Cin, int Cout, int H, int W) {
@@ -568,6 +570,7 @@ extern "C" int i2t_conv6_bwd_weight(void* stream, const void* dy, int dy_layout,
     if (e != hipSuccess) { i2t_set_error("i2t_conv6_bwd_weight: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     dim3 grid(tiles_y, B);
+    const bool det = i2t_det();      // deterministic mode: the scratch / db atomics land in (image, tile row) order, one launch each
     bool ok = true;
     if (x_layout == SRC_NCHW_F32 && !in_gelu && cp == 8) {
         if (dy_layout == SRC_NHWC_BF16 && cop == 16) LAUNCH_BW(8, 16, SRC_NHWC_BF16, SRC_NCHW_F32, false);

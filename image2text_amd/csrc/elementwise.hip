@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int64_t* __res
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const float* g = dx + (size_t)row * d;
         float* o = dwte + (size_t)id * d;
-        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);   // 256 contiguous bytes per wave-instr
+        if (gridDim.x == 1) {      // one workgroup walks every row in order (deterministic mode): a column has ONE owner thread -> plain adds
+            for (int c = threadIdx.x; c < d; c += 256) o[c] += g[c];
+        } else {
+            for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);   // 256 contiguous bytes per wave-instr
+        }
     }
 }
 
@@ -74,6 +78,7 @@ static void launch_sum_over_batch(hipStream_t s, const float* x, long x_bs, floa
     const int col_blocks = (int)((items + 255) / 256);
     int slices = 1;
     while (slices < 32 && col_blocks * slices < 1024 && B / (slices * 2) >= 32) slices *= 2;
+    if (i2t_det()) slices = 1;                  // one slice: plain adds in batch order
     if (slices > 1 && !accumulate) (void)hipMemsetAsync(dst, 0, (size_t)rows * d * sizeof(float), s);
     hipLaunchKernelGGL(sum_over_batch_kernel, dim3(col_blocks, slices), dim3(256), 0, s, x, x_bs, dst, B, rows, d, accumulate);
 }
@@ -483,7 +488,11 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_packed_kernel(const int* __
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const float* g = dx + (size_t)row * d;
         float* o = dwpe + (size_t)(pos[row] + pos_offset) * d;
-        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);
+        if (gridDim.x == 1) {      // (as embed_bwd_wte_kernel)
+            for (int c = threadIdx.x; c < d; c += 256) o[c] += g[c];
+        } else {
+            for (int c = threadIdx.x; c < d; c += 256) atomicAdd(o + c, g[c]);
+        }
     }
 }
 
@@ -499,13 +508,13 @@ extern "C" int i2t_embed_fwd(void* stream, const int64_t* ids, const float* wte,
 
 extern "C" int i2t_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dwte, float* dwpe, int B, int T,
                              int d, int pos_offset, int vocab, const int* pos) {
-    I2T_REQUIRE(ids && dx && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_bwd: bad args");
+    I2T_REQUIRE((ids || !dwte) && dx && B > 0 && T > 0 && d % 4 == 0, "i2t_embed_bwd: bad args");
     const int rows = B * T;
     hipStream_t s = (hipStream_t)stream;
     if (dwte)
-        hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, ids, dx, dwte, d, vocab, rows);
+        hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(i2t_det() ? 1 : (rows < 4096 ? rows : 4096)), dim3(256), 0, s, ids, dx, dwte, d, vocab, rows);      // (deterministic: ONE workgroup walks the rows in order)
     if (dwpe && pos) {
-        hipLaunchKernelGGL(embed_bwd_wpe_packed_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, s, pos, dx, dwpe, d, pos_offset, rows);
+        hipLaunchKernelGGL(embed_bwd_wpe_packed_kernel, dim3(i2t_det() ? 1 : (rows < 4096 ? rows : 4096)), dim3(256), 0, s, pos, dx, dwpe, d, pos_offset, rows);
     } else if (dwpe) {
         launch_sum_over_batch(s, dx, (long)T * d, dwpe + (size_t)pos_offset * d, B, T, d, 1);
     }
@@ -595,7 +604,7 @@ extern "C" int i2t_grad_normalize(void* stream, float* g, long n, float* ws, voi
     if (!(presummed & 1)) {    // presummed (bit 0): the producer of g (i2t_layernorm_bwd's sumsq_out) already accumulated sum(g^2) into ws
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
         if (e != hipSuccess) { i2t_set_error("i2t_grad_normalize: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
-        const int grid = grid_for(n >> 2, 1024);
+        const int grid = i2t_det() ? 1 : grid_for(n >> 2, 1024);          // (deterministic: one workgroup, fixed-order block sum)
         hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n >> 2, n, ws);
     }
     hipLaunchKernelGGL(scale_by_norm_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n >> 2, n, ws, (bf16_t*)g_bf16, drop_key,
@@ -615,7 +624,7 @@ extern "C" int i2t_sumsq(void* stream, const float* g, long n, float* ws, int ac
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(float), s);
         if (e != hipSuccess) { i2t_set_error("i2t_sumsq: memset: %s", hipGetErrorString(e)); return I2T_EHIP; }
     }
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2, 1024)), dim3(256), 0, s, g, n >> 2, n, ws);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(i2t_det() ? 1 : grid_for(n >> 2, 1024)), dim3(256), 0, s, g, n >> 2, n, ws);
     I2T_CHECK_LAUNCH("i2t_sumsq");
     return I2T_OK;
 }

@@ -1608,7 +1608,7 @@ bool launch_g256_dw(hipStream_t s, GemmParams p) {
     const int n_cu = g256_cus();
     p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
     const int tiles = p.tiles_m * p.tiles_n, nk_all = (p.K + 63) >> 6;
-    if (tiles >= n_cu || n_cu / tiles < 2) {
+    if (tiles >= n_cu || n_cu / tiles < 2 || i2t_det()) {      // (deterministic mode: one K slice, no atomics)
         // (more than half a round of tiles but less than one -- a Qwen2-1.5B down_proj dW, 1536 x 8960 = 210 tiles -- cannot be split:
         // one tile per workgroup on the persistent kernel still beats the 128^2 fallback it used to take, 711 TF)
         if (g256_epilogue_class(p) != 5) return false;
@@ -1871,6 +1871,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     if (accumulate && c_is_f32 && plain_epilogue) {
         const int tiles = p.tiles_m * p.tiles_n, nk_all = (K + BK - 1) / BK;
         while (tiles * splits < 384 && nk_all / (splits * 2) >= 4 && splits < 64) splits *= 2;
+        if (i2t_det()) splits = 1;            // deterministic mode: one K slice per tile, plain read-add-write epilogue
     }
     // large-tile kernel for the non-split problems with enough 256^2 tiles to occupy the chip (I2T_GEMM=v1 keeps the 128^2 one)
     // K % 128 == 0: K-tiles run in pairs and the DMA stream chains output tiles; k-major panels must fit a 32-bit byte offset
@@ -2012,7 +2013,7 @@ extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N
     int splits = (M + 63) / 64;                       // >= 64 rows per workgroup
     const int want = 512 / col_blocks;                // ~2 workgroups per CU overall
     if (splits > want) splits = want;
-    if (splits < 1) splits = 1;
+    if (splits < 1 || i2t_det()) splits = 1;           // (deterministic mode: one workgroup per column block = one add per column)
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, splits), dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out);
     I2T_CHECK_LAUNCH("i2t_colsum_bf16");
     return I2T_OK;

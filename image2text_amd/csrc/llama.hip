@@ -41,11 +41,11 @@ template <bool DY_F32>
 __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ rstd,
                                                       float* __restrict__ dx, int dx_accumulate, bf16_t* __restrict__ dx_bf16,
-                                                      float* __restrict__ dw, int M, int d) {
+                                                      float* __restrict__ dw, int M, int d, int blk0) {
     __shared__ float red[4][RMS_MAXC * 256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nc = d >> 2;
-    const int row0 = blockIdx.x * RMS_BWD_ROWS, row_end = min(M, row0 + RMS_BWD_ROWS);
+    const int row0 = (blockIdx.x + blk0) * RMS_BWD_ROWS, row_end = min(M, row0 + RMS_BWD_ROWS);      // (blk0: deterministic mode, one workgroup per launch)
     auto load_dy = [&](int row, int c) -> f32x4 {
         if (DY_F32) return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + (size_t)row * d)[c];
         const u32x2 pk = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * d)[c];
@@ -201,12 +201,15 @@ extern "C" int i2t_rmsnorm_bwd(void* stream, const void* dy, int dy_is_f32, cons
                                float* dx, int dx_accumulate, void* dx_bf16, float* dw, int M, int d) {
     I2T_REQUIRE(dy && x && w && rstd && dx && M > 0 && d > 0 && d % 4 == 0, "i2t_rmsnorm_bwd: bad args (d=%d must be a multiple of 4)", d);
     const int grid = (M + RMS_BWD_ROWS - 1) / RMS_BWD_ROWS;
-    if (dy_is_f32)
-        hipLaunchKernelGGL(rms_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dw, M, d);
-    else
-        hipLaunchKernelGGL(rms_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dw, M, d);
+    const int per = i2t_det() ? 1 : grid;       // deterministic mode: the dw atomics land in workgroup order
+    for (int b0 = 0; b0 < grid; b0 += per) {
+        if (dy_is_f32)
+            hipLaunchKernelGGL(rms_bwd_kernel<true>, dim3(per), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
+                               (bf16_t*)dx_bf16, dw, M, d, b0);
+        else
+            hipLaunchKernelGGL(rms_bwd_kernel<false>, dim3(per), dim3(256), 0, (hipStream_t)stream, dy, x, w, rstd, dx, dx_accumulate,
+                               (bf16_t*)dx_bf16, dw, M, d, b0);
+    }
     I2T_CHECK_LAUNCH("i2t_rmsnorm_bwd");
     return I2T_OK;
 }

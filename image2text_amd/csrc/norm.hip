@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      int dx_accumulate, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int d, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                                                     float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq) {
+                                                     float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq, int blk0) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     // dx_pre_sumsq: the dx this launch accumulates onto is still UN-normalised; its normaliser 1 / (||dx|| + 1e-6) -- the
     // gradient normaliser of the block boundary above, whose fp32 rescale pass this replaces -- is applied while adding
@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     f32x4 pg[MAXC], pb[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) pg[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row_end = min(M, (int)(blockIdx.x + 1) * LN_BWD_ROWS);
-    for (int row = blockIdx.x * LN_BWD_ROWS + w; row < row_end; row += 4) {
+    const int bid = blockIdx.x + blk0;        // (blk0: deterministic mode launches the workgroups one at a time, in order)
+    const int row_end = min(M, (bid + 1) * LN_BWD_ROWS);
+    for (int row = bid * LN_BWD_ROWS + w; row < row_end; row += 4) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[MAXC], g[MAXC];
         float s1 = 0.f, s2 = 0.f;
@@ -374,12 +375,16 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
     I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
     int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
     hipStream_t s = (hipStream_t)stream;
-    if (dy_is_f32)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq);
+    // deterministic mode: the workgroups' atomics onto dgamma / dbeta / sumsq_out land in workgroup order (one launch each)
+    const int per = i2t_det() ? 1 : grid;
+    for (int b0 = 0; b0 < grid; b0 += per) {
+        if (dy_is_f32)
+            hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
+                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0);
+        else
+            hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
+                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0);
+    }
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
 }
@@ -410,6 +415,7 @@ extern "C" int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch
     const int col_blocks = (n4 + 255) / 256;
     int slices = 1;                                            // >= 32 images per slice, ~1024 workgroups at most
     while (slices < 16 && col_blocks * slices < 1024 && B / (slices * 2) >= 32) slices *= 2;
+    if (i2t_det()) slices = 1;                                 // one slice: plain adds, no atomics
     hipLaunchKernelGGL(lnnd_bwd_apply_kernel, dim3(col_blocks, slices), dim3(256), 0, s, dy, dy_batch_stride, x, add, gamma,
                        stats, dx, dgamma, dbeta, dadd, B, (int)n);
     I2T_CHECK_LAUNCH("i2t_layernorm_nd_bwd");

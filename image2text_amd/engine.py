@@ -1090,8 +1090,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             return None
         if dc.advpos:
             return self.posmlp_bwd(ctx.pos_ctx, dx)
-        if ctx.vl is not None:
-            a.G(f'{self.dp}transformer.wpe.weight').index_add_(0, ctx.vl.pos.long() + ctx.pos_offset, dx)
+        if ctx.vl is not None:      # packed rows: position of row m = vl.pos[m] (the same scatter kernel the id-driven path uses; no token part)
+            ops.embed_bwd(None, dx, None, a.G(f'{self.dp}transformer.wpe.weight'), M, 1, d, ctx.pos_offset, dc.V, pos=ctx.vl.pos)
             return dx
         ops.sum_over_batch(dx, T * d, a.G(f'{self.dp}transformer.wpe.weight')[ctx.pos_offset:ctx.pos_offset + T], B, T, d, accumulate=True)
         return dx

@@ -90,6 +90,8 @@ SIGNATURES = {
     'i2t_gemm_f32': [P, P, P, P, I, I, I],
     'i2t_lsh_embed_fwd': [P, P, P, L, P, P, P, P, P, P, I, I, I, I, I],
     'i2t_lsh_embed_bwd': [P, P, P, P, L, P, I, I, I, I, I],
+    'i2t_set_deterministic': [I],
+    'i2t_deterministic': [],
     'i2t_comm_available': [],
     'i2t_comm_unique_id': [P, I],
     'i2t_comm_init': [P, I, I, C.POINTER(C.c_void_p)],

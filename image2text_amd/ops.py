@@ -61,6 +61,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     return out
 
 
+def set_deterministic(on: bool):
+    """Fixed-order reductions on the gradient path (include/i2t.h::i2t_set_deterministic): slow, bit-reproducible backward passes."""
+    _l.check(_lib().i2t_set_deterministic(int(bool(on))), 'i2t_set_deterministic')
+
+
+def deterministic() -> bool:
+    return bool(_lib().i2t_deterministic())
+
+
 def gemm_reserve_cus(n: int):
     """Leave n CUs free in later persistent-GEMM launches (0 = use all); see include/i2t.h::i2t_gemm_reserve_cus."""
     _l.check(_lib().i2t_gemm_reserve_cus(int(n)), 'i2t_gemm_reserve_cus')

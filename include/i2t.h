@@ -499,6 +499,13 @@ int i2t_comm_allreduce(void* comm, void* stream, float* buf, long count, int mea
 int i2t_comm_destroy(void* comm);
 int i2t_workspace_bytes(const char* entry, long M, long N, long K, long* bytes_out);
 
+/* Deterministic mode: every reduction of the gradient path that combines workgroup partials with fp32 atomics (dW split-K
+ * slices, column sums, LayerNorm / RMSNorm gain gradients, the gradient normaliser's sum, embedding scatter-adds, convolution
+ * weight gradients) runs in one fixed order instead (one K slice, one workgroup, or one launch per workgroup).  Slow; two backward
+ * passes of the same step are then bit-equal.  Default: the environment variable I2T_DETERMINISTIC (unset / 0 = off). */
+int i2t_set_deterministic(int on);
+int i2t_deterministic(void);
+
 #ifdef __cplusplus
 }
 #endif

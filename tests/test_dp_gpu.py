@@ -12,12 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('model', ['nano224', 'gpt2_lora'])
+@pytest.mark.parametrize('model', ['nano224', 'gpt2_lora', 'gpt2_lora:deterministic', 'nano224:deterministic'])
 def test_one_rank_rccl_hooked_exchange_matches_unhooked(model):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
+    model, _, mode = model.partition(':')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', I2T_DP_SELFCHECK_MODEL=model)
+    if mode == 'deterministic':     # fixed-order reductions: hooked == un-hooked and accumulated == accumulated EXACTLY (tolerance 0)
+        env['I2T_DETERMINISTIC'] = '1'
     env.pop('NCCL_MAX_NCHANNELS', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_selfcheck.py')]
@@ -25,4 +28,5 @@ def test_one_rank_rccl_hooked_exchange_matches_unhooked(model):
     out = r.stdout.decode(errors='replace')
     assert r.returncode == 0 and 'DP_SELFCHECK_OK' in out, out[-4000:]
     assert 'nchannels=16' in out or os.environ.get('I2T_RCCL_CUS'), out[-500:]
-    assert 'transport=rccl-abi' in out, out[-800:]        # the exchange ran on the C-ABI communicator (include/i2t.h i2t_comm_*)
+    assert 'transport=rccl-abi' in out, out[-800:]
+    assert f'deterministic={int(mode == "deterministic")}' in out, out[-800:]        # the exchange ran on the C-ABI communicator (include/i2t.h i2t_comm_*)

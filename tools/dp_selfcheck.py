@@ -28,6 +28,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # order), so a measured floor can be far below what a third pass shows; the bound below is therefore bf16-level.  The defects this
 # check exists for are O(1): a slice reduced twice or not at all, a mean applied twice, a micro-batch lost.
 TOL = 5e-3
+# I2T_DETERMINISTIC=1 (fixed-order reductions, csrc/common.h): the same comparisons must then hold EXACTLY -- the bound above is for
+# the default mode's atomics only (tests/test_round3_gpu.py::test_deterministic_mode_makes_two_backward_passes_bit_equal).
+if os.environ.get('I2T_DETERMINISTIC', '0') not in ('', '0'):
+    TOL = 0.0
 
 
 def main():
@@ -150,6 +154,7 @@ def main():
     assert sent <= eng.arena.total and (frozen == 0 or sent < eng.arena.total), (sent, frozen, eng.arena.total)
     torch.cuda.synchronize()
     print(f'DP_SELFCHECK transport=rccl-abi spans={len(spans)} floats_sent={sent} of {eng.arena.total} (frozen {frozen})', flush=True)
+    print(f'DP_SELFCHECK deterministic={int(TOL == 0.0)} tol={TOL}', flush=True)
     print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
     dist.destroy_process_group()
 
