@@ -6,7 +6,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libi2t_hip.so')
 SOURCES = ['abi.cpp', 'comm.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'conv.hip', 'conv_mfma.hip', 'decode.hip', 'sample.hip',
-           'attention_g.hip', 'family.hip', 'grouped.hip', 'llama.hip', 'lora.hip', 'vit.hip']
+           'attention_g.hip', 'family.hip', 'grouped.hip', 'llama.hip', 'lora.hip', 'vit.hip', 'fp8.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 # per-file additions.  attention: keep MFMA accumulators in VGPRs -- the softmax rescales them every key tile, and the
 # AGPR form cost ~110 v_accvgpr_read/write per tile in kernels that are VALU-bound

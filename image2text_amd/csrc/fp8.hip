@@ -1,0 +1,230 @@
+// fp8 (OCP e4m3) GEMM operand path for FROZEN weights (BASELINE.json configs[4]; the reference only names fp8 as an accelerate
+// precision option, training_configs/local/nano.yaml:21): C = (A8 . B8^T) * sa[m] * sb[n] on the block-scaled MFMA
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 = 127) -- that form runs 2x the bf16 MFMA rate per clock (the
+// non-scaled fp8 MFMAs only run at the bf16 rate, MI355X_MICROARCH.md, Matrix cores) -- and per-ROW fp32 scales applied to the
+// fp32 accumulators in the epilogue: a row of the activations (dynamic, amax / 448 per GEMM call) and a row of the weight matrix
+// (quantised once per parameter version).  A frozen weight needs no dW, so both GEMMs that touch it -- y = x W^T and dx = dy W --
+// take fp8 operands; W is kept in both orientations ([N][K] and [K][N]), 1 byte each.
+//
+// Operand map: the scaled MFMA pairs byte j of lane l in A with byte j of lane l in B (probe: tools/probes/probe_mfma_fp8.cpp --
+// any k assignment works as long as both operands use the same one), so lane (r = l & 15, q = l >> 4) simply takes the 32
+// consecutive bytes k = 32 q .. 32 q + 31 of row r: two ds_read_b128.  C/D map as every 16x16 MFMA (col = l & 15, row = 4 q + e).
+//
+// Kernel: 128 x 128 x 128-byte tiles, 4 waves (2 x 2, 64 x 64 each = 16 accumulators), register-staged double buffer, LDS rows of
+// 128 B with the 16-byte chunks XOR-swizzled by (row & 7).  First version: correctness and the 2x-rate instruction; the persistent
+// 256^2 / LDS-DMA structure of gemm.hip is the next step.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+constexpr int F8_BM = 128, F8_BN = 128, F8_BK = 128;       // BK in bytes = elements
+constexpr float E4M3_MAX = 448.0f;
+
+// ---- row quantisation: scale[m] = amax(row) / 448 (1 for an all-zero row), q = round_to_e4m3(x / scale); K padded with zero bytes
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const void* __restrict__ x, int ld, unsigned char* __restrict__ out, int ld_out,
+                                                         float* __restrict__ scale, int M, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    auto load4 = [&](int c, float (&v)[4]) {
+        if (IN_F32) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)row * ld + c);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(x) + (size_t)row * ld + c);
+            v[0] = bf16lo(t[0]); v[1] = bf16hi(t[0]); v[2] = bf16lo(t[1]); v[3] = bf16hi(t[1]);
+        }
+    };
+    float amax = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        float v[4];
+        load4(c, v);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane * 4; c < ld_out; c += 256) {
+        unsigned pk = 0;
+        if (c < K) {
+            float v[4];
+            load4(c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e] / sc, -E4M3_MAX), E4M3_MAX);      // (a true division: x / scale, as a host reference computes it)
+            pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], (int)pk, true);
+        }
+        *reinterpret_cast<unsigned*>(out + (size_t)row * ld_out + c) = pk;
+    }
+}
+
+// ---- transposed quantisation of a weight W bf16 [N][K]: out8 [K][Np] with a scale per k (row of W^T): the dx = dy . W operand.
+// One workgroup per 64 k-columns: pass 1 column amax over all n, pass 2 convert and store 4 n at a time per k (tiny, once per version).
+__global__ __launch_bounds__(256) void quant_cols_kernel(const bf16_t* __restrict__ w, int ld, unsigned char* __restrict__ out, int ld_out,
+                                                         float* __restrict__ scale, int N, int K) {
+    __shared__ float red[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float amax = 0.f;
+    if (k < K)
+        for (int n = part; n < N; n += 4) amax = fmaxf(amax, fabsf(bf16_to_f32(w[(size_t)n * ld + k])));
+    red[part][threadIdx.x & 63] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0][threadIdx.x & 63], red[1][threadIdx.x & 63]), fmaxf(red[2][threadIdx.x & 63], red[3][threadIdx.x & 63]));
+    const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+    if (k >= K) return;
+    if (part == 0) scale[k] = sc;
+    for (int n0 = part * 4; n0 < ld_out; n0 += 16) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (n0 + e < N) ? fminf(fmaxf(bf16_to_f32(w[(size_t)(n0 + e) * ld + k]) / sc, -E4M3_MAX), E4M3_MAX) : 0.f;
+        unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], (int)pk, true);
+        *reinterpret_cast<unsigned*>(out + (size_t)k * ld_out + n0) = pk;
+    }
+}
+
+struct F8Params {
+    const unsigned char* A;      // [M][lda] e4m3
+    const unsigned char* B;      // [N][ldb] e4m3
+    const float* sa;             // [M]
+    const float* sb;             // [N]
+    void* C;
+    const float* bias;           // [N] or null
+    const float* residual;       // f32 [M][ldr] or null
+    int M, N, K, lda, ldb, ldc, ldr, c_is_f32;
+};
+
+__device__ __forceinline__ void f8_stage_load(u32x4 (&r)[4], const unsigned char* base, int ld, int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u, row = c >> 3, kc = c & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + row < nrows && k0 + kc * 16 < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + row) * ld + k0 + kc * 16);
+        r[u] = v;
+    }
+}
+__device__ __forceinline__ void f8_stage_store(const u32x4 (&r)[4], unsigned char* lds, int tid) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u, row = c >> 3, kc = c & 7;
+        *reinterpret_cast<u32x4*>(lds + row * 128 + ((kc ^ (row & 7)) << 4)) = r[u];
+    }
+}
+__device__ __forceinline__ i32x8 f8_frag(const unsigned char* lds, int row0, int lane) {
+    const int r = row0 + (lane & 15), q = lane >> 4;
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(lds + r * 128 + (((2 * q) ^ (r & 7)) << 4));
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(lds + r * 128 + (((2 * q + 1) ^ (r & 7)) << 4));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][F8_BM * 128];      // [buffer][A | B][row][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // XCD-aware bijective remap of the 1-D grid, N fastest inside groups of 8 column tiles (the weight panel stays in L2)
+    const int tiles_n = (p.N + F8_BN - 1) / F8_BN, nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz / tiles_n, tile_n = swz % tiles_n;
+    const int m0 = tile_m * F8_BM, n0 = tile_n * F8_BN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + F8_BK - 1) / F8_BK;
+    u32x4 ra[4], rb[4];
+    f8_stage_load(ra, p.A, p.lda, m0, p.M, 0, p.K, tid);
+    f8_stage_load(rb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
+    f8_stage_store(ra, smem[0][0], tid);
+    f8_stage_store(rb, smem[0][1], tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            f8_stage_load(ra, p.A, p.lda, m0, p.M, (kt + 1) * F8_BK, p.K, tid);
+            f8_stage_load(rb, p.B, p.ldb, n0, p.N, (kt + 1) * F8_BK, p.K, tid);
+        }
+        i32x8 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = f8_frag(smem[cur][1], wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i32x8 af = f8_frag(smem[cur][0], wm * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)      // swapped issue (B rows as the MFMA's A operand): D[n][m] -> a lane owns 4 consecutive n of one row m
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j], af, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        if (kt + 1 < nk) {
+            f8_stage_store(ra, smem[cur ^ 1][0], tid);
+            f8_stage_store(rb, smem[cur ^ 1][1], tid);
+        }
+        __syncthreads();
+    }
+    // epilogue: lane (li = lane & 15, g = lane >> 4) holds C[m = .. + li][n = .. + 4 g + e]: 4 consecutive columns -> 8 / 16-byte stores
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + li;
+        if (m >= p.M) continue;
+        const float sa = p.sa[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ne = min(n + e, p.N - 1);
+                v[e] = acc[i][j][e] * sa * p.sb[ne] + (p.bias ? p.bias[ne] : 0.f);
+            }
+            if (n + 3 < p.N) {
+                if (p.residual) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ldr + n);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.c_is_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                    const float o = v[e] + (p.residual ? p.residual[(size_t)m * p.ldr + n + e] : 0.f);
+                    if (p.c_is_f32) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = o;
+                    else reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n + e] = f32_to_bf16(o);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int ld, void* out, int ld_out, float* scale, int M, int K) {
+    I2T_REQUIRE(x && out && scale && M > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && ld_out % 16 == 0 && ld_out >= K && ALIGNED16(x) && ALIGNED16(out),
+                "i2t_quant_rows_fp8: bad args (K=%d %% 4, ld_out=%d %% 16 and >= K)", K, ld_out);
+    if (x_is_f32) hipLaunchKernelGGL(quant_rows_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)out, ld_out, scale, M, K);
+    else hipLaunchKernelGGL(quant_rows_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)out, ld_out, scale, M, K);
+    I2T_CHECK_LAUNCH("i2t_quant_rows_fp8");
+    return I2T_OK;
+}
+
+extern "C" int i2t_quant_cols_fp8(void* stream, const void* w, int ld, void* out, int ld_out, float* scale, int N, int K) {
+    I2T_REQUIRE(w && out && scale && N > 0 && K > 0 && ld_out % 16 == 0 && ld_out >= N && ALIGNED16(out), "i2t_quant_cols_fp8: bad args");
+    hipLaunchKernelGGL(quant_cols_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, ld, (unsigned char*)out, ld_out, scale, N, K);
+    I2T_CHECK_LAUNCH("i2t_quant_cols_fp8");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gemm_fp8(void* stream, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
+                            int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr) {
+    I2T_REQUIRE(A8 && B8 && sa && sb && C && M > 0 && N > 0 && K > 0, "i2t_gemm_fp8: bad args");
+    I2T_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ALIGNED16(A8) && ALIGNED16(B8),
+                "i2t_gemm_fp8: operands must be 16-byte aligned with leading dimensions %% 16 == 0 and >= K (zero-padded rows)");
+    I2T_REQUIRE(ldc >= N && ldc % 4 == 0 && ALIGNED16(C) && (!residual || (ldr % 4 == 0 && ALIGNED16(residual))), "i2t_gemm_fp8: C / residual alignment");
+    F8Params p{(const unsigned char*)A8, (const unsigned char*)B8, sa, sb, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, c_is_f32};
+    const long tiles = (long)((M + F8_BM - 1) / F8_BM) * ((N + F8_BN - 1) / F8_BN);
+    I2T_REQUIRE(tiles < 2147483647L, "i2t_gemm_fp8: grid too large");
+    hipLaunchKernelGGL(gemm_fp8_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    I2T_CHECK_LAUNCH("i2t_gemm_fp8");
+    return I2T_OK;
+}

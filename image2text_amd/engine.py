@@ -354,6 +354,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         # mixed into every training forward's dropout seed: a second model stepped at the same cadence (the momentum twin,
         # reference wrapper.py:68-71,197-198: forward_m draws fresh torch RNG) must not repeat this model's masks
         self.seed_salt = 0
+        # fp8 (e4m3) operands for the GEMMs of FROZEN decoder weights (engine_llama._lin; BASELINE.json configs[4]); off unless I2T_FP8=1
+        self.fp8 = os.environ.get('I2T_FP8', '0') not in ('', '0')
 
     def _refresh_sparse_sets(self):
         """(Re-)read the sparse layers' position sets when their buffers changed (they are part of the state dict: a checkpoint

@@ -51,6 +51,52 @@ class LlamaBlocks:
         self._sub_cache[key] = v
         return v
 
+    # ---- fp8 operands for FROZEN weights (I2T_FP8=1; csrc/fp8.hip, BASELINE.json configs[4]): a frozen matrix has no dW, so both GEMMs
+    # that touch it -- y = x W^T and dx = dy W -- run on the block-scaled e4m3 MFMA; W is quantised once per parameter version in
+    # both orientations (per-output-row scales for the forward, per-input-row scales for the backward), activations per call
+    def _fp8_on(self, names) -> bool:
+        return self.fp8 and all(not self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names))
+
+    def _fp8_weight(self, names, W):
+        key = ('fp8w', tuple([names] if isinstance(names, str) else names), id(self.arena))
+        ent = self._sub_cache.get(key)
+        # a frozen parameter is skipped by the fused optimizers (arena.generation moves every step, these values do not): the image
+        # is rebuilt only when torch-side code wrote the parameter (load_state_dict, a manual edit -> its version counter moves)
+        version = tuple(self.arena.params[n]._version for n in key[1])
+        if ent is None or ent.generation != version:
+            self.arena.refresh_shadow()
+            N, K = W.shape
+            dev = W.device
+            ent = SimpleNamespace(generation=version,
+                                  w8=torch.empty(N, (K + 15) // 16 * 16, dtype=torch.uint8, device=dev), sw=torch.empty(N, dtype=F32, device=dev),
+                                  wt8=torch.empty(K, (N + 15) // 16 * 16, dtype=torch.uint8, device=dev), swt=torch.empty(K, dtype=F32, device=dev))
+            ops.quant_rows_fp8(W, ent.w8, ent.sw, N, K)
+            ops.quant_cols_fp8(W, ent.wt8, ent.swt, N, K)
+            self._sub_cache[key] = ent
+        return ent
+
+    def _fp8_rows(self, x_bf, M: int, K: int):
+        x8 = torch.empty(M, (K + 15) // 16 * 16, dtype=torch.uint8, device=x_bf.device)
+        sx = self._empty(M)
+        ops.quant_rows_fp8(x_bf, x8, sx, M, K)
+        return x8, sx
+
+    def _lin(self, x_bf, W, names, out, M, N, K, bias=None, residual=None):
+        """out = x W^T (+ bias) (+ residual): fp8 operands when the weight is frozen and I2T_FP8=1, else the bf16 GEMM"""
+        if self._fp8_on(names):
+            e = self._fp8_weight(names, W)
+            x8, sx = self._fp8_rows(x_bf, M, K)
+            return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=residual)
+        return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual)
+
+    def _lin_dx(self, dy_bf, W, names, out, M, N, K):
+        """out [M, K] = dy [M, N] . W [N, K]"""
+        if self._fp8_on(names):
+            e = self._fp8_weight(names, W)
+            d8, sd = self._fp8_rows(dy_bf, M, N)
+            return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, N)
+        return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True)
+
     def rope_table(self):
         """fp32 [block, hd] = [cos | sin] per position, taken from the checkpoint's own rotary module (models/decoder.py)"""
         key = ('rope', str(self.arena.device))
@@ -70,22 +116,22 @@ class LlamaBlocks:
         n1, r1 = self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
         qkv = self._empty(M, v.nq, dtype=BF16)
-        ops.gemm(n1, v.Wqkv, qkv, M, v.nq, d, bias=v.bqkv)
+        self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv)
         ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos=rpos, pos_offset=pos_offset, T=T)      # q heads and k heads are adjacent columns
         q3 = v3(qkv, v.nq)
         ao, lse = self._empty(M, H * hd, dtype=BF16), self._empty(H * M)
         ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], v3(ao, H * hd), lse,
                              B, H, G, hd, T, T, True, cu_q=cu, cu_k=cu, total_q=M)
         x1 = self._empty(M, d)
-        ops.gemm(ao, v.Wo, x1, M, d, H * hd, residual=x)
+        self._lin(ao, v.Wo, v.names.o, x1, M, d, H * hd, residual=x)
         n2, r2 = self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
         gu = self._empty(M, 2 * ff, dtype=BF16)
-        ops.gemm(n2, v.Wgu, gu, M, 2 * ff, d)
+        self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
         h = self._empty(M, ff, dtype=BF16)
         ops.swiglu_fwd(gu, h, M, ff)
         x2 = self._empty(M, d)
-        ops.gemm(h, v.Wdn, x2, M, d, ff, residual=x1)
+        self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
         return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h) if save else None)
 
     def llama_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int, vl=None):
@@ -101,19 +147,19 @@ class LlamaBlocks:
         if tr(nm.dn):
             ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dh = self._empty(M, ff, dtype=BF16)
-        ops.gemm(dxb, v.Wdn, dh, M, ff, d, b_kmajor=True)
+        self._lin_dx(dxb, v.Wdn, nm.dn, dh, M, d, ff)
         dgu = self._empty(M, 2 * ff, dtype=BF16)
         ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
         if tr(nm.gu):
             ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dn = self._empty(M, d, dtype=BF16)
-        ops.gemm(dgu, v.Wgu, dn, M, d, 2 * ff, b_kmajor=True)
+        self._lin_dx(dgu, v.Wgu, nm.gu, dn, M, 2 * ff, d)
         ops.rmsnorm_bwd(dn, sv.x1, v.n2, sv.r2, dx, v.gn2 if tr(nm.n2) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
         # ---- attention
         if tr(nm.o):
             ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dao = self._empty(M, H * hd, dtype=BF16)
-        ops.gemm(dxb, v.Wo, dao, M, H * hd, d, b_kmajor=True)
+        self._lin_dx(dxb, v.Wo, nm.o, dao, M, d, H * hd)
         dqkv = self._empty(M, v.nq, dtype=BF16)
         q3, g3 = v3(sv.qkv, v.nq), v3(dqkv, v.nq)
         sl = (slice(0, H * hd), slice(H * hd, (H + G) * hd), slice((H + G) * hd, v.nq))
@@ -125,7 +171,7 @@ class LlamaBlocks:
             ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
         if tr(nm.qkv):
             ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
-        ops.gemm(dqkv, v.Wqkv, dn, M, d, v.nq, b_kmajor=True)
+        self._lin_dx(dqkv, v.Wqkv, nm.qkv, dn, M, v.nq, d)
         ops.rmsnorm_bwd(dn, sv.x, v.n1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
 
     # ------------------------------------------------------------------------------------------------ the decoder stack

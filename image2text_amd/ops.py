@@ -620,3 +620,29 @@ def lsh_embed_bwd(dy, rows, g_tables, slot_stride, tab_off, B, n_cls, nK, n_proj
     _need_cuda(dy, rows, g_tables, tab_off)
     _l.check(_lib().i2t_lsh_embed_bwd(_stream(), _p(dy), _p(rows), _p(g_tables), int(slot_stride), _p(tab_off), B, n_cls, nK, n_proj, dout),
              'i2t_lsh_embed_bwd')
+
+
+# ---- fp8 (e4m3) operand path for frozen weights (csrc/fp8.hip)
+def quant_rows_fp8(x, out, scale, M, K):
+    """x bf16 / f32 [M, >= K] -> out uint8 [M, ld_out] (e4m3 bytes, zero pad), scale f32 [M] (amax / 448)."""
+    _need_cuda(x, out, scale)
+    assert out.dtype == torch.uint8 and scale.dtype == F32 and x.dtype in (BF16, F32) and x.stride(-1) == 1
+    _l.check(_lib().i2t_quant_rows_fp8(_stream(), _p(x), int(x.dtype == F32), x.stride(0), _p(out), out.stride(0), _p(scale), M, K), 'i2t_quant_rows_fp8')
+    return out
+
+
+def quant_cols_fp8(w, out, scale, N, K):
+    """W bf16 [N, K] -> out uint8 [K, ld_out] = W^T quantised per k, scale f32 [K]."""
+    _need_cuda(w, out, scale)
+    assert w.dtype == BF16 and out.dtype == torch.uint8
+    _l.check(_lib().i2t_quant_cols_fp8(_stream(), _p(w), w.stride(0), _p(out), out.stride(0), _p(scale), N, K), 'i2t_quant_cols_fp8')
+    return out
+
+
+def gemm_fp8(a8, sa, b8, sb, out, M, N, K, bias=None, residual=None):
+    """out[M, N] = (a8[M, K] . b8[N, K]^T) * sa[m] * sb[n] (+ bias) (+ residual f32); include/i2t.h::i2t_gemm_fp8."""
+    _need_cuda(a8, b8, sa, sb, out)
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and out.dtype in (BF16, F32)
+    _l.check(_lib().i2t_gemm_fp8(_stream(), _p(a8), a8.stride(0), _p(sa), _p(b8), b8.stride(0), _p(sb), _p(out), out.stride(0), int(out.dtype == F32),
+                                 M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0), 'i2t_gemm_fp8')
+    return out

@@ -1,0 +1,148 @@
+"""fp8 (OCP e4m3) operand path (csrc/fp8.hip; BASELINE.json configs[4]): row / column quantisation against torch.float8_e4m3fn, the
+block-scaled-MFMA GEMM against the fp32 product of the SAME quantised operands (tight: only the summation order differs) and against
+the unquantised product (the quantisation error itself, reported), and the frozen Llama decoder on it against transformers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+REPORT = {}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def write_report():
+    yield
+    import json
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_report_fp8.json', 'w') as fh:
+        json.dump(REPORT, fh, indent=1, sort_keys=True)
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def dequant(q8, scale):
+    return q8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize('M,K,dtype', [(37, 768, BF16), (130, 4096, F32), (5, 100, BF16)])
+def test_row_quantisation_is_ocp_e4m3(M, K, dtype):
+    from image2text_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-3, 2, M)[:, None]).to(dtype).to(dev())
+    x[0].zero_()
+    ld = (K + 15) // 16 * 16
+    out, scale = torch.full((M, ld), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    ops.quant_rows_fp8(x, out, scale, M, K)
+    amax = x.float().abs().amax(dim=1)
+    want_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(scale, want_scale, rtol=1e-6, atol=0)
+    want = (x.float() / scale[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    got = out[:, :K]
+    # round-to-nearest-even on both sides: identical bytes except exact ties broken differently (none expected) and the sign of zero
+    diff = (got != want) & ~(((got & 0x7f) == 0) & ((want & 0x7f) == 0))
+    assert int(diff.sum()) == 0, int(diff.sum())
+    assert int(out[:, K:].sum()) == 0                                   # zero padding
+    rel = float(((dequant(got, scale) - x.float()).abs().amax(dim=1)[1:] / amax[1:]).max())
+    assert rel <= 2 ** -4 + 1e-3                                         # e4m3: 3 mantissa bits -> half an ulp of the row maximum's binade
+
+
+@pytest.mark.parametrize('M,N,K', [(200, 300, 768), (128, 128, 128), (1000, 1536, 4096), (50, 12, 256)])
+def test_fp8_gemm_matches_the_product_of_its_quantised_operands(M, N, K):
+    from image2text_amd import ops
+    g = torch.Generator().manual_seed(K + N)
+    x = (torch.randn(M, K, generator=g) * 0.7).to(BF16).to(dev())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF16).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    res = torch.randn(M, N, generator=g).to(dev())
+    ld = (K + 15) // 16 * 16
+    x8, sx = torch.empty(M, ld, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    w8, sw = torch.empty(N, ld, dtype=torch.uint8, device=dev()), torch.empty(N, device=dev())
+    ops.quant_rows_fp8(x, x8, sx, M, K)
+    ops.quant_rows_fp8(w, w8, sw, N, K)
+    ref_q = dequant(x8[:, :K], sx).double() @ dequant(w8[:, :K], sw).double().t()
+    ref = x.double() @ w.double().t()
+    Np = (N + 3) // 4 * 4
+    out32 = torch.empty(M, Np, device=dev())
+    ops.gemm_fp8(x8, sx, w8, sw, out32, M, N, K, bias=bias, residual=res)
+    got = out32[:, :N].double() - bias.double() - res.double()
+    scale = float(ref.abs().max())
+    err_q = float((got - ref_q).abs().max()) / scale
+    err = float((got - ref).norm() / ref.norm())
+    REPORT[f'gemm.{M}x{N}x{K}'] = {'max_err_vs_quantised_product_rel': err_q, 'rel_l2_vs_unquantised_product': err}
+    assert err_q <= 5e-5 and err <= 6e-2      # (fp32 accumulate + two fp32 scale multiplies vs the float64 product)
+    outb = torch.empty(M, Np, dtype=BF16, device=dev())
+    ops.gemm_fp8(x8, sx, w8, sw, outb, M, N, K)
+    assert float((outb[:, :N].double() - ref_q).abs().max()) / scale <= 1e-2
+    # the transposed weight image: dx = dy . W through quant_cols_fp8
+    wt8, swt = torch.empty(K, (N + 15) // 16 * 16, dtype=torch.uint8, device=dev()), torch.empty(K, device=dev())
+    ops.quant_cols_fp8(w, wt8, swt, N, K)
+    want_t = dequant(wt8[:, :N], swt)                                    # [K, N] ~ W^T
+    assert float((want_t - w.float().t()).norm() / w.float().norm()) <= 5e-2
+    assert int(wt8[:, N:].sum()) == 0
+
+
+def test_frozen_llama_decoder_on_fp8_operands_against_transformers(tmp_path, monkeypatch):
+    """prepare_for_kbit_training (frozen decoder, reference local/llama2-7b.yaml) with I2T_FP8=1: every decoder GEMM -- forward and
+    dx -- takes e4m3 operands (16 fp8 launches per layer pair counted), the encoder trains through them.  Against oracle encoder +
+    transformers' fp32 Llama: the loss within 2 %, the text logits' relative L2 deviation reported (measured 5.95 %) and bounded at 8 % (two layers of
+    per-row-scaled e4m3: 3 mantissa bits), the encoder's gradients within the direction bar cos >= 0.97."""
+    import copy
+    import torch.nn.functional as F
+    from image2text_amd import ops
+    from image2text_amd.configs.trainer import TrainerWrapperConfig
+    from image2text_amd.synth import det_init_, fake_tokenizer, synthetic_batch, tiny_config
+    from image2text_amd.training.wrapper import ModelTrainerWrapper
+    from oracle import reference_model as orc
+    from test_hf_decoder_gpu import _llama_reference
+    from test_host_cpu import _hf_decoder_config, _local_hf_llama
+    monkeypatch.setenv('I2T_FP8', '1')
+    _, name, vocab = _local_hf_llama(tmp_path, monkeypatch, 'llama')
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=0, prepare_for_kbit_training=True),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    tok = fake_tokenizer(vocab)
+    w = ModelTrainerWrapper(cfg, tok, TrainerWrapperConfig(), ignore_index=-100)
+    assert w.model._engine.fp8
+    keep = {k: v.detach().clone() for k, v in w.model.decoder.state_dict().items()}
+    det_init_(w.model, seed=0)
+    w.model.decoder.load_state_dict(keep)
+    hf = copy.deepcopy(w.model.decoder.backbone).float().eval()
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in w.model.state_dict().items() if not k.startswith('decoder.')}
+    w = w.to(dev()).train()
+    images, labels = synthetic_batch(3, 32, 12, vocab, seed=17)
+    n8 = []
+    orig = ops.gemm_fp8
+    monkeypatch.setattr(ops, 'gemm_fp8', lambda *a, **k: (n8.append(1), orig(*a, **k))[1])
+    loss, _ = w.train_step(images.to(dev()), labels.to(dev()))
+    loss.backward()
+    monkeypatch.setattr(ops, 'gemm_fp8', orig)
+    assert len(n8) == 2 * (4 + 4)                     # per layer: qkv, o, gate|up, down forward + their four dx GEMMs
+    ids, _ = orc.shifted_inputs(labels, tok.bos_token_id, tok.eos_token_id, -100)
+    _, sl, _ = _llama_reference(orc, esd, hf, cfg, images, ids)
+    ce = F.cross_entropy(sl.reshape(-1, vocab), labels.reshape(-1), ignore_index=-100, reduction='none')
+    oloss = (ce * orc.loss_weights(labels, -100).reshape(-1)).sum()
+    oloss.backward()
+    REPORT['llama_frozen_fp8.loss'] = {'got': float(loss.detach()), 'ref': float(oloss)}
+    assert abs(float(loss.detach()) - float(oloss)) <= 2e-2 * float(oloss)
+    with torch.no_grad():
+        out = w.eval().model(images=images.to(dev()), ids=ids.to(dev()))
+    dev_logits = out.logits.float().cpu()
+    rel = float((dev_logits - sl.detach()).norm() / sl.detach().norm())
+    REPORT['llama_frozen_fp8.logits'] = {'rel_l2_vs_transformers_fp32': rel, 'max_abs': float((dev_logits - sl.detach()).abs().max()),
+                                         'ref_absmax': float(sl.detach().abs().max())}
+    assert rel <= 8e-2
+    worst = 1.0
+    for n, p in w.model.named_parameters():
+        if n.startswith('decoder.'):
+            assert p.grad is None
+            continue
+        g, r = p.grad.float().cpu().double().ravel(), esd[n].grad.double().ravel()
+        c = float(g @ r / (g.norm() * r.norm() + 1e-30))
+        worst = min(worst, c)
+    REPORT['llama_frozen_fp8.encoder_gradient_min_cosine'] = worst
+    assert worst >= 0.97

@@ -56,9 +56,13 @@ def main():
     ap.add_argument('--vit', default='none', choices=['none', 'frozen', 'refine'], help="encoder = the reference's PretrainedViT (torchvision ViT-B/16 "
                     "shape, randomly initialised: the SWAG checkpoint is not in the image) with the slot-MLP head of local/gpt2.yaml (n_cls 16, "
                     "gate_sizes [1024], n_embd_out_vit 768): BASELINE.json configs[2].  frozen = refine_base_model: False")
+    ap.add_argument('--fp8', action='store_true', help='I2T_FP8=1: e4m3 operands for the GEMMs of FROZEN decoder weights (use with --freeze-decoder; '
+                    'BASELINE.json configs[4])')
     ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
                     "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
     args = ap.parse_args()
+    if args.fp8:
+        os.environ['I2T_FP8'] = '1'
     from transformers import GPT2Config, GPT2LMHeadModel
     from image2text_amd import ops
     from image2text_amd.configs.models import HuggingfaceDecoderConfig
@@ -139,9 +143,28 @@ def main():
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
            'decoder': {'prefixed': eng.dec.prefixed, 'grad_norm': eng.dec.grad_norm, 'layers': eng.dec.L, 'd': eng.dec.d, 'vocab': eng.dec.V}}
     from bench import GemmTimer
+    f8rec, f8orig = [], ops.gemm_fp8
+
+    def f8timed(a8, sa, b8, sb, o, M, N, K, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        r = f8orig(a8, sa, b8, sb, o, M, N, K, **kw)
+        e1.record(torch.cuda.current_stream())
+        f8rec.append((e0, e1, 2.0 * M * N * K))
+        return r
+    ops.gemm_fp8 = f8timed
     with GemmTimer(ops) as gt:
         step()
         gs = gt.summary()
+    ops.gemm_fp8 = f8orig
+    if f8rec:
+        torch.cuda.synchronize()
+        ms8 = sum(e0.elapsed_time(e1) for e0, e1, _ in f8rec)
+        fl8 = sum(f for _, _, f in f8rec)
+        out['fp8_gemm_family'] = {'launches': len(f8rec), 'ms_per_step': round(ms8, 2), 'tflops': round(fl8 / ms8 / 1e9, 1),
+                                  'frac_of_5000_tflops': round(fl8 / ms8 / 1e9 / 5000.0, 3)}
+    if args.fp8:
+        out['fp8'] = 'e4m3 operands (block-scaled MFMA, per-row scales) on every frozen decoder GEMM, forward and dx'
     out['gemm_family'] = {'launches': gs['launches'], 'ms_per_step': round(gs['total_ms'], 2), 'tflops': round(gs['tflops'], 1),
                           'frac_of_2500_tflops': round(gs['tflops'] / 2500.0, 3)}
     if not args.no_decode:
