@@ -791,6 +791,276 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnPtr Q, AttnPtr K,
     }
 }
 
+// ================================================================================================== v2 backward (fused)
+// One workgroup (8 waves) per (sequence, head) with Q, K, V and dO ALL resident in LDS (4 x 288 rows x 128 B = 144 KiB, one workgroup
+// per CU): the tiled pair above reads every operand 5 times per pair at T = 260 and stages it behind two barriers per tile; here each
+// operand is read ONCE, delta = rowsum(dO . O) is computed while staging, and after the staging barrier no wave waits for another:
+//   phase A (dQ):      a wave owns up to 3 sixteen-query blocks (Q / dO fragments in registers) and walks the keys in 64-row steps --
+//                      S^T = K Q^T, dP^T = V dO^T (row fragments of K and V serve all its blocks), dS^T, dQ^T += K^T dS^T;
+//   phase B (dK, dV):  a wave owns up to 3 sixteen-key blocks (K / V fragments in registers) and walks the queries in 32-row steps --
+//                      S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS (lane owns a key column).
+// Blocks are dealt round-robin, phase B in the opposite direction, so the wave that got the extra query block (T = 260: 17 blocks
+// on 8 waves) is not the one that gets the extra key block; both phases only READ the resident operands, so a wave moves on to
+// phase B without a barrier.
+constexpr int B2_MAXBLK = 3;                                            // blocks per wave and phase: 8 x 3 x 16 = 384 rows >= V2_MAXROWS
+
+template <bool DROP, int CNT>
+__device__ __forceinline__ void b2_phase_dq(const unsigned char* q_lds, const unsigned char* k_lds, const unsigned char* v_lds,
+                                            const unsigned char* do_lds, const float* lse_l, const float* dl_l, int w, int Tq, int Tk,
+                                            unsigned drow_base, unsigned drop_key, unsigned drop_thr, float dscale, bf16_t* dqb, int dq_rs,
+                                            unsigned od_key, unsigned od_thr, float od_scale, unsigned grow_base, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int nkb = (Tk + 15) >> 4;
+    bf16x8 qf[CNT][2], df[CNT][2];
+    float lse2[CNT], dl[CNT];
+    unsigned drow[CNT];
+    f32x4 acc[CNT][4];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int q0 = (w + 8 * c) * 16, qrow = min(q0 + li, Tq - 1);
+        qf[c][0] = v2_row_frag(q_lds, q0, 0, lane); qf[c][1] = v2_row_frag(q_lds, q0, 1, lane);
+        df[c][0] = v2_row_frag(do_lds, q0, 0, lane); df[c][1] = v2_row_frag(do_lds, q0, 1, lane);
+        lse2[c] = lse_l[q0 + li]; dl[c] = dl_l[q0 + li];
+        drow[c] = drow_base + (unsigned)qrow * (unsigned)Tk;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int cb = 0; cb < nkb; cb += 4) {
+        const int nkj = min(4, nkb - cb);
+        const bool full = (cb + 4) * 16 <= Tk;
+        f32x4 ds[CNT][4];
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) {
+            if (kj >= nkj) {
+#pragma unroll
+                for (int c = 0; c < CNT; ++c) ds[c][kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const bf16x8 k0 = v2_row_frag(k_lds, (cb + kj) * 16, 0, lane), k1 = v2_row_frag(k_lds, (cb + kj) * 16, 1, lane);
+            const bf16x8 v0 = v2_row_frag(v_lds, (cb + kj) * 16, 0, lane), v1 = v2_row_frag(v_lds, (cb + kj) * 16, 1, lane);
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[c][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[c][1], a, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df[c][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df[c][1], dp, 0, 0, 0);
+                bool keep[4] = {true, true, true, true};
+                if constexpr (DROP) dropout_keep4_even(drop_key, drow[c] + (cb + kj) * 16 + 4 * g, drop_thr, keep);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - lse2[c]);       // (lse2 = +inf for rows past Tq: p = 0)
+                    if (!full && (cb + kj) * 16 + 4 * g + r >= Tk) pr = 0.f;
+                    float dpr = dp[r];
+                    if constexpr (DROP) dpr = keep[r] ? dpr : 0.f;
+                    ds[c][kj][r] = pr * fmaf(dpr, dscale, -dl[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 t0 = v2_tr_frag(k_lds, cb * 16, dt * 16, lane);
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) acc[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, pack_frag(ds[c][0], ds[c][1]), acc[c][dt], 0, 0, 0);
+            if (nkj > 2) {
+                const bf16x8 t1 = v2_tr_frag(k_lds, cb * 16 + 32, dt * 16, lane);
+#pragma unroll
+                for (int c = 0; c < CNT; ++c) acc[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, pack_frag(ds[c][2], ds[c][3]), acc[c][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int qrow = (w + 8 * c) * 16 + li;
+        if (qrow < Tq) {
+            const float f = (od_thr ? (dropout_keep(od_key, grow_base + (unsigned)qrow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+            bf16_t* op = dqb + (size_t)qrow * dq_rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 o = acc[c][dt] * f;
+                *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
+        }
+    }
+}
+
+template <bool DROP, int CNT>
+__device__ __forceinline__ void b2_phase_dkv(const unsigned char* q_lds, const unsigned char* k_lds, const unsigned char* v_lds,
+                                             const unsigned char* do_lds, const float* lse_l, const float* dl_l, int w, int Tq, int Tk,
+                                             unsigned drow_base, unsigned drop_key, unsigned drop_thr, float dscale, bf16_t* dkb, int dk_rs,
+                                             bf16_t* dvb, int dv_rs, unsigned od_key, unsigned od_thr, float od_scale, unsigned grow_base,
+                                             int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int nqb = (Tq + 15) >> 4;
+    bf16x8 kf[CNT][2], vf[CNT][2];
+    f32x4 adk[CNT][4], adv[CNT][4];
+    int key[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int k0 = ((7 - w) + 8 * c) * 16;                               // (dealt from the other end than phase A's query blocks)
+        key[c] = k0 + li;
+        kf[c][0] = v2_row_frag(k_lds, k0, 0, lane); kf[c][1] = v2_row_frag(k_lds, k0, 1, lane);
+        vf[c][0] = v2_row_frag(v_lds, k0, 0, lane); vf[c][1] = v2_row_frag(v_lds, k0, 1, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) adk[c][dt] = adv[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int qb = 0; qb < nqb; qb += 2) {                                    // 32 queries per step (rows past Tq: zero Q / dO rows, lse = +inf)
+        f32x4 pp[CNT][2], ds[CNT][2];
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            const int q0 = (qb + qj) * 16;
+            const bf16x8 q0f = v2_row_frag(q_lds, q0, 0, lane), q1f = v2_row_frag(q_lds, q0, 1, lane);
+            const bf16x8 d0f = v2_row_frag(do_lds, q0, 0, lane), d1f = v2_row_frag(do_lds, q0, 1, lane);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_l + q0 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_l + q0 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[c][0], a, 0, 0, 0);      // D[q][key]: rows q = 4 g + e, column key = li
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[c][1], a, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[c][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[c][1], dp, 0, 0, 0);
+                bool keep4[4] = {true, true, true, true};
+                if constexpr (DROP) {      // a lane's 4 elements sit in 4 query rows: the quad of keys 4c..4c+3 shares one hash word per row (DPP)
+                    const int j = li & 3;
+                    const int qm = min(q0 + 4 * g + j, Tq - 1);
+                    const int mine = (int)dropout_hash(drop_key, (drow_base + (unsigned)qm * (unsigned)Tk + (unsigned)key[c]) >> 2);
+                    const unsigned sh = 8u * (unsigned)j;
+                    keep4[0] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                    keep4[1] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                    keep4[2] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                    keep4[3] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xff, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                }
+                const bool kvalid = key[c] < Tk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]);
+                    pv = kvalid ? pv : 0.f;
+                    float pd = pv, dpr = dp[r];
+                    if constexpr (DROP) {
+                        pd = keep4[r] ? pv : 0.f;
+                        dpr = keep4[r] ? dpr : 0.f;
+                    }
+                    pp[c][qj][r] = pd;
+                    ds[c][qj][r] = pv * fmaf(dpr, dscale, -d4[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 dot = v2_tr_frag(do_lds, qb * 16, dt * 16, lane), qt = v2_tr_frag(q_lds, qb * 16, dt * 16, lane);
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                adv[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pack_frag(pp[c][0], pp[c][1]), adv[c][dt], 0, 0, 0);
+                adk[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pack_frag(ds[c][0], ds[c][1]), adk[c][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        if (key[c] < Tk) {
+            const unsigned grow = grow_base + (unsigned)key[c];
+            const float fk = (od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+            const float fv = (od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f) * dscale;
+            bf16_t* pk_ = dkb + (size_t)key[c] * dk_rs;
+            bf16_t* pv_ = dvb + (size_t)key[c] * dv_rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 a = adk[c][dt] * fk, b = adv[c][dt] * fv;
+                *reinterpret_cast<u32x2*>(pk_ + dt * 16 + 4 * g) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                *reinterpret_cast<u32x2*>(pv_ + dt * 16 + 4 * g) = u32x2{pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void b2_stage2(unsigned char* la, unsigned char* lb, const bf16_t* a, int a_rs, const bf16_t* b, int b_rs,
+                                          int nrows, int rows_pad, int tid) {      // v2_stage2 for 512 threads
+    const int total = rows_pad * 8;
+    for (int c0 = tid; c0 < total; c0 += 2048) {
+        u32x4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 512 * u, r = c >> 3, kc = c & 7;
+            va[u] = vb[u] = u32x4{0u, 0u, 0u, 0u};
+            if (c < total && r < nrows) {
+                va[u] = *reinterpret_cast<const u32x4*>(a + (size_t)r * a_rs + kc * 8);
+                vb[u] = *reinterpret_cast<const u32x4*>(b + (size_t)r * b_rs + kc * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 512 * u, r = c >> 3, kc = c & 7;
+            if (c < total) {
+                const int off = r * V2_RB + ((kc ^ (r & 7)) << 4);
+                *reinterpret_cast<u32x4*>(la + off) = va[u];
+                *reinterpret_cast<u32x4*>(lb + off) = vb[u];
+            }
+        }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 1) void attn_bwd2_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, bf16_t* __restrict__ dK, long dk_bs,
+                                                           int dk_rs, bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq, int Tk,
+                                                           unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned od_key,
+                                                           unsigned od_thr, float od_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * V2_MAXROWS * V2_RB + 2 * V2_MAXROWS * 4];
+    unsigned char* q_lds = smem;
+    unsigned char* do_lds = smem + V2_MAXROWS * V2_RB;
+    unsigned char* k_lds = smem + 2 * V2_MAXROWS * V2_RB;
+    unsigned char* v_lds = smem + 3 * V2_MAXROWS * V2_RB;
+    float* lse_l = reinterpret_cast<float*>(smem + 4 * V2_MAXROWS * V2_RB);
+    float* dl_l = lse_l + V2_MAXROWS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const bf16_t* qb_ = Q.p + (size_t)b * Q.bs + h * 64;
+    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    const bf16_t* ob = O.p + (size_t)b * O.bs + h * 64;
+    const int qpad = (Tq + 31) & ~31, kpad = (Tk + 31) & ~31;
+    b2_stage2(q_lds, do_lds, qb_, Q.rs, dob, dO.rs, Tq, qpad, tid);
+    b2_stage2(k_lds, v_lds, K.p + (size_t)b * K.bs + h * 64, K.rs, V.p + (size_t)b * V.bs + h * 64, V.rs, Tk, kpad, tid);
+    // delta[q] = sum_d dO[q][d] O[q][d] (8 lanes per row: one 16-byte chunk each, both from global: dO is L2-hot) and lse in log2 units;
+    // rows past Tq get lse = +inf (p = 0) and delta = 0
+    const size_t stat_base = ((size_t)b * H + h) * Tq;
+    for (int r0 = 0; r0 < qpad; r0 += 64) {
+        const int r = r0 + (tid >> 3), kc = tid & 7;
+        float s = 0.f;
+        if (r < Tq) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dob + (size_t)r * dO.rs + kc * 8), c = *reinterpret_cast<const u32x4*>(ob + (size_t)r * O.rs + kc * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (kc == 0 && r < qpad) {
+            dl_l[r] = r < Tq ? s : 0.f;
+            lse_l[r] = r < Tq ? lse[stat_base + r] * LOG2E : INFINITY;
+        }
+    }
+    __syncthreads();
+    const float dscale = DROP ? drop_scale : 1.f;
+    const unsigned drow_base = ((unsigned)b * H + h) * (unsigned)Tq * (unsigned)Tk, grow_q = (unsigned)b * Tq, grow_k = (unsigned)b * Tk;
+    bf16_t* dqb = dQ + (size_t)b * dq_bs + h * 64;
+    bf16_t* dkb = dK + (size_t)b * dk_bs + h * 64;
+    bf16_t* dvb = dV + (size_t)b * dv_bs + h * 64;
+    const int nqb = (Tq + 15) >> 4, nkb = (Tk + 15) >> 4;
+    const int ca = (nqb - w + 7) >> 3;                                       // query blocks w, w + 8, ... < nqb
+    const int cbk = (nkb - (7 - w) + 7) >> 3;                                // key blocks 7 - w, 15 - w, ... < nkb
+#define B2_ARGS_A q_lds, k_lds, v_lds, do_lds, lse_l, dl_l, w, Tq, Tk, drow_base, drop_key, drop_thr, dscale, dqb, dq_rs, od_key, od_thr, od_scale, grow_q, lane
+#define B2_ARGS_B q_lds, k_lds, v_lds, do_lds, lse_l, dl_l, w, Tq, Tk, drow_base, drop_key, drop_thr, dscale, dkb, dk_rs, dvb, dv_rs, od_key, od_thr, od_scale, grow_k, lane
+    if (ca == 1) b2_phase_dq<DROP, 1>(B2_ARGS_A);
+    else if (ca == 2) b2_phase_dq<DROP, 2>(B2_ARGS_A);
+    else if (ca >= 3) b2_phase_dq<DROP, 3>(B2_ARGS_A);
+    if (cbk == 1) b2_phase_dkv<DROP, 1>(B2_ARGS_B);
+    else if (cbk == 2) b2_phase_dkv<DROP, 2>(B2_ARGS_B);
+    else if (cbk >= 3) b2_phase_dkv<DROP, 3>(B2_ARGS_B);
+#undef B2_ARGS_A
+#undef B2_ARGS_B
+}
+
 // the resident-operand kernels cover dense, non-causal calls whose operands fit (the encoders); I2T_ATTN_V2=0 keeps the tiled ones
 bool v2_applies(int Tq, int Tk, int causal, const int* cu_q, const int* cu_k, unsigned drop_thr) {
     const char* e = getenv("I2T_ATTN_V2");                               // read per call: tests switch it inside one process
@@ -867,6 +1137,16 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
     const VarLen vl{cu_q, cu_k, total_q, B};
     const AttnPtr Ow{(const bf16_t*)o, o_bs, o_rs};
+    if (v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS && !(getenv("I2T_ATTN_BWD2") && getenv("I2T_ATTN_BWD2")[0] == '0')) {
+        if (!drop_thr) hipLaunchKernelGGL((attn_bwd2_kernel<false>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
+                                          (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
+                                          out_drop_key, out_drop_thr, out_drop_scale);
+        else hipLaunchKernelGGL((attn_bwd2_kernel<true>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
+                                (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
+                                out_drop_key, out_drop_thr, out_drop_scale);
+        I2T_CHECK_LAUNCH("i2t_attention_bwd(v2)");
+        return I2T_OK;
+    }
     ATTN_DISPATCH(attn_bwd_dq_kernel, drop_thr, Tk, dim3(((Tq + 63) / 64) * H * B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
                   (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
                   out_drop_scale);
