@@ -285,7 +285,7 @@ def main():
     fence()
 
     # ---- greedy decode: B captions x 64 new tokens per run (encoder + KV-cache decode under hipGraph replay)
-    cap_s = dec_attn = None
+    cap_s = dec_attn = dec_gemm = None
     if not args.no_decode:
         wrapper.eval()
         opt.zero_grad()
@@ -329,9 +329,12 @@ def main():
         # ---- dominant decode kernel (decode_attention: K/V cache streaming, HBM-bound): one eager greedy run of lane 0
         if not args.no_kernel_timing:
             eng = wrapper.model._engine
-            with DecodeAttnTimer(ops, eng.dec.L, sum(eng.dec_cross)) as dt_:
+            # (the same eager run also times every GEMM of the decode leg: by kernel time they are the larger family -- r02 rocprof:
+            # 52 % of the leg against 29 % for decode_attention -- and MFMA-bound, so both are reported)
+            with DecodeAttnTimer(ops, eng.dec.L, sum(eng.dec_cross)) as dt_, GemmTimer(ops) as dg_:
                 cdec.lanes[0][0].generate(dimgs[0], prompts[0], 64, use_graph=False)
             dec_attn = dt_.summary()
+            dec_gemm = dg_.summary()
         wrapper.train()
 
     if rank == 0:
@@ -373,6 +376,15 @@ def main():
                                       'algorithmic_bytes_per_launch': round(dec_attn['bytes_per_launch']),
                                       'launches': dec_attn['launches'], 'avg_launch_us': round(dec_attn['avg_us'], 2),
                                       'decode_attention_ms_per_run': round(dec_attn['total_ms'], 2), 'captions': Bd, 'new_tokens': 64}
+        if dec_gemm is not None and dec_gemm['launches']:
+            out['decode_gemm_roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel / gemm_bf16_kernel (every i2t_gemm_bf16 launch of the same eager run: '
+                                           'encoder forward of the captions + 64 decode steps at M = captions rows)',
+                                           'achieved': round(dec_gemm['tflops'], 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                           'frac': round(dec_gemm['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                                           'launches': dec_gemm['launches'], 'avg_launch_us': round(dec_gemm['avg_us'], 2),
+                                           'gemm_ms_per_run': round(dec_gemm['total_ms'], 2),
+                                           'share_of_timed_decode_kernels': round(dec_gemm['total_ms'] / (dec_gemm['total_ms'] + dec_attn['total_ms']), 3)
+                                           if dec_attn is not None else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dropout=args.dropout)
         print(json.dumps(out), file=json_out, flush=True)

@@ -111,5 +111,8 @@ class LoraAdapters:
             ls = self._lora_site(l, site)
             W = a.P(W_name)
             W = W if rows is None else W[rows]
-            A = a.P(f'{self.dp}lora_params.h{l}_{site}_A')
-            buf.copy_(torch.addmm(W, ls.B, A, alpha=ls.scale))
+            # buf = bf16(W + s B A): one GEMM on the padded rank (B -> [N, LPAD] bf16 with zero pad columns; A's pad rows are zero in the
+            # arena), the fp32 base weight as the epilogue's residual
+            Bp = torch.zeros(ls.N, LPAD, dtype=BF16, device=buf.device)
+            Bp[:, :ls.r].copy_(ls.B)
+            ops.gemm(Bp, ls.A, buf, ls.N, ls.K, LPAD, b_kmajor=True, alpha=ls.scale, residual=W.contiguous())
