@@ -226,12 +226,53 @@ class VisionEncoderDecoder(nn.Module):
 
 
 def _owner_of(module):
+    """The VisionEncoderDecoder whose engine runs ``module``'s arithmetic.  A FREE-STANDING ``Encoder.from_config(...)`` /
+    ``Decoder.from_config(...)`` module (the reference's factories return usable nn.Modules, encoder.py:34-45, decoder.py:39-42) gets
+    a private holder on first use: the module itself plus the smallest counterpart that satisfies the engine (a one-layer decoder as
+    wide as the encoder's output / a one-layer 64-wide encoder), kept alive on the module.  Only the module's own tower ever runs."""
     ref = getattr(module, '_owner', None)
     owner = ref() if ref is not None else None
     if owner is None:
-        raise NotImplementedError(f'{type(module).__name__} runs its arithmetic through the VisionEncoderDecoder that owns it; '
-                                  'a free-standing encoder/decoder has no HIP path of its own')
+        owner = _standalone_holder(module)
+        object.__setattr__(module, '_standalone_holder', owner)         # strong reference: the weak _owner must not outlive its target
+    if getattr(module, '_standalone_holder', None) is owner:             # the module may have been moved since: the stand-in tower follows
+        dev = next(module.parameters()).device
+        if any(p.device != dev for p in owner.parameters()):
+            owner.to(dev)
     return owner
+
+
+def _standalone_holder(module):
+    from ..configs.models import (ImageInputSpec, MLPConfig, SelfAttentionConfig, SelfAttentionType, TransformerConfig,
+                                  TransformerDecoderConfig, VisionEncoderDecoderConfig, VisionTransformerEncoderConfig)
+
+    def tf(d, heads, causal, cross):
+        return TransformerConfig(rotator_config=MLPConfig(ff_mult=1), is_causal=causal, is_cross_attn=cross,
+                                 attn_config=SelfAttentionConfig(attn_dropout=0.0, bias=True, dropout=0.0, n_head=heads, n_embd=d,
+                                                                 attn_type=SelfAttentionType.MULTI_HEAD))
+    if isinstance(module, Encoder):
+        d = module.output_embed_dim
+        if d % 64:
+            raise NotImplementedError('a free-standing encoder needs an output width that is a multiple of 64 (its stand-in decoder)')
+        dcfg = TransformerDecoderConfig(transformer_config=tf(d, d // 64, True, False), n_layer=1, block_size=module.num_outputs + 8, vocab_size=8)
+        cfg = VisionEncoderDecoderConfig(vision_encoder_config=module.config, decoder_config=dcfg, use_cross_attn=False, use_soft_prompting=True)
+        dev = next(module.parameters()).device
+        holder = VisionEncoderDecoder(cfg, encoder=module)
+        holder.decoder.to(dev)
+        return holder
+    if isinstance(module, Decoder):
+        ecfg = VisionTransformerEncoderConfig(transformer_config=tf(64, 1, False, False), input=ImageInputSpec(n_channels=3, width=8, height=8),
+                                              n_layer=1, n_cls=1, num_patches=2, n_channels=8, feature_extractor_gate_sizes=None,
+                                              feature_extractor_kernel_size=(4, 4))
+        cross = bool(getattr(module, 'use_cross_attn', True)) and \
+            (not hasattr(module.config, 'transformer_config') or module.config.transformer_config.is_cross_attn)
+        cfg = VisionEncoderDecoderConfig(vision_encoder_config=ecfg, decoder_config=module.config, use_cross_attn=cross,
+                                         use_soft_prompting=not cross)
+        dev = next(module.parameters()).device
+        holder = VisionEncoderDecoder(cfg, decoder=module)
+        holder.encoder.to(dev)
+        return holder
+    raise NotImplementedError(f'{type(module).__name__} has no HIP path of its own')
 
 
 def run_encoder_standalone(encoder, images):

@@ -312,3 +312,38 @@ def test_train_loop_equals_hand_written_steps_exactly_in_deterministic_mode():
         ops.set_deterministic(False)
     for (n, p0), (_, p1) in zip(w0.model.named_parameters(), w1.model.named_parameters()):
         assert torch.equal(p0, p1), n
+
+
+def test_free_standing_encoder_and_decoder_modules_run_on_the_hip_path(tiny_weights):
+    """``Encoder.from_config(cfg)`` / ``Decoder.from_config(cfg)`` return usable modules in the reference (encoder.py:34-45,
+    decoder.py:39-42).  Here a free-standing module builds a private holder on first use; its outputs equal the oracle's for the same
+    weights (and the same module inside a VisionEncoderDecoder)."""
+    from image2text_amd.models.decoder import Decoder
+    from image2text_amd.models.encoder import Encoder
+    from oracle import reference_model as orc
+    cfg = tiny_config(enc_d=128, enc_heads=2)                      # encoder width = decoder width: no bridge, the encoder output is exposed
+    V = cfg.decoder_config.vocab_size
+    enc = Encoder.from_config(cfg.vision_encoder_config)
+    dec = Decoder.from_config(cfg.decoder_config, space_for_prompt=0)
+    det_init_(enc, seed=1)
+    det_init_(dec, seed=2)
+    esd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    dsd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    enc, dec = enc.to(dev()), dec.to(dev())
+    images, labels = synthetic_batch(3, 32, 12, V, seed=4)
+    with torch.no_grad():
+        out = enc(images.to(dev()))
+    ref = orc.vit_encoder(esd, cfg.vision_encoder_config, images)
+    assert out.shape == ref.shape == (3, cfg.vision_encoder_config.n_cls, 128)
+    err = float((out.float().cpu() - ref).abs().max())
+    REPORT['standalone.encoder'] = {'max_abs_err': err, 'ref_absmax': float(ref.abs().max())}
+    assert err <= 1.5e-2 * max(1.0, float(ref.abs().max()))
+    ids = labels.clamp(min=0)
+    mem = torch.randn(3, cfg.vision_encoder_config.n_cls, 128, generator=torch.Generator().manual_seed(6)) * 0.5
+    with torch.no_grad():
+        logits, hidden = dec(idx=ids.to(dev()), cross_attn_embeds=mem.to(dev()))
+    rl, rh = orc.gpt_decoder(dsd, cfg.decoder_config, idx=ids, cross_attn_embeds=mem)
+    assert logits.shape == rl.shape and hidden.shape == rh.shape
+    e1, e2 = float((logits.float().cpu() - rl).abs().max()), float((hidden.float().cpu() - rh).abs().max())
+    REPORT['standalone.decoder'] = {'logits_max_abs_err': e1, 'hidden_max_abs_err': e2, 'ref_absmax': float(rl.abs().max())}
+    assert e1 <= 1e-2 * max(1.0, float(rl.abs().max())) and e2 <= 1.5e-2 * max(1.0, float(rh.abs().max()))
