@@ -285,6 +285,11 @@ class GreedyDecoder:
         cs = eng.rope_table()
         for l in range(dc.L):
             v = eng._llama_views(l)
+            if getattr(dc, 'lora', None) is not None:          # merged W + s B A per adapted projection (engine_lora.lora_merged)
+                nm = v.names
+                Wqkv, Wo, Wgu, Wdn = (eng.lora_merged(l, site, names) if eng._llama_lora(l, site) is not None else W for site, names, W in
+                                      (('qkv', nm.qkv, v.Wqkv), ('o', nm.o, v.Wo), ('gu', nm.gu, v.Wgu), ('dn', nm.dn, v.Wdn)))
+                v = SimpleNamespace(**{**vars(v), 'Wqkv': Wqkv, 'Wo': Wo, 'Wgu': Wgu, 'Wdn': Wdn})
             ops.rmsnorm_fwd(st.x, v.n1, st.ln, None, B, d, ls.eps)
             ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, bias=v.bqkv, workspace=st.ws)
             ops.rope(st.qkv, v.nq, 0, H + G, hd, cs, B, pos_ptr=pos_ptr)

@@ -71,7 +71,7 @@ class DropPlan:
     lora_<site> = the input dropout of a LoRA adapter (peft's lora_dropout, rate ``p_lora``).
     The same plan object is kept in the saved context and re-evaluated in backward."""
     KINDS = {'emb': 0, 'qkv': 1, 'sdpa': 2, 'resid': 3, 'xattn': 4, 'mlp': 5, 'xresid': 6, 'lora_attn_c_attn': 7, 'lora_xattn_c_attn': 8,
-             'lora_mlp_c_fc': 9, 'lora_mlp_c_proj': 10}
+             'lora_mlp_c_fc': 9, 'lora_mlp_c_proj': 10, 'lora_qkv': 11, 'lora_o': 12, 'lora_gu': 13, 'lora_dn': 14}
 
     def __init__(self, seed: int, tower: int, p: float, p_attn: float, compact_layer: int = -1, live_rows: int = 0, xresid: bool = False,
                  p_lora: float = 0.0):
@@ -308,6 +308,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                                        prefixed=bool(self.cfg.use_soft_prompting))
             self.dcfg = dcfg = SimpleNamespace(skip_alternate_cross_attn=False, advanced_pos_emb_gate_sizes=None, n_layer=ls.L,
                                                transformer_config=SimpleNamespace(is_cross_attn=False))
+            self.dec.lora = getattr(model.decoder, 'lora', None)              # LoRA adapters on the Llama / Qwen2 blocks (engine_llama._llama_lora)
             self.n_wte = f'{self.dp}backbone.model.embed_tokens.weight'
             self.n_head = self.n_wte if ls.tied else f'{self.dp}backbone.lm_head.weight'
         else:

@@ -19,6 +19,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
+from .engine_lora import LPAD
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -97,6 +98,35 @@ class LlamaBlocks:
             return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, N)
         return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True)
 
+    # ---- LoRA adapters on these blocks (reference models/utils.py:46-65 -> peft LoraModel over the transformers module; the targets of
+    # training_configs/gpu/llama2-13b.yaml: q_proj, k_proj, v_proj, o_proj, up_proj, down_proj).  The fused projections keep ONE GEMM:
+    # the adapters of q | k | v (gate | up) share a stacked lora_A -- u = dropout(x) [A_q; A_k; A_v]^T -- and their B matrices sit
+    # block-diagonally in the K panel (engine_lora._lora_panel); everything else is engine_lora's machinery.
+    _LLAMA_SITES = {'qkv': ('q', 'k', 'v'), 'o': ('o',), 'gu': ('gate', 'up'), 'dn': ('down',)}
+
+    def _llama_lora(self, l: int, site: str):
+        lo = getattr(self.dec, 'lora', None)
+        if lo is None or site not in lo.sites:
+            return None
+        key = ('llama_lora', l, site, id(self.arena))
+        v = self._sub_cache.get(key)
+        if v is None:
+            a, ls = self.arena, self.dec.llama
+            nA = f'{self.dp}lora_params.h{l}_{site}_A'
+            K = a.entries[nA][2][1]
+            rows = {'q': ls.H * ls.hd, 'k': ls.Hkv * ls.hd, 'v': ls.Hkv * ls.hd, 'o': ls.d, 'gate': ls.ff, 'up': ls.ff, 'down': ls.d}
+            parts, row0, col0 = [], 0, 0
+            for t in self._LLAMA_SITES[site]:
+                nB = f'{self.dp}lora_params.h{l}_{t}_B'
+                if nB in a.entries:
+                    parts.append((row0, rows[t], col0, a.P(nB), a.G(nB)))
+                    col0 += lo.r
+                row0 += rows[t]
+            names = [nA] + ([nA + '.<pad>'] if a.entries[nA][2][0] < LPAD else [])
+            v = self._sub_cache[key] = SimpleNamespace(K=K, N=row0, r=lo.r, scale=lo.scale, kind=f'lora_{site}', A=a.span('W', names, (LPAD, K)),
+                                                       GA=a.span('G', names, (LPAD, K)), parts=parts, nA=nA)
+        return v
+
     def rope_table(self):
         """fp32 [block, hd] = [cos | sin] per position, taken from the checkpoint's own rotary module (models/decoder.py)"""
         key = ('rope', str(self.arena.device))
@@ -116,23 +146,40 @@ class LlamaBlocks:
         n1, r1 = self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
         qkv = self._empty(M, v.nq, dtype=BF16)
-        self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv)
+        plan = self.dec_drop if save else None
+        ldrop = (lambda site: plan.get(l, f'lora_{site}') if plan is not None else None)
+        lo = {site: self._llama_lora(l, site) for site in ('qkv', 'o', 'gu', 'dn')}
+        svlo = {}
+        if lo['qkv'] is not None:
+            svlo['qkv'] = self._lora_gemm(lo['qkv'], n1, v.Wqkv, qkv, M, ldrop('qkv'), save, bias=v.bqkv)
+        else:
+            self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv)
         ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos=rpos, pos_offset=pos_offset, T=T)      # q heads and k heads are adjacent columns
         q3 = v3(qkv, v.nq)
         ao, lse = self._empty(M, H * hd, dtype=BF16), self._empty(H * M)
         ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], v3(ao, H * hd), lse,
                              B, H, G, hd, T, T, True, cu_q=cu, cu_k=cu, total_q=M)
         x1 = self._empty(M, d)
-        self._lin(ao, v.Wo, v.names.o, x1, M, d, H * hd, residual=x)
+        if lo['o'] is not None:
+            svlo['o'] = self._lora_gemm(lo['o'], ao, v.Wo, x1, M, ldrop('o'), save, residual=x)
+        else:
+            self._lin(ao, v.Wo, v.names.o, x1, M, d, H * hd, residual=x)
         n2, r2 = self._empty(M, d, dtype=BF16), self._empty(M)
         ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
         gu = self._empty(M, 2 * ff, dtype=BF16)
-        self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
+        if lo['gu'] is not None:
+            svlo['gu'] = self._lora_gemm(lo['gu'], n2, v.Wgu, gu, M, ldrop('gu'), save)
+        else:
+            self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
         h = self._empty(M, ff, dtype=BF16)
         ops.swiglu_fwd(gu, h, M, ff)
         x2 = self._empty(M, d)
-        self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
-        return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h) if save else None)
+        if lo['dn'] is not None:
+            svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1)
+        else:
+            self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
+        return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h, lo=svlo,
+                                    lo_drop={site: ldrop(site) for site in lo}) if save else None)
 
     def llama_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int, vl=None):
         """dx fp32 / dxb bf16: gradient w.r.t. the block output; on return both hold the gradient w.r.t. the block input"""
@@ -144,22 +191,38 @@ class LlamaBlocks:
         tr = (lambda names: all(self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names)))
         nm = v.names
         # ---- MLP
-        if tr(nm.dn):
-            ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+        svlo = getattr(sv, 'lo', None) or {}
+        span_g = (lambda names, shape: self.arena.span('G', names, shape) if tr(names) else None)
+
+        def lora_bwd(site, dY, x_in, W, names, shape, gb=None):          # -> fp32 dx (engine_lora._lora_bwd), base dW only when trainable
+            return self._lora_bwd(self._llama_lora(l, site), svlo[site], dY, x_in, W, span_g([names] if isinstance(names, str) else names, shape),
+                                  gb, M, sv.lo_drop.get(site))
         dh = self._empty(M, ff, dtype=BF16)
-        self._lin_dx(dxb, v.Wdn, nm.dn, dh, M, d, ff)
+        if 'dn' in svlo:
+            ops.cast_f32_bf16(lora_bwd('dn', dxb, sv.h, v.Wdn, nm.dn, (d, ff)), dh)
+        else:
+            if tr(nm.dn):
+                ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            self._lin_dx(dxb, v.Wdn, nm.dn, dh, M, d, ff)
         dgu = self._empty(M, 2 * ff, dtype=BF16)
         ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
-        if tr(nm.gu):
-            ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dn = self._empty(M, d, dtype=BF16)
-        self._lin_dx(dgu, v.Wgu, nm.gu, dn, M, 2 * ff, d)
-        ops.rmsnorm_bwd(dn, sv.x1, v.n2, sv.r2, dx, v.gn2 if tr(nm.n2) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
+        if 'gu' in svlo:
+            dn2 = lora_bwd('gu', dgu, sv.n2, v.Wgu, nm.gu, (2 * ff, d))      # fp32: rmsnorm_bwd takes either
+        else:
+            if tr(nm.gu):
+                ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            self._lin_dx(dgu, v.Wgu, nm.gu, dn, M, 2 * ff, d)
+            dn2 = dn
+        ops.rmsnorm_bwd(dn2, sv.x1, v.n2, sv.r2, dx, v.gn2 if tr(nm.n2) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
         # ---- attention
-        if tr(nm.o):
-            ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dao = self._empty(M, H * hd, dtype=BF16)
-        self._lin_dx(dxb, v.Wo, nm.o, dao, M, d, H * hd)
+        if 'o' in svlo:
+            ops.cast_f32_bf16(lora_bwd('o', dxb, sv.ao, v.Wo, nm.o, (d, H * hd)), dao)
+        else:
+            if tr(nm.o):
+                ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            self._lin_dx(dxb, v.Wo, nm.o, dao, M, d, H * hd)
         dqkv = self._empty(M, v.nq, dtype=BF16)
         q3, g3 = v3(sv.qkv, v.nq), v3(dqkv, v.nq)
         sl = (slice(0, H * hd), slice(H * hd, (H + G) * hd), slice((H + G) * hd, v.nq))
@@ -167,12 +230,16 @@ class LlamaBlocks:
                              self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True,
                              cu_q=cu, cu_k=cu, total_q=M)
         ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos=rpos, pos_offset=pos_offset, T=T, inverse=True)
-        if v.gbqkv is not None and tr(nm.qkv_b):
-            ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
-        if tr(nm.qkv):
-            ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
-        self._lin_dx(dqkv, v.Wqkv, nm.qkv, dn, M, v.nq, d)
-        ops.rmsnorm_bwd(dn, sv.x, v.n1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
+        if 'qkv' in svlo:
+            dn1 = lora_bwd('qkv', dqkv, sv.n1, v.Wqkv, nm.qkv, (v.nq, d), gb=v.gbqkv if (v.gbqkv is not None and tr(nm.qkv_b)) else None)
+        else:
+            if v.gbqkv is not None and tr(nm.qkv_b):
+                ops.colsum(dqkv, v.gbqkv, M, v.nq, accumulate=True)
+            if tr(nm.qkv):
+                ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            self._lin_dx(dqkv, v.Wqkv, nm.qkv, dn, M, v.nq, d)
+            dn1 = dn
+        ops.rmsnorm_bwd(dn1, sv.x, v.n1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
 
     # ------------------------------------------------------------------------------------------------ the decoder stack
     def llama_decode_fwd(self, B: int, T: int, save: bool, ids, embeds, pos_offset: int, vl):

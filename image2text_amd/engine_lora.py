@@ -38,8 +38,17 @@ class LoraAdapters:
             names = [nA] + ([nA + '.<pad>'] if lo.r < LPAD else [])
             v = self._sub_cache[key] = SimpleNamespace(
                 K=K, N=N, r=lo.r, scale=lo.scale, kind=f'lora_{site}', A=a.span('W', names, (LPAD, K)), GA=a.span('G', names, (LPAD, K)),
-                B=a.P(nB), GB=a.G(nB))
+                B=a.P(nB), GB=a.G(nB), parts=[(0, N, 0, a.P(nB), a.G(nB))], nA=nA)
         return v
+
+    def _lora_panel(self, ls, dtype=BF16):
+        """[N, LPAD] = the adapter's B matrices at their (row block, rank column block) -- ONE block for a plain linear, block-diagonal for
+        a fused projection (q | k | v, gate | up: engine_llama) -- times the LoRA scale, zero elsewhere."""
+        dev = ls.A.device
+        panel = torch.zeros(ls.N, LPAD, dtype=dtype, device=dev)
+        for row0, nrows, col0, B, _ in ls.parts:
+            panel[row0:row0 + nrows, col0:col0 + B.shape[1]].copy_(B * ls.scale)
+        return panel
 
     def _lora_gemm(self, ls, x, W, out, M: int, drop_l, save: bool, **epilogue):
         """out = epilogue([x | u] . [W | s B | 0]^T), u = dropout(x) . A^T.  x bf16 [M, K] contiguous, W bf16 [N, K].  Returns what
@@ -49,9 +58,9 @@ class LoraAdapters:
         xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
         ops.lora_stage(x, xcat, xd, M, K, drop_l)                    # one pass: x into the concatenated operand + its masked copy
         ops.gemm(xd if xd is not None else x, ls.A, xcat[:, K:], M, LPAD, K)
-        wcat = torch.zeros(N, K + LPAD, dtype=BF16, device=x.device)
+        wcat = torch.empty(N, K + LPAD, dtype=BF16, device=x.device)
         wcat[:, :K].copy_(W)
-        wcat[:, K:K + ls.r].copy_(ls.B * ls.scale)
+        wcat[:, K:].copy_(self._lora_panel(ls))
         ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
         return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd) if save else None
@@ -66,7 +75,8 @@ class LoraAdapters:
             ops.gemm(dY, x, gW, N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         tmp = torch.zeros(N, LPAD, dtype=F32, device=dY.device)
         ops.gemm(dY, sv_l.u, tmp, N, LPAD, M, a_kmajor=True, b_kmajor=True, accumulate=True)
-        ls.GB.add_(tmp[:, :ls.r], alpha=ls.scale)
+        for row0, nrows, col0, B, GB in ls.parts:             # (a fused projection: only the diagonal blocks are parameters)
+            GB.add_(tmp[row0:row0 + nrows, col0:col0 + B.shape[1]], alpha=ls.scale)
         du = torch.empty(M, LPAD, dtype=BF16, device=dY.device)
         ops.gemm(dY, sv_l.sB, du, M, LPAD, N, b_kmajor=True)
         xd = sv_l.xd if sv_l.xd is not None else x
@@ -83,7 +93,7 @@ class LoraAdapters:
         key = ('lora_merged', l, site, id(self.arena))
         buf = self._sub_cache.get(key)
         if buf is None:
-            ls = self._lora_site(l, site)
+            ls = self._lora_site(l, site) if self.dec.llama is None else self._llama_lora(l, site)
             buf = self._sub_cache[key] = torch.empty(ls.N, ls.K, dtype=BF16, device=self.arena.device)
             self._lora_merge_list.append((buf, l, site, W_name, rows))
         return buf
@@ -96,7 +106,12 @@ class LoraAdapters:
         if lo is None:
             return
         a, d = self.arena, self.dec.d
-        for l in range(self.dec.L):
+        for l in range(self.dec.L if self.dec.llama is not None else 0):          # Llama / Qwen2 blocks (engine_llama._llama_lora)
+            v = self._llama_views(l)
+            for site, names in (('qkv', v.names.qkv), ('o', v.names.o), ('gu', v.names.gu), ('dn', v.names.dn)):
+                if self._llama_lora(l, site) is not None:
+                    self.lora_merged(l, site, names, None)
+        for l in range(self.dec.L if self.dec.llama is None else 0):
             p = f'{self.dp}transformer.h.{l}'
             for site, name, rows in (('attn_c_attn', f'{p}.attn.c_attn.weight', None), ('mlp_c_fc', f'{p}.mlp.c_fc.weight', None),
                                      ('mlp_c_proj', f'{p}.mlp.c_proj.weight', None),
@@ -108,11 +123,9 @@ class LoraAdapters:
             return
         self._lora_merged_ver = ver
         for buf, l, site, W_name, rows in self._lora_merge_list:
-            ls = self._lora_site(l, site)
-            W = a.P(W_name)
+            ls = self._lora_site(l, site) if self.dec.llama is None else self._llama_lora(l, site)
+            W = a.P(W_name) if isinstance(W_name, str) else a.span('P', W_name, (ls.N, ls.K))
             W = W if rows is None else W[rows]
-            # buf = bf16(W + s B A): one GEMM on the padded rank (B -> [N, LPAD] bf16 with zero pad columns; A's pad rows are zero in the
-            # arena), the fp32 base weight as the epilogue's residual
-            Bp = torch.zeros(ls.N, LPAD, dtype=BF16, device=buf.device)
-            Bp[:, :ls.r].copy_(ls.B)
-            ops.gemm(Bp, ls.A, buf, ls.N, ls.K, LPAD, b_kmajor=True, alpha=ls.scale, residual=W.contiguous())
+            # buf = bf16(W + s B A): one GEMM on the padded rank (the [N, LPAD] panel of _lora_panel; A's pad rows are zero in the arena),
+            # the fp32 base weight as the epilogue's residual
+            ops.gemm(self._lora_panel(ls), ls.A, buf, ls.N, ls.K, LPAD, b_kmajor=True, residual=W.contiguous())

@@ -47,8 +47,6 @@ class Decoder(nn.Module, abc.ABC):
         if isinstance(config, HuggingfaceDecoderConfig):
             if config.model_str.startswith('gpt2'):                    # reference decoder.py:120-121 (+ get_lora_model, :133-134)
                 return GPT2HuggingfaceDecoder(config, space_for_prompt)
-            if config.lora_spec is not None:
-                raise NotImplementedError('LoRA adapters run on the HIP hot path for the GPT-2 decoder only (SURVEY.md 8(f) next #3)')
             if config.model_str.startswith('meta-llama/Llama-2'):      # reference decoder.py:124-125
                 return Llama2HuggingfaceDecoder(config)
             if 'Qwen' in config.model_str:                             # reference decoder.py:126-127
@@ -439,10 +437,138 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         self.backbone = hf
         if config.prepare_for_kbit_training:
             _freeze_like_prepare_for_kbit_training(self)
+        self.lora = None
+        self._register_state_dict_hook(self._to_peft_keys)
+        self._register_load_state_dict_pre_hook(self._from_peft_keys)
+        if config.lora_spec is not None:
+            self._apply_lora(config.lora_spec)
+            from .utils import register_decoder_name_aliases
+            register_decoder_name_aliases(self.reference_parameter_names())
         self.llama_spec = SimpleNamespace(
             d=hc.hidden_size, H=hc.num_attention_heads, Hkv=hc.num_key_value_heads, hd=hd, L=hc.num_hidden_layers,
             ff=hc.intermediate_size, V=config.vocab_size + config.extra_tokens, eps=float(hc.rms_norm_eps), block=self.block_size,
             qkv_bias=attn0.q_proj.bias is not None, tied=hf.lm_head.weight is hf.model.embed_tokens.weight)
+
+    # -- LoRA (reference models/utils.py:46-65 -> peft LoraModel over the transformers module; decoder.py:404-440 reads the embedding
+    #    through it: backbone.model.model.embed_tokens) ---------------------------------------------------------------------------
+    # hot-path site (ONE GEMM) -> the transformers linears it fuses, in row order
+    _LORA_SITES = {'qkv': ('self_attn.q_proj', 'self_attn.k_proj', 'self_attn.v_proj'), 'o': ('self_attn.o_proj',),
+                   'gu': ('mlp.gate_proj', 'mlp.up_proj'), 'dn': ('mlp.down_proj',)}
+    _LORA_TAGS = {'self_attn.q_proj': 'q', 'self_attn.k_proj': 'k', 'self_attn.v_proj': 'v', 'self_attn.o_proj': 'o',
+                  'mlp.gate_proj': 'gate', 'mlp.up_proj': 'up', 'mlp.down_proj': 'down'}
+
+    def _apply_lora(self, spec):
+        """``get_lora_model(backbone, CAUSAL_LM, lora_spec)`` on this module's own parameters: every linear of the blocks whose name ends
+        in one of ``target_modules`` (peft's suffix rule; peft's default for llama / qwen2: q_proj, v_proj) gets
+        ``y += lora_B(lora_A(dropout(x))) * lora_alpha / r``, lora_A [r, in] ~ kaiming_uniform(a = sqrt 5), lora_B [out, r] = 0; every
+        other parameter is frozen, ``force_enable_update_modules`` (fnmatch over the LoraModel's names, ``model.model.layers...``)
+        switches named ones back on.  The adapters of linears the hot path fuses into one GEMM (q | k | v, gate | up) keep ONE stacked
+        lora_A parameter ``h{l}_{site}_A`` [n_adapted * r, in] and one lora_B per linear; the state dict speaks peft's per-module keys.
+        (One input-dropout mask per fused site: q / k / v adapters see the same masked x where peft draws three masks of the same
+        distribution -- each adapter's own statistics are peft's.)"""
+        import fnmatch
+        import math
+        hc = self.hf_config
+        targets = list(spec.target_modules) if spec.target_modules else ['q_proj', 'v_proj']
+        linears = [m for ms in self._LORA_SITES.values() for m in ms]
+        match = (lambda key, t: key == t or key.endswith('.' + t))
+        hit = [m for m in linears if any(match(f'model.layers.0.{m}', t) for t in targets)]
+        other = [t for t in targets if not any(match(f'model.layers.0.{m}', t) for m in linears)]
+        if other or not hit:
+            raise NotImplementedError(f'LoRA target_modules {targets}: the HIP hot path adapts the block linears {linears} '
+                                      f'(unsupported here: {other or "no module matched"})')
+        hd = getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads
+        d, ff = hc.hidden_size, hc.intermediate_size
+        shapes = {'self_attn.q_proj': (d, hc.num_attention_heads * hd), 'self_attn.k_proj': (d, hc.num_key_value_heads * hd),
+                  'self_attn.v_proj': (d, hc.num_key_value_heads * hd), 'self_attn.o_proj': (hc.num_attention_heads * hd, d),
+                  'mlp.gate_proj': (d, ff), 'mlp.up_proj': (d, ff), 'mlp.down_proj': (ff, d)}
+        sites = {site: [m for m in ms if m in hit] for site, ms in self._LORA_SITES.items()}
+        sites = {site: ms for site, ms in sites.items() if ms}
+        if not 0 < spec.r or max(len(ms) for ms in sites.values()) * spec.r > 128:
+            raise NotImplementedError('LoRA rank: the adapters of one fused projection share a 128-column panel (3 r <= 128 with q, k and v adapted)')
+        self.lora_params = nn.ParameterDict()
+        for l in range(hc.num_hidden_layers):
+            for site, ms in sites.items():
+                As = []
+                for m in ms:
+                    A = torch.empty(spec.r, shapes[m][0])
+                    nn.init.kaiming_uniform_(A, a=math.sqrt(5))
+                    As.append(A)
+                self.lora_params[f'h{l}_{site}_A'] = nn.Parameter(torch.cat(As, 0))
+                for m in ms:
+                    self.lora_params[f'h{l}_{self._LORA_TAGS[m]}_B'] = nn.Parameter(torch.zeros(shapes[m][1], spec.r))
+        self.lora = SimpleNamespace(r=spec.r, scale=spec.lora_alpha / spec.r, p=float(spec.lora_dropout), sites=tuple(sites),
+                                    hf_sites=tuple(hit), members=sites)
+        pats = spec.force_enable_update_modules
+        every = pats is not None and len(pats) == 0      # PatternMatcher: an empty list matches everything (models/utils.py:22-23)
+        for name, p in self.named_parameters():
+            if name.startswith('lora_params.'):
+                p.requires_grad = True
+            else:
+                p.requires_grad = every or (pats is not None and any(fnmatch.fnmatch(self._peft_name(name), pat) for pat in pats))
+
+    def _peft_name(self, internal: str) -> str:
+        """own parameter name ``backbone.<transformers name>`` -> the LoraModel's: ``model.<name>``, ``base_layer`` inside adapted linears"""
+        key = internal[len('backbone.'):]
+        for m in (self.lora.hf_sites if self.lora is not None else ()):
+            if f'.{m}.' in key:
+                key = key.replace(f'.{m}.', f'.{m}.base_layer.')
+        return 'model.' + key
+
+    def _lora_rows(self, name: str):
+        """``lora_params.h{l}_{x}_{A|B}`` -> [(peft key under ``backbone.``, row slice | None)]"""
+        l, rest = name[len('lora_params.h'):].split('_', 1)
+        x, ab = rest.rsplit('_', 1)
+        base = f'model.model.layers.{l}.'
+        if ab == 'B':
+            m = {v: k for k, v in self._LORA_TAGS.items()}[x]
+            return [(f'{base}{m}.lora_B.default.weight', None)]
+        r = self.lora.r
+        return [(f'{base}{m}.lora_A.default.weight', slice(i * r, (i + 1) * r)) for i, m in enumerate(self.lora.members[x])]
+
+    def reference_parameter_names(self):
+        """{own parameter name: [the reference's name(s) for the same numbers]} (see GPT2HuggingfaceDecoder.reference_parameter_names)"""
+        out = {}
+        for name, _ in self.named_parameters():
+            if name.startswith('lora_params.'):
+                out[name] = ['backbone.' + k for k, _ in self._lora_rows(name)]
+            else:
+                out[name] = ['backbone.' + self._peft_name(name)]
+        return out
+
+    @staticmethod
+    def _to_peft_keys(module, sd, prefix, local_metadata):
+        if module.lora is None:
+            return sd
+        for k in [k for k in sd if k.startswith(prefix)]:
+            v, name = sd.pop(k), k[len(prefix):]
+            if name.startswith('lora_params.'):
+                for key, rows in module._lora_rows(name):
+                    sd[f'{prefix}backbone.{key}'] = v if rows is None else v[rows]
+            else:
+                sd[f'{prefix}backbone.{module._peft_name(name)}'] = v
+        return sd
+
+    def _from_peft_keys(self, sd, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self.lora is None:
+            return
+        bb = prefix + 'backbone.'
+        stacks = {}
+        for k in [k for k in sd if k.startswith((bb + 'model.model.', bb + 'model.lm_head.'))]:      # a LoraModel's keys; plain transformers keys pass
+            v, name = sd.pop(k), k[len(bb) + len('model.'):]
+            if '.lora_A.' in name or '.lora_B.' in name:
+                mod, rest = name.split('.lora_')
+                l, m = mod.split('.')[2], mod.split('.', 3)[3]
+                if rest[0] == 'B':
+                    sd[f'{prefix}lora_params.h{l}_{self._LORA_TAGS[m]}_B'] = v
+                else:
+                    site = next(s for s, ms in self.lora.members.items() if m in ms)
+                    stacks.setdefault((l, site), {})[m] = v
+            else:
+                sd[bb + name.replace('.base_layer.', '.')] = v
+        for (l, site), parts in stacks.items():
+            if all(m in parts for m in self.lora.members[site]):
+                sd[f'{prefix}lora_params.h{l}_{site}_A'] = torch.cat([parts[m] for m in self.lora.members[site]], 0)
 
     def rope_table(self, n_positions: int) -> torch.Tensor:
         """fp32 [n_positions, head_dim] = [cos(p f_i) | sin(p f_i)], i < head_dim / 2: the values the checkpoint's own rotary module

@@ -365,6 +365,143 @@ def test_llama_family_long_sequence_forward(tmp_path, monkeypatch, kind):
     assert (out.logits.argmax(-1).cpu() == ologits.argmax(-1)).float().mean() > 0.9
 
 
+class _LoraLinear(torch.nn.Module):
+    """peft's LoRA layer around an nn.Linear, restated (peft is not in this image): base(x) + lora_B(lora_A(dropout(x))) * alpha / r"""
+
+    def __init__(self, base, A, B, scale):
+        super().__init__()
+        self.base, self.scale, self.mask = base, scale, None
+        self.A, self.B = torch.nn.Parameter(A.clone()), torch.nn.Parameter(B.clone())
+
+    def forward(self, x):
+        xd = x if self.mask is None else x * self.mask.view(x.shape)
+        return self.base(x) + (xd @ self.A.t() @ self.B.t()) * self.scale
+
+
+@pytest.mark.parametrize('kind,p_lora', [('llama', 0.0), ('llama', 0.25), ('qwen', 0.0)])
+def test_llama_family_decoder_lora(tmp_path, monkeypatch, kind, p_lora):
+    """lora_spec on the Llama-2 / Qwen2 plugins with the targets of the reference's gpu/llama2-13b.yaml (q, k, v, o, up, down): the adapters
+    of a fused projection ride block-diagonally in the K panel of its ONE GEMM, frozen base weights get no gradient (and no dW GEMM), the
+    adapter input dropout uses the same mask forward and backward, generation runs on merged weights.  Checker: the checkpoint's own
+    transformers module on the CPU in fp32 with peft's published LoRA layer restated around the targeted linears."""
+    import copy
+    from oracle import reference_model as orc
+    from image2text_amd import rng
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from test_host_cpu import _local_hf_llama
+    tag = f'hf_{kind}_lora.p{p_lora}'
+    _, name, vocab = _local_hf_llama(tmp_path, monkeypatch, kind)
+    extra = 4 if kind == 'llama' else 0
+    V = vocab + extra
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=p_lora, target_modules=['q_proj', 'k_proj', 'v_proj', 'o_proj', 'up_proj', 'down_proj'],
+                    force_enable_update_modules=['*.norm.*'] if kind == 'qwen' else None)
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, lora_spec=spec),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    m.decoder.tie_weights()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for n, p in m.decoder.lora_params.items():
+            if n.endswith('_B'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)          # lora_B starts at zero: give the adapters something to do
+    dec = m.decoder
+    hf = copy.deepcopy(dec.backbone).float().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    wraps = {}
+    for l in range(2):
+        for site, members in dec.lora.members.items():
+            for mod_path in members:
+                parent_name, leaf = mod_path.split('.')
+                parent = getattr(hf.model.layers[l], parent_name)
+                key = f'backbone.model.model.layers.{l}.{mod_path}.lora_'
+                w = _LoraLinear(getattr(parent, leaf), sd[key + 'A.default.weight'], sd[key + 'B.default.weight'], dec.lora.scale)
+                setattr(parent, leaf, w)
+                wraps[(l, site, mod_path)] = w
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    assert 'decoder.backbone.model.layers.0.self_attn.q_proj.weight' in frozen and 'decoder.lora_params.h0_qkv_A' not in frozen
+    assert ('decoder.backbone.model.norm.weight' in frozen) == (kind == 'llama')
+    m = m.to(dev()).train()
+    eng = m._engine
+    images, labels = synthetic_batch(3, 32, 12, V, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls
+    gg = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, 256, generator=gg) * 0.05
+    wl = torch.randn(3, 12, V, generator=gg) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    if p_lora > 0:          # the masks this step drew (one per fused site), replicated on the host for the checker's adapters
+        plan = eng.dec_drop
+        for (l, site, _), w in wraps.items():
+            _, key, thr, scale = plan.get(l, f'lora_{site}')
+            rows, K = 3 * (n_p + 12), w.A.shape[1]
+            w.mask = rng.keep_mask(key, rows * K, thr).view(rows, K).float() * scale
+    enc, ologits, ohid = _llama_reference(orc, esd, hf, cfg, images, ids)
+    # (max over 3 x 12 x V logits of bf16 rounding noise: the un-adapted tests sit at 0.85 of 1e-2 x max|logit|; the adapters add two
+    # bf16 roundings (u and s B) per site, so the max-norm bound is 1.25e-2 here and the rel-L2 error is bounded beside it)
+    for name_, got, ref, tol in (('logits', out.logits, ologits, 1.25e-2), ('hidden', out.hidden_state, ohid, 1.5e-2)):
+        diff = got.float().cpu() - ref.detach()
+        err, scale_ = float(diff.abs().max()), max(1.0, float(ref.detach().abs().max()))
+        rel = float(diff.norm() / ref.detach().norm())
+        REPORT[f'{tag}.{name_}'] = {'max_abs_err': err, 'tol': tol * scale_, 'rel_l2': rel}
+        assert err <= tol * scale_ and rel <= 2e-2, (name_, err, tol * scale_, rel)
+    ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.backbone.' + k.replace('.base.', '.'): p.grad for k, p in hf.named_parameters()
+                      if not (k.endswith('.A') or k.endswith('.B'))})
+    r = dec.lora.r
+    for l in range(2):
+        for site, members in dec.lora.members.items():
+            ref_grads[f'decoder.lora_params.h{l}_{site}_A'] = torch.cat([wraps[(l, site, mp)].A.grad for mp in members], 0)
+            for mp in members:
+                ref_grads[f'decoder.lora_params.h{l}_{dec._LORA_TAGS[mp]}_B'] = wraps[(l, site, mp)].B.grad
+    fails, checked = [], 0
+    for name_, p in m.named_parameters():
+        if name_ in frozen:
+            assert p.grad is None, f'{name_} is frozen but received a gradient'
+            continue
+        checked += 1
+        try:
+            grad_close(f'{tag}.{name_}', p.grad, ref_grads[name_].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert checked >= 2 * 10 and not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    if p_lora > 0:
+        return
+    # generation on merged weights against greedy decoding by full (adapter-in-the-K-panel) forwards
+    m.eval()
+    tok = fake_tokenizer(V)
+    with torch.no_grad():
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = m.generate(images.to(dev()), prompt, max_new_tokens=10, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(10):
+            lg = m(images=images.to(dev()), ids=cur).logits[:, -1].float().cpu()
+            lg = orc.apply_ngram_ban(cur.cpu(), lg, cfg.no_repeat_n_grams)
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * lg[torch.isfinite(lg)].abs().max().clamp(min=1.0)
+            same_prefix = (gen[:, :cur.shape[1]].cpu() == cur.cpu()).all(dim=1)
+            ok = gen[:, cur.shape[1]].cpu() == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
+        REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
+        assert total >= 8 and agree == total, (agree, total)
+        _, l0, _ = _llama_reference(orc, esd, hf, cfg, images, prompt.cpu())
+        l0 = l0[:, -1].detach()
+        t2 = l0.topk(2, dim=-1).values
+        sure = (t2[:, 0] - t2[:, 1]) > 3e-2 * l0.abs().max()
+        assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
+
+
 def test_llama_decoder_frozen_by_prepare_for_kbit_training(tmp_path, monkeypatch):
     """prepare_for_kbit_training: True without 4-bit loading (reference local/llama2-7b.yaml; peft freezes the base model): no decoder
     parameter receives a gradient, the weight-gradient GEMMs are skipped, and the encoder's gradients -- through the soft prompt rows of

@@ -338,8 +338,6 @@ def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
     m_soft = VisionEncoderDecoder(cfg.model_copy(update=dict(decoder_config=_hf_decoder_config())))
     assert not m_soft._engine.cross_inputs                                  # model asks for cross-attention, the decoder has none: dropped
     # refusals
-    with pytest.raises(NotImplementedError, match='LoRA'):
-        Decoder.from_config(_hf_decoder_config(name='Qwen-x', vocab_size=151936, lora_spec=LoraSpec(r=4, target_modules=['q_proj'])))
     with pytest.raises(NotImplementedError, match='4-bit'):
         Decoder.from_config(_hf_decoder_config(load_in_4bit=True))
     with pytest.raises(NotImplementedError, match='Falcon'):
@@ -504,6 +502,72 @@ def test_llama_qwen2_huggingface_decoder_plugins(tmp_path, monkeypatch):
         Decoder.from_config(_hf_decoder_config(name='meta-llama/Llama-2-tiny', vocab_size=1000))          # 'vocab should not shrink' (decoder.py:407)
     with pytest.raises(NotImplementedError, match='Falcon'):
         Decoder.from_config(_hf_decoder_config(name='tiiuae/falcon-7b', vocab_size=65024))
+
+
+def test_llama_qwen2_huggingface_decoder_lora(tmp_path, monkeypatch):
+    """lora_spec on the Llama-2 / Qwen2 plugins (reference gpu/llama2-13b.yaml:35-39; decoder.py:133-134 -> models/utils.py:46-65): adapters
+    on the block linears peft's suffix rule selects, the adapters of a fused projection stacked in one lora_A parameter, everything else
+    frozen, state dict in the LoraModel's per-module keys (backbone.model.model.layers...base_layer / lora_A.default / lora_B.default)."""
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.engine import _arena_order
+    targets = ['q_proj', 'k_proj', 'v_proj', 'o_proj', 'up_proj', 'down_proj']
+    for kind, extra in (('llama', 4), ('qwen', 0)):
+        hf, name, vocab = _local_hf_llama(tmp_path, monkeypatch, kind)
+        mk = lambda **kw: Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, lora_spec=LoraSpec(
+            **{**dict(r=4, lora_alpha=16, lora_dropout=0.1, target_modules=targets), **kw})))
+        d = mk()
+        ls = d.llama_spec
+        assert d.lora.sites == ('qkv', 'o', 'gu', 'dn') and d.lora.members['gu'] == ['mlp.up_proj'] and d.lora.scale == 4.0
+        sd = d.state_dict()
+        p_ = 'backbone.model.model.layers.1.'
+        kv = ls.Hkv * ls.hd
+        shapes = {p_ + 'self_attn.q_proj.base_layer.weight': (256, 256), p_ + 'self_attn.q_proj.lora_A.default.weight': (4, 256),
+                  p_ + 'self_attn.k_proj.lora_A.default.weight': (4, 256), p_ + 'self_attn.k_proj.lora_B.default.weight': (kv, 4),
+                  p_ + 'self_attn.v_proj.lora_B.default.weight': (kv, 4), p_ + 'self_attn.o_proj.lora_A.default.weight': (4, 256),
+                  p_ + 'mlp.up_proj.lora_B.default.weight': (512, 4), p_ + 'mlp.gate_proj.weight': (512, 256),
+                  p_ + 'mlp.down_proj.lora_A.default.weight': (4, 512), p_ + 'mlp.down_proj.base_layer.weight': (256, 512),
+                  p_ + 'input_layernorm.weight': (256,), 'backbone.model.model.embed_tokens.weight': (vocab + extra, 256),
+                  'backbone.model.lm_head.weight': (vocab + extra, 256)}
+        if kind == 'qwen':
+            shapes[p_ + 'self_attn.q_proj.base_layer.bias'] = (256,)
+        for k, shp in shapes.items():
+            assert k in sd and tuple(sd[k].shape) == shp, k
+        assert not any('lora_params' in k or k.startswith('backbone.model.layers.') for k in sd)
+        assert set(k for k in sd if '.lora_' not in k) == {'backbone.model.' + k.replace('_proj.', '_proj.base_layer.') if 'gate_proj' not in k
+                                                           else 'backbone.model.' + k for k in hf.state_dict()}
+        # the stacked lora_A: q rows, then k rows, then v rows
+        A = d.lora_params['h1_qkv_A']
+        assert A.shape == (12, 256) and torch.equal(sd[p_ + 'self_attn.k_proj.lora_A.default.weight'], A[4:8])
+        assert float(d.lora_params['h0_q_B'].abs().max()) == 0.0 and float(A.std()) > 0.01
+        grads = {n: p.requires_grad for n, p in d.named_parameters()}
+        assert all(v == n.startswith('lora_params.') for n, v in grads.items())
+        order = _arena_order(list(d.named_parameters()))
+        i = [n for n, *_ in order].index('lora_params.h0_qkv_A')
+        assert order[i + 1][0] == 'lora_params.h0_qkv_A.<pad>' and order[i + 1][2] == (128 - 12) * 256
+        # round trips: the LoraModel's keys (strict), and an un-adapted checkpoint in transformers' keys
+        d2 = mk()
+        d2.load_state_dict(sd, strict=True)
+        assert all(torch.equal(a, b) for a, b in zip(d.parameters(), d2.parameters()))
+        plain = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra)).state_dict()
+        missing, unexpected = d2.load_state_dict(plain, strict=False)
+        assert not unexpected and missing and all('lora_' in k for k in missing)
+        # force_enable_update_modules is matched against the LoraModel's names; the defaults are peft's (q_proj, v_proj)
+        d3 = mk(force_enable_update_modules=['*.embed_tokens.*', '*.q_proj.base_layer.*', '*norm*'])
+        on = {n for n, p in d3.named_parameters() if p.requires_grad and not n.startswith('lora_params.')}
+        assert 'backbone.model.embed_tokens.weight' in on and 'backbone.model.layers.0.self_attn.q_proj.weight' in on
+        assert 'backbone.model.norm.weight' in on and 'backbone.model.layers.0.self_attn.k_proj.weight' not in on
+        d4 = mk(target_modules=None)
+        assert d4.lora.sites == ('qkv',) and d4.lora.members['qkv'] == ['self_attn.q_proj', 'self_attn.v_proj']
+        assert d4.lora_params['h0_qkv_A'].shape == (8, 256) and 'h0_k_B' not in d4.lora_params
+        from image2text_amd.models.utils import PatternMatcher
+        names = ['model.decoder.' + n for n, _ in d.named_parameters()]
+        pick = lambda pats: [n for n in names if PatternMatcher(pats).match(n)]
+        assert pick(['*.k_proj.lora_A.*']) == ['model.decoder.lora_params.h0_qkv_A', 'model.decoder.lora_params.h1_qkv_A']
+        assert pick(['*.o_proj.base_layer.*']) == [f'model.decoder.backbone.model.layers.{l}.self_attn.o_proj.weight' for l in (0, 1)]
+        with pytest.raises(NotImplementedError, match='target_modules'):
+            mk(target_modules=['q_proj', 'lm_head'])
+        with pytest.raises(NotImplementedError, match='rank'):
+            mk(r=64)
 
 
 def _gpt2_decoder_config(**kw):
