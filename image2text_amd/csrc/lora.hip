@@ -18,6 +18,18 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const float* __restrict_
     }
 }
 
+// the same behind an exact (erf) GELU: transformers' Falcon MLP (engine_llama.py falcon blocks)
+__global__ __launch_bounds__(256) void dgelu_erf_mul_kernel(const float* __restrict__ dh, const bf16_t* __restrict__ pre, bf16_t* __restrict__ out,
+                                                            long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
+        const u32x2 p = reinterpret_cast<const u32x2*>(pre)[i];
+        const float o0 = g[0] * gelu_erf_grad(bf16lo(p[0])), o1 = g[1] * gelu_erf_grad(bf16hi(p[0]));
+        const float o2 = g[2] * gelu_erf_grad(bf16lo(p[1])), o3 = g[3] * gelu_erf_grad(bf16hi(p[1]));
+        reinterpret_cast<u32x2*>(out)[i] = u32x2{pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+    }
+}
+
 // One pass over the adapted layer's input x [M][K] (bf16): copy it into the first K columns of the K-concatenated operand
 // xcat [M][ldc] and, when the adapter has input dropout, write the masked copy xd [M][K] next to it (mask index r * K + c: the index
 // space of i2t_dropout_apply and of the residual + dropout GEMM epilogue that applies the same mask in backward).
@@ -51,6 +63,16 @@ extern "C" int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, voi
     hipLaunchKernelGGL(dgelu_mul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, dh,
                        (const bf16_t*)pre, (bf16_t*)out, n4);
     I2T_CHECK_LAUNCH("i2t_dgelu_mul");
+    return I2T_OK;
+}
+
+extern "C" int i2t_dgelu_erf_mul(void* stream, const float* dh, const void* pre, void* out, long n) {
+    I2T_REQUIRE(dh && pre && out && n > 0 && n % 4 == 0 && ALIGNED16(dh), "i2t_dgelu_erf_mul: bad args (n=%ld must be a multiple of 4)", n);
+    const long n4 = n >> 2;
+    const long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(dgelu_erf_mul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, dh,
+                       (const bf16_t*)pre, (bf16_t*)out, n4);
+    I2T_CHECK_LAUNCH("i2t_dgelu_erf_mul");
     return I2T_OK;
 }
 

@@ -228,8 +228,11 @@ class GreedyDecoder:
         else:
             self._layers_dense(st)
         if with_head:
-            if dc.llama is not None:
-                ops.rmsnorm_fwd(st.x, a.P(f'{dp}backbone.model.norm.weight'), st.hid, None, B, d, dc.llama.eps)
+            if dc.llama is not None and dc.llama.arch == 'falcon':
+                wn = dp + dc.llama.norm_f
+                ops.layernorm_fwd(st.x, a.P(wn + '.weight'), a.P(wn + '.bias'), st.hid, None, None, B, d, eps=dc.llama.eps)
+            elif dc.llama is not None:
+                ops.rmsnorm_fwd(st.x, a.P(dp + dc.llama.norm_f + '.weight'), st.hid, None, B, d, dc.llama.eps)
             else:
                 ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
             ops.gemm(st.hid, a.W(eng.n_head), st.logits, B, dc.V, d, workspace=st.ws)
@@ -290,6 +293,16 @@ class GreedyDecoder:
                 Wqkv, Wo, Wgu, Wdn = (eng.lora_merged(l, site, names) if eng._llama_lora(l, site) is not None else W for site, names, W in
                                       (('qkv', nm.qkv, v.Wqkv), ('o', nm.o, v.Wo), ('gu', nm.gu, v.Wgu), ('dn', nm.dn, v.Wdn)))
                 v = SimpleNamespace(**{**vars(v), 'Wqkv': Wqkv, 'Wo': Wo, 'Wgu': Wgu, 'Wdn': Wdn})
+            if ls.arch == 'falcon':        # n = LN(x);  x += dense(attn(rope(qkv(n)))) + W2 gelu(W1 n)   (engine_llama.falcon_block_fwd)
+                ops.layernorm_fwd(st.x, v.n1, v.b1, st.ln, None, None, B, d, eps=ls.eps)
+                ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, workspace=st.ws)
+                ops.rope(st.qkv, v.nq, 0, H + G, hd, cs, B, pos_ptr=pos_ptr)
+                ops.gq_decode_attention(st.qkv[:, :H * hd], st.qkv[:, H * hd:(H + G) * hd], st.qkv[:, (H + G) * hd:], st.kc[l], st.vc[l],
+                                        st.clen * G * hd, G * hd, st.ao, pos_ptr, 0, st.clen, B, H, G, hd)
+                ops.gemm(st.ao, v.Wo, st.x, B, d, H * hd, residual=st.x, workspace=st.ws)
+                ops.gemm(st.ln, v.Wgu, st.h, B, ff, d, act=ops.ACT_GELU_ERF)
+                ops.gemm(st.h, v.Wdn, st.x, B, d, ff, residual=st.x, workspace=st.ws)
+                continue
             ops.rmsnorm_fwd(st.x, v.n1, st.ln, None, B, d, ls.eps)
             ops.gemm(st.ln, v.Wqkv, st.qkv, B, v.nq, d, bias=v.bqkv, workspace=st.ws)
             ops.rope(st.qkv, v.nq, 0, H + G, hd, cs, B, pos_ptr=pos_ptr)

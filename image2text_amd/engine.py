@@ -309,7 +309,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             self.dcfg = dcfg = SimpleNamespace(skip_alternate_cross_attn=False, advanced_pos_emb_gate_sizes=None, n_layer=ls.L,
                                                transformer_config=SimpleNamespace(is_cross_attn=False))
             self.dec.lora = getattr(model.decoder, 'lora', None)              # LoRA adapters on the Llama / Qwen2 blocks (engine_llama._llama_lora)
-            self.n_wte = f'{self.dp}backbone.model.embed_tokens.weight'
+            self.n_wte = self.dp + ls.wte                                     # (Falcon: transformer.word_embeddings)
             self.n_head = self.n_wte if ls.tied else f'{self.dp}backbone.lm_head.weight'
         else:
             dac = dcfg.transformer_config.attn_config

@@ -33,8 +33,19 @@ class LlamaBlocks:
         if v is not None:
             return v
         a, ls = self.arena, self.dec.llama
-        p = f'{self.dp}backbone.model.layers.{l}'
         nq = ls.H * ls.hd + 2 * ls.Hkv * ls.hd
+        if ls.arch == 'falcon':          # ONE fused query_key_value [q heads | k | v], ONE LayerNorm (weight + bias), a two-matrix GELU MLP
+            p = f'{self.dp}backbone.transformer.h.{l}'
+            nm = SimpleNamespace(qkv=[f'{p}.self_attention.query_key_value.weight'], qkv_b=[], o=f'{p}.self_attention.dense.weight',
+                                 gu=[f'{p}.mlp.dense_h_to_4h.weight'], dn=f'{p}.mlp.dense_4h_to_h.weight',
+                                 n1=f'{p}.input_layernorm.weight', b1=f'{p}.input_layernorm.bias', n2=None)
+            v = SimpleNamespace(
+                nq=nq, Wqkv=a.W(nm.qkv[0]), Gqkv=a.G(nm.qkv[0]), bqkv=None, gbqkv=None, Wo=a.W(nm.o), Go=a.G(nm.o),
+                Wgu=a.W(nm.gu[0]), Ggu=a.G(nm.gu[0]), Wdn=a.W(nm.dn), Gdn=a.G(nm.dn), n1=a.P(nm.n1), gn1=a.G(nm.n1), b1=a.P(nm.b1),
+                gb1=a.G(nm.b1), names=nm)
+            self._sub_cache[key] = v
+            return v
+        p = f'{self.dp}backbone.model.layers.{l}'
         qkv_w = [f'{p}.self_attn.{x}_proj.weight' for x in 'qkv']
         qkv_b = [f'{p}.self_attn.{x}_proj.bias' for x in 'qkv']
         gu = [f'{p}.mlp.gate_proj.weight', f'{p}.mlp.up_proj.weight']
@@ -103,6 +114,7 @@ class LlamaBlocks:
     # the adapters of q | k | v (gate | up) share a stacked lora_A -- u = dropout(x) [A_q; A_k; A_v]^T -- and their B matrices sit
     # block-diagonally in the K panel (engine_lora._lora_panel); everything else is engine_lora's machinery.
     _LLAMA_SITES = {'qkv': ('q', 'k', 'v'), 'o': ('o',), 'gu': ('gate', 'up'), 'dn': ('down',)}
+    _FALCON_SITES = {'qkv': ('qkv',), 'o': ('o',), 'gu': ('fc',), 'dn': ('proj',)}      # query_key_value, dense, dense_h_to_4h, dense_4h_to_h
 
     def _llama_lora(self, l: int, site: str):
         lo = getattr(self.dec, 'lora', None)
@@ -114,9 +126,10 @@ class LlamaBlocks:
             a, ls = self.arena, self.dec.llama
             nA = f'{self.dp}lora_params.h{l}_{site}_A'
             K = a.entries[nA][2][1]
-            rows = {'q': ls.H * ls.hd, 'k': ls.Hkv * ls.hd, 'v': ls.Hkv * ls.hd, 'o': ls.d, 'gate': ls.ff, 'up': ls.ff, 'down': ls.d}
+            rows = {'q': ls.H * ls.hd, 'k': ls.Hkv * ls.hd, 'v': ls.Hkv * ls.hd, 'o': ls.d, 'gate': ls.ff, 'up': ls.ff, 'down': ls.d,
+                    'qkv': (ls.H + 2 * ls.Hkv) * ls.hd, 'fc': ls.ff, 'proj': ls.d}
             parts, row0, col0 = [], 0, 0
-            for t in self._LLAMA_SITES[site]:
+            for t in (self._FALCON_SITES if ls.arch == 'falcon' else self._LLAMA_SITES)[site]:
                 nB = f'{self.dp}lora_params.h{l}_{t}_B'
                 if nB in a.entries:
                     parts.append((row0, rows[t], col0, a.P(nB), a.G(nB)))
@@ -241,6 +254,98 @@ class LlamaBlocks:
             dn1 = dn
         ops.rmsnorm_bwd(dn1, sv.x, v.n1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, M, d, dx_accumulate=True, dx_bf16=dxb)
 
+    # ------------------------------------------------------------------------------------------------ one Falcon block
+    # transformers' FalconDecoderLayer with parallel_attn (falcon-7b):  n = LN(x);  y = x + dense(attn(rope(qkv(n)))) + W2 gelu(W1 n)
+    def falcon_block_fwd(self, l: int, x, B: int, T: int, pos_offset: int, save: bool, vl=None):
+        ls, v = self.dec.llama, self._llama_views(l)
+        M, d, H, G, hd, ff = (vl.total if vl is not None else B * T), ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
+        n1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
+        ops.layernorm_fwd(x, v.n1, v.b1, n1, m1, r1, M, d, eps=ls.eps)
+        plan = self.dec_drop if save else None
+        ldrop = (lambda site: plan.get(l, f'lora_{site}') if plan is not None else None)
+        lo = {site: self._llama_lora(l, site) for site in ('qkv', 'o', 'gu', 'dn')}
+        svlo = {}
+        qkv = self._empty(M, v.nq, dtype=BF16)
+        if lo['qkv'] is not None:
+            svlo['qkv'] = self._lora_gemm(lo['qkv'], n1, v.Wqkv, qkv, M, ldrop('qkv'), save)
+        else:
+            self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d)
+        ops.rope(qkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos=rpos, pos_offset=pos_offset, T=T)
+        q3 = v3(qkv, v.nq)
+        ao, lse = self._empty(M, H * hd, dtype=BF16), self._empty(H * M)
+        ops.gq_attention_fwd(q3[..., :H * hd], q3[..., H * hd:(H + G) * hd], q3[..., (H + G) * hd:], v3(ao, H * hd), lse,
+                             B, H, G, hd, T, T, True, cu_q=cu, cu_k=cu, total_q=M)
+        x1 = self._empty(M, d)
+        if lo['o'] is not None:
+            svlo['o'] = self._lora_gemm(lo['o'], ao, v.Wo, x1, M, ldrop('o'), save, residual=x)
+        else:
+            self._lin(ao, v.Wo, v.names.o, x1, M, d, H * hd, residual=x)
+        h, pre = self._empty(M, ff, dtype=BF16), (self._empty(M, ff, dtype=BF16) if save else None)
+        if lo['gu'] is not None:
+            svlo['gu'] = self._lora_gemm(lo['gu'], n1, v.Wgu, h, M, ldrop('gu'), save, act=ops.ACT_GELU_ERF, aux_out=pre)
+        else:
+            ops.gemm(n1, v.Wgu, h, M, ff, d, act=ops.ACT_GELU_ERF, aux_out=pre)
+        x2 = self._empty(M, d)
+        if lo['dn'] is not None:
+            svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1)
+        else:
+            self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
+        return x2, (SimpleNamespace(x=x, n1=n1, m1=m1, r1=r1, qkv=qkv, ao=ao, lse=lse, h=h, pre=pre, lo=svlo,
+                                    lo_drop={site: ldrop(site) for site in lo}) if save else None)
+
+    def falcon_block_bwd(self, l: int, sv, dx, dxb, B: int, T: int, pos_offset: int, vl=None):
+        """dx fp32 / dxb bf16: gradient w.r.t. the block output; on return both hold the gradient w.r.t. the block input"""
+        ls, v = self.dec.llama, self._llama_views(l)
+        M, d, H, G, hd, ff = (vl.total if vl is not None else B * T), ls.d, ls.H, ls.Hkv, ls.hd, ls.ff
+        cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
+        v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
+        tr = (lambda names: all(self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names)))
+        nm, svlo = v.names, sv.lo
+        gview = (lambda names, G_: G_ if tr(names) else None)
+
+        def lora_bwd(site, dY, x_in, W, names, G_):
+            return self._lora_bwd(self._llama_lora(l, site), svlo[site], dY, x_in, W, gview(names, G_), None, M, sv.lo_drop.get(site))
+        # ---- MLP branch: dn1 (fp32) = (dy W2 * gelu'(pre)) W1
+        dpre = self._empty(M, ff, dtype=BF16)
+        if 'dn' in svlo:
+            ops.dgelu_mul(lora_bwd('dn', dxb, sv.h, v.Wdn, nm.dn, v.Gdn), sv.pre, dpre, erf=True)
+        else:
+            if tr(nm.dn):
+                ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            ops.gemm(dxb, v.Wdn, dpre, M, ff, d, b_kmajor=True, act=ops.ACT_DGELU_ERF, aux_in=sv.pre)
+        if 'gu' in svlo:
+            dn1 = lora_bwd('gu', dpre, sv.n1, v.Wgu, nm.gu, v.Ggu)
+        else:
+            if tr(nm.gu):
+                ops.gemm(dpre, sv.n1, v.Ggu, ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            dn1 = self._empty(M, d)
+            ops.gemm(dpre, v.Wgu, dn1, M, d, ff, b_kmajor=True)
+        # ---- attention branch: both branches read the same LayerNorm output, their input gradients add up in dn1
+        dao = self._empty(M, H * hd, dtype=BF16)
+        if 'o' in svlo:
+            ops.cast_f32_bf16(lora_bwd('o', dxb, sv.ao, v.Wo, nm.o, v.Go), dao)
+        else:
+            if tr(nm.o):
+                ops.gemm(dxb, sv.ao, v.Go, d, H * hd, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            self._lin_dx(dxb, v.Wo, nm.o, dao, M, d, H * hd)
+        dqkv = self._empty(M, v.nq, dtype=BF16)
+        q3, g3 = v3(sv.qkv, v.nq), v3(dqkv, v.nq)
+        sl = (slice(0, H * hd), slice(H * hd, (H + G) * hd), slice((H + G) * hd, v.nq))
+        ops.gq_attention_bwd(q3[..., sl[0]], q3[..., sl[1]], q3[..., sl[2]], v3(sv.ao, H * hd), v3(dao, H * hd), sv.lse,
+                             self._empty(H * M), g3[..., sl[0]], g3[..., sl[1]], g3[..., sl[2]], B, H, G, hd, T, T, True,
+                             cu_q=cu, cu_k=cu, total_q=M)
+        ops.rope(dqkv, v.nq, 0, H + G, hd, self.rope_table(), M, pos=rpos, pos_offset=pos_offset, T=T, inverse=True)
+        if 'qkv' in svlo:
+            dn1.add_(lora_bwd('qkv', dqkv, sv.n1, v.Wqkv, nm.qkv, v.Gqkv))
+        else:
+            if tr(nm.qkv):
+                ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            ops.gemm(dqkv, v.Wqkv, dn1, M, d, v.nq, b_kmajor=True, residual=dn1)
+        ops.layernorm_bwd(dn1, sv.x, v.n1, sv.m1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, v.gb1 if tr(nm.b1) else None, M, d,
+                          dx_accumulate=True, dx_bf16=dxb)
+
     # ------------------------------------------------------------------------------------------------ the decoder stack
     def llama_decode_fwd(self, B: int, T: int, save: bool, ids, embeds, pos_offset: int, vl):
         """decode_segment for these decoders: (hidden fp32 [M, d] after the final norm, its bf16 copy, ctx)"""
@@ -256,13 +361,19 @@ class LlamaBlocks:
         else:
             x = embeds.to(device=a.device, dtype=F32).contiguous().view(M, d)
         saves, cur = [], x
+        block = self.falcon_block_fwd if ls.arch == 'falcon' else self.llama_block_fwd
         for l in range(dc.L):
-            cur, sv = self.llama_block_fwd(l, cur, B, T, pos_offset, save, vl)
+            cur, sv = block(l, cur, B, T, pos_offset, save, vl)
             saves.append(sv)
-        wn = a.P(f'{self.dp}backbone.model.norm.weight')
-        hid, hb, rf = self._empty(M, d), self._empty(M, d, dtype=BF16), self._empty(M)
-        ops.rmsnorm_fwd(cur, wn, hb, rf, M, d, ls.eps, y_f32=hid)
-        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, rf=rf, hb=hb, B=B, T=T, S=0, pos_offset=pos_offset, vl=vl, M=M,
+        wn = self.dp + ls.norm_f
+        hid, hb, rf, mf = self._empty(M, d), self._empty(M, d, dtype=BF16), self._empty(M), None
+        if ls.arch == 'falcon':          # ln_f: a LayerNorm; the fp32 output is what forward() returns, the bf16 copy feeds the head
+            mf = self._empty(M)
+            ops.layernorm_fwd(cur, a.P(wn + '.weight'), a.P(wn + '.bias'), hid, mf, rf, M, d, eps=ls.eps)
+            ops.cast_f32_bf16(hid, hb)
+        else:
+            ops.rmsnorm_fwd(cur, a.P(wn + '.weight'), hb, rf, M, d, ls.eps, y_f32=hid)
+        ctx = SimpleNamespace(ids=ids, saves=saves, xl=cur, rf=rf, mf=mf, hb=hb, B=B, T=T, S=0, pos_offset=pos_offset, vl=vl, M=M,
                               emb_drop=None, pos_ctx=None) if save else None
         return hid, hb, ctx
 
@@ -271,8 +382,13 @@ class LlamaBlocks:
         a, dc = self.arena, self.dec
         M, d = ctx.M, dc.d
         dx, dxb = self._empty(M, d), self._empty(M, d, dtype=BF16)
-        wn = f'{self.dp}backbone.model.norm.weight'
-        ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn), ctx.rf, dx, a.Gt(wn), M, d, dx_bf16=dxb)
+        ls = dc.llama
+        wn = self.dp + ls.norm_f
+        if ls.arch == 'falcon':
+            ops.layernorm_bwd(dh, ctx.xl, a.P(wn + '.weight'), ctx.mf, ctx.rf, dx, a.Gt(wn + '.weight'), a.Gt(wn + '.bias'), M, d, dx_bf16=dxb)
+        else:
+            ops.rmsnorm_bwd(dh, ctx.xl, a.P(wn + '.weight'), ctx.rf, dx, a.Gt(wn + '.weight'), M, d, dx_bf16=dxb)
+        block = self.falcon_block_bwd if ls.arch == 'falcon' else self.llama_block_bwd
         for l in reversed(range(dc.L)):
-            self.llama_block_bwd(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset, ctx.vl)
+            block(l, ctx.saves[l], dx, dxb, ctx.B, ctx.T, ctx.pos_offset, ctx.vl)
         return dx

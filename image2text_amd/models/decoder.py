@@ -51,11 +51,10 @@ class Decoder(nn.Module, abc.ABC):
                 return Llama2HuggingfaceDecoder(config)
             if 'Qwen' in config.model_str:                             # reference decoder.py:126-127
                 return Qwen2HuggingfaceDecoder(config)
-            # (Falcon: the reference's own wrapper reads ``backbone.model.embed_tokens`` (decoder.py:390-393), which neither transformers'
-            # FalconForCausalLM nor its LoraModel wrapping has -- ``transformer.word_embeddings`` -- so its soft-prompt path, the only one
-            # gpu/falcon-7b.yaml uses, cannot run as written; there is no behaviour to be a drop-in for)
-            raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: GPT-2, Llama-2 and Qwen2 checkpoints run on the HIP hot '
-                                      'path; Falcon blocks and free-form AutoModelForCausalLM architectures do not (SURVEY.md 8(f) next #3)')
+            if config.model_str.startswith('tiiuae/falcon'):           # reference decoder.py:122-123
+                return FalconHuggingfaceDecoder(config)
+            raise NotImplementedError(f'HuggingfaceDecoder {config.model_str!r}: GPT-2, Falcon, Llama-2 and Qwen2 checkpoints run on the HIP '
+                                      'hot path; free-form AutoModelForCausalLM architectures do not (SURVEY.md 8(f) next #3)')
         raise ValueError('Unknown config type!!!')
 
     @staticmethod
@@ -412,8 +411,28 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         self.config = config
         self.use_cross_attn = False
         hf = AutoModelForCausalLM.from_pretrained(config.model_str)
-        hc = self.hf_config = hf.config
+        self.hf_config = hf.config
         hf.resize_token_embeddings(config.vocab_size + config.extra_tokens)
+        spec = self._inspect(hf, config)              # raises NotImplementedError for checkpoints outside the hot path
+        if config.enable_gradient_checkpointing:
+            pass            # the hot path keeps what its hand-written backward needs; nothing to switch on (decoder.py:322-323)
+        self.backbone = hf
+        if config.prepare_for_kbit_training:
+            _freeze_like_prepare_for_kbit_training(self)
+        self.lora = None
+        self._register_state_dict_hook(self._to_peft_keys)
+        self._register_load_state_dict_pre_hook(self._from_peft_keys)
+        if config.lora_spec is not None:
+            self._apply_lora(config.lora_spec)
+            from .utils import register_decoder_name_aliases
+            register_decoder_name_aliases(self.reference_parameter_names())
+        self.llama_spec = spec
+
+    # transformers attribute paths under ``backbone`` (the Falcon subclass has its own)
+    _BLOCKS, _ROTARY = 'model.layers', 'model.rotary_emb'
+
+    def _inspect(self, hf, config):
+        hc = hf.config
         hd = getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads
         attn0 = hf.model.layers[0].self_attn
         problems = [msg for bad, msg in (
@@ -432,22 +451,11 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         ) if bad]
         if problems:
             raise NotImplementedError(f'{hc.model_type} checkpoint outside the HIP hot path: ' + '; '.join(problems))
-        if config.enable_gradient_checkpointing:
-            pass            # the hot path keeps what its hand-written backward needs; nothing to switch on (decoder.py:322-323)
-        self.backbone = hf
-        if config.prepare_for_kbit_training:
-            _freeze_like_prepare_for_kbit_training(self)
-        self.lora = None
-        self._register_state_dict_hook(self._to_peft_keys)
-        self._register_load_state_dict_pre_hook(self._from_peft_keys)
-        if config.lora_spec is not None:
-            self._apply_lora(config.lora_spec)
-            from .utils import register_decoder_name_aliases
-            register_decoder_name_aliases(self.reference_parameter_names())
-        self.llama_spec = SimpleNamespace(
-            d=hc.hidden_size, H=hc.num_attention_heads, Hkv=hc.num_key_value_heads, hd=hd, L=hc.num_hidden_layers,
+        return SimpleNamespace(
+            arch='llama', d=hc.hidden_size, H=hc.num_attention_heads, Hkv=hc.num_key_value_heads, hd=hd, L=hc.num_hidden_layers,
             ff=hc.intermediate_size, V=config.vocab_size + config.extra_tokens, eps=float(hc.rms_norm_eps), block=self.block_size,
-            qkv_bias=attn0.q_proj.bias is not None, tied=hf.lm_head.weight is hf.model.embed_tokens.weight)
+            qkv_bias=attn0.q_proj.bias is not None, tied=hf.lm_head.weight is hf.model.embed_tokens.weight,
+            wte='backbone.model.embed_tokens.weight', norm_f='backbone.model.norm')
 
     # -- LoRA (reference models/utils.py:46-65 -> peft LoraModel over the transformers module; decoder.py:404-440 reads the embedding
     #    through it: backbone.model.model.embed_tokens) ---------------------------------------------------------------------------
@@ -469,19 +477,15 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         import fnmatch
         import math
         hc = self.hf_config
-        targets = list(spec.target_modules) if spec.target_modules else ['q_proj', 'v_proj']
+        targets = list(spec.target_modules) if spec.target_modules else list(self._LORA_DEFAULT_TARGETS)
         linears = [m for ms in self._LORA_SITES.values() for m in ms]
         match = (lambda key, t: key == t or key.endswith('.' + t))
-        hit = [m for m in linears if any(match(f'model.layers.0.{m}', t) for t in targets)]
-        other = [t for t in targets if not any(match(f'model.layers.0.{m}', t) for m in linears)]
+        hit = [m for m in linears if any(match(f'{self._BLOCKS}.0.{m}', t) for t in targets)]
+        other = [t for t in targets if not any(match(f'{self._BLOCKS}.0.{m}', t) for m in linears)]
         if other or not hit:
             raise NotImplementedError(f'LoRA target_modules {targets}: the HIP hot path adapts the block linears {linears} '
                                       f'(unsupported here: {other or "no module matched"})')
-        hd = getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads
-        d, ff = hc.hidden_size, hc.intermediate_size
-        shapes = {'self_attn.q_proj': (d, hc.num_attention_heads * hd), 'self_attn.k_proj': (d, hc.num_key_value_heads * hd),
-                  'self_attn.v_proj': (d, hc.num_key_value_heads * hd), 'self_attn.o_proj': (hc.num_attention_heads * hd, d),
-                  'mlp.gate_proj': (d, ff), 'mlp.up_proj': (d, ff), 'mlp.down_proj': (ff, d)}
+        shapes = self._lora_shapes()
         sites = {site: [m for m in ms if m in hit] for site, ms in self._LORA_SITES.items()}
         sites = {site: ms for site, ms in sites.items() if ms}
         if not 0 < spec.r or max(len(ms) for ms in sites.values()) * spec.r > 128:
@@ -507,6 +511,17 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
             else:
                 p.requires_grad = every or (pats is not None and any(fnmatch.fnmatch(self._peft_name(name), pat) for pat in pats))
 
+    _LORA_DEFAULT_TARGETS = ('q_proj', 'v_proj')           # peft's TRANSFORMERS_MODELS_TO_LORA_TARGET_MODULES_MAPPING for llama / qwen2
+
+    def _lora_shapes(self):
+        """{linear: (in features, out features)}"""
+        hc = self.hf_config
+        hd = getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads
+        d, ff = hc.hidden_size, hc.intermediate_size
+        return {'self_attn.q_proj': (d, hc.num_attention_heads * hd), 'self_attn.k_proj': (d, hc.num_key_value_heads * hd),
+                'self_attn.v_proj': (d, hc.num_key_value_heads * hd), 'self_attn.o_proj': (hc.num_attention_heads * hd, d),
+                'mlp.gate_proj': (d, ff), 'mlp.up_proj': (d, ff), 'mlp.down_proj': (ff, d)}
+
     def _peft_name(self, internal: str) -> str:
         """own parameter name ``backbone.<transformers name>`` -> the LoraModel's: ``model.<name>``, ``base_layer`` inside adapted linears"""
         key = internal[len('backbone.'):]
@@ -519,7 +534,7 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         """``lora_params.h{l}_{x}_{A|B}`` -> [(peft key under ``backbone.``, row slice | None)]"""
         l, rest = name[len('lora_params.h'):].split('_', 1)
         x, ab = rest.rsplit('_', 1)
-        base = f'model.model.layers.{l}.'
+        base = f'model.{self._BLOCKS}.{l}.'
         if ab == 'B':
             m = {v: k for k, v in self._LORA_TAGS.items()}[x]
             return [(f'{base}{m}.lora_B.default.weight', None)]
@@ -554,11 +569,13 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
             return
         bb = prefix + 'backbone.'
         stacks = {}
-        for k in [k for k in sd if k.startswith((bb + 'model.model.', bb + 'model.lm_head.'))]:      # a LoraModel's keys; plain transformers keys pass
+        top = self._BLOCKS.split('.')[0]                 # 'model' (Llama / Qwen2) | 'transformer' (Falcon)
+        depth = self._BLOCKS.count('.') + 1
+        for k in [k for k in sd if k.startswith((f'{bb}model.{top}.', bb + 'model.lm_head.'))]:      # a LoraModel's keys; plain transformers keys pass
             v, name = sd.pop(k), k[len(bb) + len('model.'):]
             if '.lora_A.' in name or '.lora_B.' in name:
                 mod, rest = name.split('.lora_')
-                l, m = mod.split('.')[2], mod.split('.', 3)[3]
+                l, m = mod.split('.')[depth], mod.split('.', depth + 1)[depth + 1]
                 if rest[0] == 'B':
                     sd[f'{prefix}lora_params.h{l}_{self._LORA_TAGS[m]}_B'] = v
                 else:
@@ -573,7 +590,7 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
     def rope_table(self, n_positions: int) -> torch.Tensor:
         """fp32 [n_positions, head_dim] = [cos(p f_i) | sin(p f_i)], i < head_dim / 2: the values the checkpoint's own rotary module
         produces (whatever its rope type and scaling), in the layout of i2t_rope"""
-        rot = self.backbone.model.rotary_emb
+        rot = self.backbone.get_submodule(self._ROTARY)
         dev = rot.inv_freq.device
         with torch.no_grad():
             cos, sin = rot(torch.zeros(1, 1, dtype=torch.float32, device=dev), torch.arange(n_positions, device=dev)[None])
@@ -593,6 +610,65 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
     @property
     def n_embd(self):
         return self.hf_config.hidden_size
+
+
+class FalconHuggingfaceDecoder(_LlamaFamilyHuggingfaceDecoder):
+    """``tiiuae/falcon*`` checkpoints (reference decoder.py:383-400) of the falcon-7b architecture: parallel attention + MLP behind ONE
+    LayerNorm, multi-query attention (71 query heads on one key/value head), rotary embedding, exact GELU, no biases.  Same container
+    as the Llama-2 / Qwen2 plugins (the transformers module owns the parameters, engine_llama runs the arithmetic).
+
+    What the reference does with it: the id-driven ``forward`` (decoder.py:332-361) works -- that is what the parity test matches
+    against transformers' FalconForCausalLM; its ``get_inputs_embeds`` reads ``backbone.model.embed_tokens`` (decoder.py:389-392), an
+    attribute FalconForCausalLM does not have (``transformer.word_embeddings``), so a soft prompt -- the mode gpu/falcon-7b.yaml asks
+    for -- raises AttributeError there.  Here it returns the word embeddings, which is what that code path can only have meant."""
+    _BLOCKS, _ROTARY = 'transformer.h', 'transformer.rotary_emb'
+    _LORA_SITES = {'qkv': ('self_attention.query_key_value',), 'o': ('self_attention.dense',), 'gu': ('mlp.dense_h_to_4h',),
+                   'dn': ('mlp.dense_4h_to_h',)}
+    _LORA_TAGS = {'self_attention.query_key_value': 'qkv', 'self_attention.dense': 'o', 'mlp.dense_h_to_4h': 'fc', 'mlp.dense_4h_to_h': 'proj'}
+    _LORA_DEFAULT_TARGETS = ('query_key_value',)           # peft's default for falcon
+
+    def __init__(self, config: HuggingfaceDecoderConfig):
+        assert config.model_str.startswith('tiiuae/falcon')
+        assert config.vocab_size >= 65024
+        super().__init__(config)
+
+    def _inspect(self, hf, config):
+        hc = hf.config
+        hd = hc.hidden_size // hc.num_attention_heads
+        problems = [msg for bad, msg in (
+            (hc.model_type != 'falcon', f'model_type {hc.model_type!r}'),
+            (hc.new_decoder_architecture, 'new_decoder_architecture (falcon-40b / 180b blocks)'),
+            (not hc.parallel_attn, 'sequential attention + MLP (falcon-rw blocks)'),
+            (not hc.multi_query, 'multi_query off'),
+            (hc.alibi, 'alibi positions'),
+            (hc.bias, 'linear biases'),
+            (getattr(hc, 'activation', 'gelu') != 'gelu', f'activation {getattr(hc, "activation", None)!r}'),
+            (float(hc.hidden_dropout) != 0.0 or float(hc.attention_dropout) != 0.0, 'hidden / attention dropout > 0'),
+            (hd not in (16, 32, 64, 128), f'head_dim {hd}'),
+            (hc.hidden_size % 8 != 0, 'hidden size not a multiple of 8'),
+        ) if bad]
+        if problems:
+            raise NotImplementedError('Falcon checkpoint outside the HIP hot path: ' + '; '.join(problems))
+        return SimpleNamespace(
+            arch='falcon', d=hc.hidden_size, H=hc.num_attention_heads, Hkv=1, hd=hd, L=hc.num_hidden_layers,
+            ff=getattr(hc, 'ffn_hidden_size', None) or 4 * hc.hidden_size, V=config.vocab_size + config.extra_tokens,
+            eps=float(hc.layer_norm_epsilon), block=self.block_size, qkv_bias=False,
+            tied=hf.lm_head.weight is hf.transformer.word_embeddings.weight,
+            wte='backbone.transformer.word_embeddings.weight', norm_f='backbone.transformer.ln_f')
+
+    def _lora_shapes(self):
+        hc = self.hf_config
+        d, hd = hc.hidden_size, hc.hidden_size // hc.num_attention_heads
+        ff = getattr(hc, 'ffn_hidden_size', None) or 4 * d
+        return {'self_attention.query_key_value': (d, d + 2 * hd), 'self_attention.dense': (d, d), 'mlp.dense_h_to_4h': (d, ff),
+                'mlp.dense_4h_to_h': (ff, d)}
+
+    def get_inputs_embeds(self, idx: torch.LongTensor):
+        return self.backbone.transformer.word_embeddings(idx)
+
+    @property
+    def block_size(self):
+        return 2048                                        # reference decoder.py:394-396
 
 
 class Llama2HuggingfaceDecoder(_LlamaFamilyHuggingfaceDecoder):

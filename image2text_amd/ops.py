@@ -373,11 +373,14 @@ def swiglu_bwd(dh, gate_up, d_gate_up, M, ff):
     return d_gate_up
 
 
-def dgelu_mul(dh, pre, out):
-    """out (bf16) = dh (fp32) * gelu_tanh'(pre (bf16)), contiguous  (include/i2t.h::i2t_dgelu_mul)"""
+def dgelu_mul(dh, pre, out, erf=False):
+    """out (bf16) = dh (fp32) * gelu'(pre (bf16)), contiguous; tanh form (include/i2t.h::i2t_dgelu_mul) or exact (i2t_dgelu_erf_mul)"""
     _need_cuda(dh, pre, out)
     assert dh.dtype == F32 and pre.dtype == BF16 and out.dtype == BF16 and dh.is_contiguous() and pre.is_contiguous() and out.is_contiguous()
-    _l.check(_lib().i2t_dgelu_mul(_stream(), _p(dh), _p(pre), _p(out), dh.numel()), 'i2t_dgelu_mul')
+    if erf:
+        _l.check(_lib().i2t_dgelu_erf_mul(_stream(), _p(dh), _p(pre), _p(out), dh.numel()), 'i2t_dgelu_erf_mul')
+    else:
+        _l.check(_lib().i2t_dgelu_mul(_stream(), _p(dh), _p(pre), _p(out), dh.numel()), 'i2t_dgelu_mul')
     return out
 
 

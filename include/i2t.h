@@ -415,6 +415,8 @@ int i2t_swiglu_bwd(void* stream, const void* dh, const void* gate_up, int ld, vo
  * are i2t_gemm_bf16 calls (rank padded to 64 by zero rows), the input dropout is i2t_dropout_apply; this is the GELU derivative behind
  * an adapted mlp.c_proj, whose input gradient is the fp32 sum of the base and adapter paths: out (bf16) = dh (fp32) * gelu_tanh'(pre). */
 int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, void* out, long n);
+/* ... and behind an exact (erf) GELU (transformers' Falcon MLP, nn.GELU()): out = dh * gelu_erf'(pre). */
+int i2t_dgelu_erf_mul(void* stream, const float* dh, const void* pre, void* out, long n);
 /* One pass over an adapted layer's input x bf16 [M][K]: xcat[m][0..K) = x[m] (xcat bf16 [M][ldc] is the K-concatenated operand
  * [x | u] of the layer's GEMM) and, when xd is not null, xd [M][K] = dropout(x) with the elementwise mask (key, thr, scale; index
  * m * K + k, the index space of i2t_dropout_apply) -- the adapter's input (peft's lora_dropout). */

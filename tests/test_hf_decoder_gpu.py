@@ -502,6 +502,153 @@ def test_llama_family_decoder_lora(tmp_path, monkeypatch, kind, p_lora):
         assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# FalconHuggingfaceDecoder (reference decoder.py:122-123, 383-400; gpu/falcon-7b.yaml): parallel attention + MLP behind one LayerNorm,
+# multi-query attention, rotary embedding, exact GELU.  Checker: transformers' FalconForCausalLM on the CPU in fp32 (+ the restated peft
+# layer for LoRA).  'ids' is the mode the reference itself can run (decoder.py:352-361: the decoder sees token ids only); 'soft' is the
+# mode its yaml asks for and its get_inputs_embeds cannot deliver (models/decoder.py FalconHuggingfaceDecoder docstring).
+# ------------------------------------------------------------------------------------------------------------------------------
+def test_falcon_decoder_id_driven_forward_matches_transformers(tmp_path, monkeypatch):
+    """``Decoder.from_config(cfg)(idx=ids) -> (logits, hidden_states[-1])``: the call the reference's FalconHuggingfaceDecoder can make
+    (decoder.py:332-361; inside a VisionEncoderDecoder the model needs cross-attention or a soft prompt, vision_encoder_decoder.py:38-39, and
+    Falcon has neither there), against transformers' FalconForCausalLM(input_ids=ids)."""
+    import copy
+    from image2text_amd.models.decoder import Decoder
+    from test_host_cpu import _local_hf_falcon
+    _, name, vocab = _local_hf_falcon(tmp_path, monkeypatch)
+    dec = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1))
+    hf = copy.deepcopy(dec.backbone).float().eval()
+    dec = dec.to(dev()).eval()
+    g = torch.Generator().manual_seed(5)
+    for B, T in ((3, 12), (2, 100)):                    # (100 rows: several key tiles per head in the grouped attention kernel)
+        ids = torch.randint(0, vocab + 1, (B, T), generator=g)
+        logits, hidden = dec(idx=ids.to(dev()))
+        with torch.no_grad():
+            out = hf(input_ids=ids, output_hidden_states=True)
+        for name_, got, ref, tol in (('logits', logits, out.logits, 1.25e-2), ('hidden', hidden, out.hidden_states[-1], 1.5e-2)):
+            diff = got.float().cpu() - ref
+            err, scale_ = float(diff.abs().max()), max(1.0, float(ref.abs().max()))
+            REPORT[f'hf_falcon.ids.T{T}.{name_}'] = {'max_abs_err': err, 'tol': tol * scale_, 'rel_l2': float(diff.norm() / ref.norm())}
+            assert err <= tol * scale_, (name_, T, err, tol * scale_)
+
+
+@pytest.mark.parametrize('mode', ['soft', 'soft_lora'])
+def test_falcon_decoder_forward_gradients_generate(tmp_path, monkeypatch, mode):
+    import copy
+    from oracle import reference_model as orc
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from test_host_cpu import _local_hf_falcon
+    tag = f'hf_falcon.{mode}'
+    _, name, vocab = _local_hf_falcon(tmp_path, monkeypatch)
+    V, soft = vocab + 1, mode != 'ids'
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=0.0, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h'],
+                    force_enable_update_modules=['*.word_embeddings.*', '*.lm_head.*']) if mode == 'soft_lora' else None      # gpu/falcon-7b.yaml:55-60
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec),
+                                     use_cross_attn=False, use_soft_prompting=soft))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    m.decoder.tie_weights()
+    dec = m.decoder
+    wraps = {}
+    if spec is not None:
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(9)
+            for n, p in dec.lora_params.items():
+                if n.endswith('_B'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    hf = copy.deepcopy(dec.backbone).float().eval()
+    if spec is not None:
+        sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+        for l in range(2):
+            for site, members in dec.lora.members.items():
+                for mod_path in members:
+                    parent_name, leaf = mod_path.split('.')
+                    parent = getattr(hf.transformer.h[l], parent_name)
+                    key = f'backbone.model.transformer.h.{l}.{mod_path}.lora_'
+                    w = _LoraLinear(getattr(parent, leaf), sd[key + 'A.default.weight'], sd[key + 'B.default.weight'], dec.lora.scale)
+                    setattr(parent, leaf, w)
+                    wraps[(l, site, mod_path)] = w
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    m = m.to(dev()).train()
+    eng = m._engine
+    assert eng.dec.llama.arch == 'falcon' and eng.dec.prefixed == soft and not eng.cross_inputs
+    images, labels = synthetic_batch(3, 32, 12, V, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls if soft else 0
+
+    def reference(ids_):
+        enc = orc.encode(esd, cfg, images, training=False)
+        if soft:
+            out = hf(inputs_embeds=torch.cat((enc, hf.transformer.word_embeddings(ids_)), dim=-2), output_hidden_states=True)
+        else:
+            out = hf(input_ids=ids_, output_hidden_states=True)             # reference decoder.py:352-361
+        return enc, out.logits[..., n_p:, :], out.hidden_states[-1]
+    gg = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, 256, generator=gg) * 0.05
+    wl = torch.randn(3, 12, V, generator=gg) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    enc, ologits, ohid = reference(ids)
+    for name_, got, ref, tol in (('logits', out.logits, ologits, 1.25e-2), ('hidden', out.hidden_state, ohid, 1.5e-2),
+                                 ('encoder_output', out.encoder_output, enc, 1e-2)):
+        diff = got.float().cpu() - ref.detach()
+        err, scale_ = float(diff.abs().max()), max(1.0, float(ref.detach().abs().max()))
+        REPORT[f'{tag}.{name_}'] = {'max_abs_err': err, 'tol': tol * scale_, 'rel_l2': float(diff.norm() / ref.detach().norm())}
+        assert err <= tol * scale_, (name_, err, tol * scale_)
+    ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.backbone.' + k.replace('.base.', '.'): p.grad for k, p in hf.named_parameters()
+                      if not (k.endswith('.A') or k.endswith('.B'))})
+    for (l, site, mp), w in wraps.items():
+        ref_grads[f'decoder.lora_params.h{l}_{site}_A'] = w.A.grad
+        ref_grads[f'decoder.lora_params.h{l}_{dec._LORA_TAGS[mp]}_B'] = w.B.grad
+    fails, checked = [], 0
+    for name_, p in m.named_parameters():
+        if name_ in frozen:
+            assert p.grad is None, f'{name_} is frozen but received a gradient'
+            continue
+        if not soft and not name_.startswith('decoder.'):        # the decoder never saw the image: nothing flows back to the encoder
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name_
+            continue
+        checked += 1
+        try:
+            grad_close(f'{tag}.{name_}', p.grad, ref_grads[name_].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert checked >= 12 and not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    # generation on the KV cache (merged adapter weights under LoRA) against greedy decoding by full forwards
+    m.eval()
+    tok = fake_tokenizer(V)
+    with torch.no_grad():
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = m.generate(images.to(dev()), prompt, max_new_tokens=10, temperature=1.0, top_k=1)
+        cur, agree, total = prompt, 0, 0
+        for t in range(10):
+            lg = m(images=images.to(dev()), ids=cur).logits[:, -1].float().cpu()
+            lg = orc.apply_ngram_ban(cur.cpu(), lg, cfg.no_repeat_n_grams)
+            top2 = lg.topk(2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 3e-2 * lg[torch.isfinite(lg)].abs().max().clamp(min=1.0)
+            same_prefix = (gen[:, :cur.shape[1]].cpu() == cur.cpu()).all(dim=1)
+            ok = gen[:, cur.shape[1]].cpu() == lg.argmax(-1)
+            agree += int((ok & clear & same_prefix).sum())
+            total += int((clear & same_prefix).sum())
+            cur = torch.cat((cur, lg.argmax(-1, keepdim=True).to(dev())), dim=1)
+        REPORT[f'{tag}.generate_vs_forward'] = {'agree': agree, 'of': total}
+        assert total >= 8 and agree == total, (agree, total)
+        _, l0, _ = reference(prompt.cpu())
+        l0 = l0[:, -1].detach()
+        t2 = l0.topk(2, dim=-1).values
+        sure = (t2[:, 0] - t2[:, 1]) > 3e-2 * l0.abs().max()
+        assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
+
+
 def test_llama_decoder_frozen_by_prepare_for_kbit_training(tmp_path, monkeypatch):
     """prepare_for_kbit_training: True without 4-bit loading (reference local/llama2-7b.yaml; peft freezes the base model): no decoder
     parameter receives a gradient, the weight-gradient GEMMs are skipped, and the encoder's gradients -- through the soft prompt rows of

@@ -340,8 +340,8 @@ def test_gpt2_huggingface_decoder_plugin(tmp_path, monkeypatch):
     # refusals
     with pytest.raises(NotImplementedError, match='4-bit'):
         Decoder.from_config(_hf_decoder_config(load_in_4bit=True))
-    with pytest.raises(NotImplementedError, match='Falcon'):
-        Decoder.from_config(_hf_decoder_config(name='tiiuae/falcon-7b', vocab_size=65024))
+    with pytest.raises(NotImplementedError, match='free-form'):
+        Decoder.from_config(_hf_decoder_config(name='mistralai/Mistral-7B', vocab_size=32000))
     hf_relu = _local_hf_gpt2(tmp_path, monkeypatch, name='gpt2-relu', activation_function='relu')
     with pytest.raises(NotImplementedError, match='activation'):
         Decoder.from_config(_hf_decoder_config(name='gpt2-relu'))
@@ -500,8 +500,70 @@ def test_llama_qwen2_huggingface_decoder_plugins(tmp_path, monkeypatch):
             Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=extra, use_cross_attn=True))
     with pytest.raises(AssertionError):
         Decoder.from_config(_hf_decoder_config(name='meta-llama/Llama-2-tiny', vocab_size=1000))          # 'vocab should not shrink' (decoder.py:407)
-    with pytest.raises(NotImplementedError, match='Falcon'):
-        Decoder.from_config(_hf_decoder_config(name='tiiuae/falcon-7b', vocab_size=65024))
+
+
+def _local_hf_falcon(tmp_path, monkeypatch, **cfg_kw):
+    """a randomly initialised 2-layer checkpoint of the falcon-7b architecture (parallel attention + MLP, multi-query, rotary, no
+    biases) in a local directory whose name satisfies the reference's dispatch (decoder.py:122-123, 385-386: 'tiiuae/falcon*', vocab >= 65024)"""
+    from transformers import FalconConfig, FalconForCausalLM
+    torch.manual_seed(11)
+    name, vocab = 'tiiuae/falcon-tiny', 65024
+    args = dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, vocab_size=vocab, multi_query=True, parallel_attn=True,
+                new_decoder_architecture=False, bias=False, alibi=False, max_position_embeddings=128)
+    args.update(cfg_kw)
+    hf = FalconForCausalLM(FalconConfig(**args))
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if 'layernorm' in n_ or 'ln_f' in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    hf.save_pretrained(str(tmp_path / name))
+    monkeypatch.chdir(tmp_path)
+    return hf.eval(), name, vocab
+
+
+def test_falcon_huggingface_decoder_plugin(tmp_path, monkeypatch):
+    """FalconHuggingfaceDecoder (reference decoder.py:122-123, 383-400): the transformers module is the parameter container, the spec
+    the engine reads describes the falcon-7b block, LoRA on the targets of gpu/falcon-7b.yaml:55-60 with its force-enable patterns, the
+    LoraModel-keyed state dict; architectures of the family the hot path does not run are refused by name."""
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.decoder import FalconHuggingfaceDecoder
+    hf, name, vocab = _local_hf_falcon(tmp_path, monkeypatch)
+    d = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1))
+    assert isinstance(d, FalconHuggingfaceDecoder) and d.n_embd == 256 and d.block_size == 2048
+    ls = d.llama_spec
+    assert (ls.arch, ls.H, ls.Hkv, ls.hd, ls.L, ls.ff, ls.V, ls.tied) == ('falcon', 4, 1, 64, 2, 1024, vocab + 1, True)
+    sd, sh = d.state_dict(), hf.state_dict()
+    assert set(sd) == {'backbone.' + k for k in sh} and all(torch.equal(sd['backbone.' + k][:v.shape[0]], v) for k, v in sh.items())
+    assert d.get_inputs_embeds(torch.tensor([[1, 2]])).shape == (1, 2, 256)           # (the reference raises AttributeError here)
+    tab = d.rope_table(16)
+    cos, sin = hf.transformer.rotary_emb(torch.zeros(1, 1), torch.arange(16)[None])
+    assert tab.shape == (16, 64) and torch.equal(tab[:, :32], cos[0, :, :32]) and torch.equal(tab[:, 32:], sin[0, :, 32:])
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=0.1, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h'],
+                    force_enable_update_modules=['*.word_embeddings.*', '*.lm_head.*'])
+    dl = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec))
+    assert dl.lora.sites == ('qkv', 'o', 'gu', 'dn')
+    sdl = dl.state_dict()
+    p_ = 'backbone.model.transformer.h.1.'
+    for k, shp in {p_ + 'self_attention.query_key_value.base_layer.weight': (384, 256), p_ + 'self_attention.query_key_value.lora_A.default.weight': (4, 256),
+                   p_ + 'self_attention.query_key_value.lora_B.default.weight': (384, 4), p_ + 'self_attention.dense.lora_B.default.weight': (256, 4),
+                   p_ + 'mlp.dense_h_to_4h.lora_B.default.weight': (1024, 4), p_ + 'mlp.dense_4h_to_h.lora_A.default.weight': (4, 1024),
+                   p_ + 'input_layernorm.bias': (256,), 'backbone.model.transformer.word_embeddings.weight': (vocab + 1, 256),
+                   'backbone.model.lm_head.weight': (vocab + 1, 256)}.items():
+        assert k in sdl and tuple(sdl[k].shape) == shp, k
+    on = {n for n, p in dl.named_parameters() if p.requires_grad}
+    assert on == {n for n, _ in dl.named_parameters() if n.startswith('lora_params.')} | {'backbone.transformer.word_embeddings.weight'}
+    d2 = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec))
+    d2.load_state_dict(sdl, strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(dl.parameters(), d2.parameters()))
+    missing, unexpected = d2.load_state_dict(sd, strict=False)
+    assert not unexpected and missing and all('lora_' in k for k in missing)
+    with pytest.raises(ValueError, match='cross attention'):
+        Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, use_cross_attn=True))
+    with pytest.raises(NotImplementedError, match='4-bit'):              # gpu/falcon-7b.yaml loads in 4 bits (bitsandbytes: not in this image)
+        Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, load_in_4bit=True))
+    _local_hf_falcon(tmp_path, monkeypatch, alibi=True)
+    with pytest.raises(NotImplementedError, match='alibi'):
+        Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab))
 
 
 def test_llama_qwen2_huggingface_decoder_lora(tmp_path, monkeypatch):

@@ -4,7 +4,7 @@
 the pieces this image cannot load: torchvision's pretrained ViT-B/16 -> the nano-224 from-scratch ViT; peft LoRA -> every parameter
 trains).
 
-    python tools/bench_hf_decoder.py [--size gpt2|gpt2-medium|qwen2-1.5b|llama2-7b|llama2-tiny] [--batch 1024] [--steps 6] [--warmup 2]
+    python tools/bench_hf_decoder.py [--size gpt2|gpt2-medium|qwen2-1.5b|llama2-7b|llama2-tiny|falcon-7b] [--lora] [--batch 1024] [--steps 6] [--warmup 2]
                                      [--decode-batch 1024] [--cpu]
 
 There is no network: the 'checkpoint' is a randomly initialised model of the named shape written to a scratch directory and loaded
@@ -34,6 +34,9 @@ LLAMA_SIZES = {      # name -> (checkpoint directory name satisfying decoder.py:
     'llama2-7b': ('meta-llama/Llama-2-7b-random', 'LlamaConfig', dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
                                                                       num_attention_heads=32, num_key_value_heads=32,
                                                                       max_position_embeddings=4096, rms_norm_eps=1e-5), 32000),
+    'falcon-7b': ('tiiuae/falcon-7b-random', 'FalconConfig', dict(hidden_size=4544, num_hidden_layers=32, num_attention_heads=71, multi_query=True,
+                                                                   parallel_attn=True, new_decoder_architecture=False, bias=False, alibi=False,
+                                                                   max_position_embeddings=2048), 65024),
     'llama2-tiny': ('meta-llama/Llama-2-tiny-random', 'LlamaConfig', dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=8,
                                                                           num_attention_heads=8, num_key_value_heads=8,
                                                                           max_position_embeddings=4096, rms_norm_eps=1e-5), 32000),
@@ -89,8 +92,16 @@ def main():
         t_init = time.perf_counter()
         transformers.AutoModelForCausalLM.from_config(hf_cfg, dtype=torch.bfloat16 if big else torch.float32).save_pretrained(name)
         print(f'[bench_hf_decoder] random checkpoint written in {time.perf_counter() - t_init:.0f} s', file=sys.stderr, flush=True)
+        lora = None
+        if args.lora:            # the lora_spec of the reference's gpu/falcon-7b.yaml:55-60 / gpu/llama2-13b.yaml:35-39
+            from image2text_amd.configs.models import LoraSpec
+            if args.size.startswith('falcon'):
+                lora = LoraSpec(r=16, lora_alpha=64, lora_dropout=0.1, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h'],
+                                force_enable_update_modules=['*.word_embeddings.*', '*.lm_head.*'])
+            else:
+                lora = LoraSpec(r=16, lora_alpha=64, lora_dropout=0.1, target_modules=['q_proj', 'k_proj', 'v_proj', 'o_proj', 'up_proj', 'down_proj'])
         dcfg = HuggingfaceDecoderConfig(vocab_size=vocab, use_cross_attn=False, model_str=name, extra_tokens=0, load_in_4bit=False,
-                                        prepare_for_kbit_training=args.freeze_decoder)
+                                        prepare_for_kbit_training=args.freeze_decoder, lora_spec=lora)
         cfg = base.model_copy(update=dict(decoder_config=dcfg, use_cross_attn=False, use_soft_prompting=True))
         V, eos = vocab, vocab - 1
     else:
@@ -137,7 +148,7 @@ def main():
     n_prompt = eng.enc.ncls
     out = {'workload': f'{enc_name} + {kind}({args.size}, randomly initialised checkpoint, '
                        + ('' if llama else 'cross-attention, dropout 0.1, ') +
-                       f'soft prompt of {n_prompt} + {args.caption_len} text positions)' + (', LoRA r 16 (gpu/gpt2-xl.yaml lora_spec)' if (args.lora and not llama) else (', decoder frozen (prepare_for_kbit_training)' if args.freeze_decoder else ', every parameter trains')),
+                       f'soft prompt of {n_prompt} + {args.caption_len} text positions)' + (', LoRA r 16 (the lora_spec of the reference yaml of this decoder)' if args.lora else (', decoder frozen (prepare_for_kbit_training)' if args.freeze_decoder else ', every parameter trains')),
            'params_M': round(n_params / 1e6, 1), 'trainable_params_M': round(n_train / 1e6, 1), 'batch': args.batch, 'train_images_per_sec': round(args.batch / dt, 1),
            'ms_per_step': round(dt * 1e3, 2), 'final_loss': round(float(loss.detach()), 4),
            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'dtype': 'bf16', 'data': 'synthetic',
