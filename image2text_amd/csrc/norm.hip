@@ -170,6 +170,140 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
+// ------------------------------------------------------------------------------------------------ wide rows (1024 < d <= 8192)
+// One WORKGROUP per row (a thread owns chunks tid + 256 i): the rows of the big Hugging Face decoders (Falcon-7B: d = 4544).  Same
+// arithmetic as the one-wave-per-row kernels above, the reductions go through LDS (block_sum).
+constexpr int WIDEC = 8;
+constexpr int LN_BWD_WIDE_ROWS = 8;
+
+template <bool Y_F32>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, void* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int d, float eps) {
+    __shared__ float red[16];
+    const int nc = d >> 2;
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * d);
+        f32x4 v[WIDEC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WIDEC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            v[i] = (c < nc) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = block_sum(s, red) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < WIDEC; ++i)
+            if (threadIdx.x + 256 * i < nc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[i][e] - mean;
+                    q += t * t;
+                }
+            }
+        const float rstd = rsqrtf(block_sum(q, red) / d + eps);
+        if (threadIdx.x == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < WIDEC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            if (c < nc) {
+                const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c];
+                const f32x4 bt = beta ? reinterpret_cast<const f32x4*>(beta)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+                if (Y_F32) {
+                    reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + (size_t)row * d)[c] = o;
+                } else {
+                    const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + (size_t)row * d)[c] = pk;
+                }
+            }
+        }
+    }
+}
+
+// a workgroup walks LN_BWD_WIDE_ROWS consecutive rows, its threads keep the dgamma / dbeta partials of their own columns in
+// registers: one atomic per column and workgroup at the end (no dropout / gradient-normaliser extras on this form)
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx, int dx_accumulate,
+                                                          bf16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int M, int d, int blk0) {
+    __shared__ float red[16];
+    const int nc = d >> 2;
+    f32x4 pg[WIDEC], pb[WIDEC];
+#pragma unroll
+    for (int i = 0; i < WIDEC; ++i) pg[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bid = blockIdx.x + blk0;
+    const int row_end = min(M, (bid + 1) * LN_BWD_WIDE_ROWS);
+    for (int row = bid * LN_BWD_WIDE_ROWS; row < row_end; ++row) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[WIDEC], g[WIDEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < WIDEC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            xh[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nc) {
+                const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c];
+                f32x4 dyv;
+                if (DY_F32) {
+                    dyv = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + (size_t)row * d)[c];
+                } else {
+                    const u32x2 pk = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * d)[c];
+                    dyv = f32x4{bf16lo(pk[0]), bf16hi(pk[0]), bf16lo(pk[1]), bf16hi(pk[1])};
+                }
+                const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    g[i][e] = dyv[e] * gm[e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                    pg[i][e] += dyv[e] * xh[i][e];
+                    pb[i][e] += dyv[e];
+                }
+            }
+        }
+        const float c1 = block_sum(s1, red) / d, c2 = block_sum(s2, red) / d;
+#pragma unroll
+        for (int i = 0; i < WIDEC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            if (c < nc) {
+                f32x4* dxp = reinterpret_cast<f32x4*>(dx + (size_t)row * d) + c;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+                if (dx_accumulate) o += *dxp;
+                *dxp = o;
+                if (dx_bf16) {
+                    const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * d)[c] = pk;
+                }
+            }
+        }
+    }
+    if (!dgamma && !dbeta) return;
+#pragma unroll
+    for (int i = 0; i < WIDEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dgamma) atomicAdd(dgamma + c * 4 + e, pg[i][e]);
+                if (dbeta) atomicAdd(dbeta + c * 4 + e, pb[i][e]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNormND
 // stats layout per image: [0]=mean [1]=rstd [2 + 2s], [3 + 2s] = partial (mean_s, M2_s) of split s (fwd)
 //                         or partial (sum g, sum g*xhat) (bwd);  NSPLIT splits per image.
@@ -355,10 +489,17 @@ extern "C" int i2t_layernorm_fwd(void* stream, const float* x, const float* gamm
 extern "C" int i2t_layernorm_fwd_eps(void* stream, const float* x, const float* gamma, const float* beta, void* y,
                                      int y_is_f32, float* mean, float* rstd, int M, int d, float eps) {
     I2T_REQUIRE(x && gamma && y && M > 0 && eps > 0.f, "i2t_layernorm_fwd: bad args");
-    I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
+    I2T_REQUIRE(d % 4 == 0 && d <= WIDEC * 1024, "i2t_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, WIDEC * 1024);
+    hipStream_t s = (hipStream_t)stream;
+    if (d > MAXC * 256) {                 // wide rows: one workgroup per row
+        const int wgrid = M < 16384 ? M : 16384;
+        if (y_is_f32) hipLaunchKernelGGL(ln_fwd_wide_kernel<true>, dim3(wgrid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
+        else hipLaunchKernelGGL(ln_fwd_wide_kernel<false>, dim3(wgrid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
+        I2T_CHECK_LAUNCH("i2t_layernorm_fwd");
+        return I2T_OK;
+    }
     int grid = (M + 3) / 4;
     if (grid > 8192) grid = 8192;
-    hipStream_t s = (hipStream_t)stream;
     if (y_is_f32) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
     else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, d, eps);
     I2T_CHECK_LAUNCH("i2t_layernorm_fwd");
@@ -372,9 +513,23 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
     I2T_REQUIRE(!dx_pre_sumsq || dx_accumulate, "i2t_layernorm_bwd: dx_pre_sumsq only applies when accumulating onto dx");
     I2T_REQUIRE(drop_thr == 0 || (dx_bf16 && (long)M * d < (1L << 32)), "i2t_layernorm_bwd: dropout needs dx_bf16 and M*d < 2^32");
-    I2T_REQUIRE(d % 4 == 0 && d <= MAXC * 256, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, MAXC * 256);
-    int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+    I2T_REQUIRE(d % 4 == 0 && d <= WIDEC * 1024, "i2t_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, WIDEC * 1024);
     hipStream_t s = (hipStream_t)stream;
+    if (d > MAXC * 256) {                 // wide rows: one workgroup per row group; the extras of the narrow form are not offered here
+        I2T_REQUIRE(drop_thr == 0 && !sumsq_out && !dx_pre_sumsq, "i2t_layernorm_bwd: d=%d > %d supports neither dropout nor the gradient-normaliser extras", d, MAXC * 256);
+        const int wgrid = (M + LN_BWD_WIDE_ROWS - 1) / LN_BWD_WIDE_ROWS, wper = i2t_det() ? 1 : wgrid;
+        for (int b0 = 0; b0 < wgrid; b0 += wper) {
+            if (dy_is_f32)
+                hipLaunchKernelGGL(ln_bwd_wide_kernel<true>, dim3(wper), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
+                                   (bf16_t*)dx_bf16, dgamma, dbeta, M, d, b0);
+            else
+                hipLaunchKernelGGL(ln_bwd_wide_kernel<false>, dim3(wper), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
+                                   (bf16_t*)dx_bf16, dgamma, dbeta, M, d, b0);
+        }
+        I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
+        return I2T_OK;
+    }
+    int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
     // deterministic mode: the workgroups' atomics onto dgamma / dbeta / sumsq_out land in workgroup order (one launch each)
     const int per = i2t_det() ? 1 : grid;
     for (int b0 = 0; b0 < grid; b0 += per) {

@@ -292,7 +292,8 @@ def test_colsum(ops):
 
 
 # ------------------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize('M,d,bias', [(1000, 768, True), (777, 512, False), (64, 64, False), (33, 128, True), (16, 1024, True)])
+@pytest.mark.parametrize('M,d,bias', [(1000, 768, True), (777, 512, False), (64, 64, False), (33, 128, True), (16, 1024, True),
+                                         (77, 4544, True), (19, 8192, False)])      # > 1024: the wide-row form (Falcon-7B's d = 4544)
 def test_layernorm(ops, M, d, bias):
     x = rnd(M, d, seed=12) * 2 + 0.5
     g = 1 + 0.1 * rnd(d, seed=13)
