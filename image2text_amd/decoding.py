@@ -368,15 +368,20 @@ class GreedyDecoder:
                          2 * dc.d, dc.d, bias=a.P(f'{p}.in_proj_bias')[dc.d:])
         if st.prefix:       # the prompt rows' keys and values (one causal pass over the encoder outputs) open every caption's cache
             n_p = st.prefix
-            _, _, pctx = eng.decode_segment(B, n_p, eng._mem_bf16(enc_out) if eng.cross_inputs else None, S, True,
-                                            embeds=enc_out[:, :n_p].reshape(B * n_p, dc.d), pos_offset=0)
-            for l in range(dc.L):
-                if dc.llama is not None:      # row-major cache [B][slot][Hkv hd]; the saved keys already carry their rotation
-                    ls = dc.llama
-                    qkv = pctx.saves[l].qkv.view(B, n_p, -1)
+            if dc.llama is not None:          # row-major cache [B][slot][Hkv hd]; the saved keys already carry their rotation.  Each layer's
+                ls = dc.llama                 # K / V go into the cache as the layer finishes (a 7-B model's 32 saves would not fit beside it)
+
+                def take_kv(l, sv):
+                    qkv = sv.qkv.view(B, n_p, -1)
                     st.kc[l][:, :n_p].copy_(qkv[..., ls.H * ls.hd:(ls.H + ls.Hkv) * ls.hd])
                     st.vc[l][:, :n_p].copy_(qkv[..., (ls.H + ls.Hkv) * ls.hd:])
-                    continue
+                eng._layer_sink = take_kv
+            try:
+                _, _, pctx = eng.decode_segment(B, n_p, eng._mem_bf16(enc_out) if eng.cross_inputs else None, S, True,
+                                                embeds=enc_out[:, :n_p].reshape(B * n_p, dc.d), pos_offset=0)
+            finally:
+                eng._layer_sink = None
+            for l in range(dc.L if dc.llama is None else 0):
                 qkv = pctx.saves[l].qkv.view(B, n_p, 3, dc.H, 64)
                 st.kc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 1].transpose(1, 2))
                 st.vc[l].view(B, dc.H, st.clen, 64)[:, :, :n_p].copy_(qkv[:, :, 2].transpose(1, 2))

@@ -362,8 +362,12 @@ class LlamaBlocks:
             x = embeds.to(device=a.device, dtype=F32).contiguous().view(M, d)
         saves, cur = [], x
         block = self.falcon_block_fwd if ls.arch == 'falcon' else self.llama_block_fwd
+        sink = getattr(self, '_layer_sink', None)         # generation's prompt prefill: takes a layer's K / V and lets the rest go
         for l in range(dc.L):
             cur, sv = block(l, cur, B, T, pos_offset, save, vl)
+            if sink is not None and sv is not None:
+                sink(l, sv)
+                sv = None
             saves.append(sv)
         wn = self.dp + ls.norm_f
         hid, hb, rf, mf = self._empty(M, d), self._empty(M, d, dtype=BF16), self._empty(M), None

@@ -142,6 +142,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    loss = loss.detach().clone()             # (the loss tensor's graph node holds the step's saved activations: let them go)
     kind = type(wrapper.model.decoder).__name__
     enc_name = 'nano-224 ViT (6x512, 224x224x3, 64 CLS)' if args.vit == 'none' else \
         f'PretrainedViT (ViT-B/16 shape 12x768, 224x224x3, random init, backbone {"trains" if args.vit == "refine" else "frozen"}, 16 slot MLPs 768-1024-768)'
