@@ -1891,7 +1891,10 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         // ... and only without the per-row dropout multipliers and up to ~4e5 rows: at the benchmark's M = 798 720 (B = 3072) the
         // 256^2 kernel is the faster one (1363 vs 1654 us with dropout, 1417 vs 1528 without), and with dropout gemm3 does not win
         // at M = 266 240 either (515 vs 513 us)
-        const int g3 = e3 ? atoi(e3) : ((g256_epilogue_class(p) == 1 && K <= 512 && !p.drop_mode && (long)M <= 400000) ? 2 : 0);
+        // Round 3 re-measurement (tools/ab_gemm_classes.py, M = 99 840, K = 512, class 1): since the 256^2 kernel's stores became
+        // non-temporal it is the faster one here too -- 843 / 850 TF against gemm3's 775 / 798 (N = 2048 / 1536) -- so the default
+        // rule is OFF; gemm3 stays reachable through I2T_GEMM3 for the record of the overlap experiment.
+        const int g3 = e3 ? atoi(e3) : 0;
         const int cls3 = g256_epilogue_class(p);
         if (g3 && splits == 1 && !a_kmajor && !b_kmajor && K % 64 == 0 && alpha == 1.0f && (N & 7) == 0 && (ldc & 7) == 0 && ALIGNED16(C) &&
             ((cls3 == 1 && K >= 5 * 64) || (cls3 == 2 && K >= 8 * 64 && (!aux_out || ((ld_aux_out & 7) == 0 && ALIGNED16(aux_out))))) &&
