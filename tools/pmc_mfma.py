@@ -15,6 +15,7 @@ import sys
 
 FAMILIES = (('gemm256_kernel<false, false, 8>', 'fused cross-attention (K/V projection + attention)'), ('gemm3_kernel', 'gemm3 (256x128, overlapped epilogue)'),
             ('gemm256_kernel', 'gemm256 (persistent 256^2)'), ('gemm_bf16_kernel', 'gemm 128^2'), ('gemm_skinny', 'gemm skinny'),
+            ('attn_fwd2', 'attention fwd (LDS-resident, encoder)'), ('attn_bwd2', 'attention bwd (LDS-resident, fused dQ/dK/dV, encoder)'),
             ('attn_fwd', 'attention fwd'), ('attn_bwd_dq', 'attention bwd dQ'), ('attn_bwd_dkv', 'attention bwd dK/dV'),
             ('conv_mfma_bwd_weight', 'conv bwd-weight'), ('conv_mfma_kernel', 'conv fwd / bwd-data'), ('ln_bwd', 'layernorm bwd'))
 N_SIMD = 256 * 4
@@ -32,7 +33,7 @@ def main():
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
             d['launches'] = d.get('launches', 0) + 1
     out = {}
-    print(f'{"kernel family":28s} {"launches":>8s} {"MFMA busy":>10s} {"waves parked":>13s} {"issue stall":>12s} {"issuing":>8s}')
+    print(f'{"kernel family":56s} {"launches":>8s} {"MFMA busy":>10s} {"waves parked":>13s} {"issue stall":>12s} {"issuing":>8s}')
     for fam, d in acc.items():
         cyc = d.get('GRBM_GUI_ACTIVE', 0.0)
         if cyc <= 0:
@@ -43,7 +44,7 @@ def main():
              'wait_inst_any_frac_of_wave_cycles': d.get('SQ_WAIT_INST_ANY', 0.0) / wc,
              'active_inst_any_frac_of_wave_cycles': d.get('SQ_ACTIVE_INST_ANY', 0.0) / wc}
         out[fam] = o
-        print(f'{fam:28s} {o["launches"]:8d} {o["mfma_busy_frac"] * 100:9.1f}% {o["wait_any_frac_of_wave_cycles"] * 100:12.1f}% '
+        print(f'{fam:56s} {o["launches"]:8d} {o["mfma_busy_frac"] * 100:9.1f}% {o["wait_any_frac_of_wave_cycles"] * 100:12.1f}% '
               f'{o["wait_inst_any_frac_of_wave_cycles"] * 100:11.1f}% {o["active_inst_any_frac_of_wave_cycles"] * 100:7.1f}%')
     if len(sys.argv) > 2:
         json.dump(out, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
