@@ -1061,6 +1061,207 @@ __global__ __launch_bounds__(512, 1) void attn_bwd2_kernel(AttnPtr Q, AttnPtr K,
 #undef B2_ARGS_B
 }
 
+// ================================================================================================== v3 backward: ONE softmax pass
+// attn_bwd2 issues the exp / dropout-hash / dS arithmetic of every (query, key) pair TWICE (once per phase) and that VALU work is what
+// bounds it (PMC: matrix pipe 18 % busy, both waves of a SIMD issuing 39 % of their cycles).  Here a pair is evaluated once, by the wave
+// that owns its KEY block (S = Q K^T orientation: a lane owns a key column, so dV^T += dO^T P and dK^T += Q^T dS contract over the
+// accumulator's own row index and stay in registers).  dQ contracts over KEYS, i.e. over the accumulator's column index and across
+// waves: each 32-query chunk's dS goes to LDS once (bf16, [key][query], one ds_write_b64 per tile) and after ONE barrier per chunk
+// the 8 waves each take one 16 x 16 tile of dQ^T[64 dims][32 queries] and contract it over all keys -- K^T and dS^T both as
+// transposed LDS reads.  The dS buffer takes V's place in LDS (V is only needed as the owner's row fragments: loaded from global once);
+// its 128-byte rows hold two chunks side by side (double buffer: chunk i + 1 is written while stragglers still read chunk i).
+template <bool DROP, int CNT>
+__device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigned char* k_lds, const unsigned char* do_lds, unsigned char* ds_lds,
+                                       const float* lse_l, const float* dl_l, const bf16_t* vb, int v_rs, int w, int Tq, int Tk,
+                                       unsigned drow_base, unsigned drop_key, unsigned drop_thr, float dscale, bf16_t* dqb, int dq_rs,
+                                       bf16_t* dkb, int dk_rs, bf16_t* dvb, int dv_rs, unsigned od_key, unsigned od_thr, float od_scale,
+                                       unsigned grow_q, unsigned grow_k, int lane) {
+    constexpr int NC = CNT > 0 ? CNT : 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int qpad = (Tq + 31) & ~31, kpad = (Tk + 31) & ~31;
+    bf16x8 kf[NC][2], vf[NC][2];
+    f32x4 adk[NC][4], adv[NC][4];
+    int key[NC];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int k0 = (w + 8 * c) * 16;
+        key[c] = k0 + li;
+        kf[c][0] = v2_row_frag(k_lds, k0, 0, lane); kf[c][1] = v2_row_frag(k_lds, k0, 1, lane);
+        vf[c][0] = global_row_frag(vb, v_rs, k0, Tk, 0, lane); vf[c][1] = global_row_frag(vb, v_rs, k0, Tk, 1, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) adk[c][dt] = adv[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int dt_w = w & 3, qt_w = w >> 2;                                    // this wave's tile of a chunk's dQ^T[4 x 16 dims][2 x 16 queries]
+    const int nks3 = ((kpad >> 5) + 2) / 3;                                   // 32-key steps in threes (rows up to 288 exist and are zero)
+    // dQ^T[dims 16 dt_w ..][queries 16 (qb + qt_w) ..] = sum over keys K^T[dim][key] dS^T[key][query]: three independent accumulation
+    // chains, the six transposed reads of a trip issued together
+    auto dq_tile = [&](int qb) {
+        const int col = ((qb >> 1) & 1) * 32 + qt_w * 16;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+        for (int k3 = 0; k3 < nks3; ++k3) {
+            const int r = k3 * 96;
+            const bf16x8 t0 = v2_tr_frag(k_lds, r, dt_w * 16, lane), t1 = v2_tr_frag(k_lds, r + 32, dt_w * 16, lane), t2 = v2_tr_frag(k_lds, r + 64, dt_w * 16, lane);
+            const bf16x8 s0 = v2_tr_frag(ds_lds, r, col, lane), s1 = v2_tr_frag(ds_lds, r + 32, col, lane), s2 = v2_tr_frag(ds_lds, r + 64, col, lane);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, s0, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, s1, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t2, s2, a2, 0, 0, 0);
+        }
+        const int qrow = (qb + qt_w) * 16 + li;
+        if (qrow < Tq) {
+            const float f = (od_thr ? (dropout_keep(od_key, grow_q + (unsigned)qrow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+            const f32x4 o = (a0 + a1 + a2) * f;
+            *reinterpret_cast<u32x2*>(dqb + (size_t)qrow * dq_rs + dt_w * 16 + 4 * g) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    };
+    for (int qb = 0; qb < (qpad >> 4); qb += 2) {
+        const int half = (qb >> 1) & 1;
+        if constexpr (CNT > 0) {
+            f32x4 pp[NC][2], ds[NC][2];
+#pragma unroll
+            for (int qj = 0; qj < 2; ++qj) {
+                const int q0 = (qb + qj) * 16;
+                const bf16x8 q0f = v2_row_frag(q_lds, q0, 0, lane), q1f = v2_row_frag(q_lds, q0, 1, lane);
+                const bf16x8 d0f = v2_row_frag(do_lds, q0, 0, lane), d1f = v2_row_frag(do_lds, q0, 1, lane);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_l + q0 + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_l + q0 + 4 * g);
+#pragma unroll
+                for (int c = 0; c < CNT; ++c) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[c][0], a, 0, 0, 0);      // D[q][key]: rows q = 4 g + e, column key = li
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[c][1], a, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[c][0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[c][1], dp, 0, 0, 0);
+                    bool keep4[4] = {true, true, true, true};
+                    if constexpr (DROP) {      // (as attn_bwd2's phase B: the quad of keys 4c..4c+3 shares one hash word per query row)
+                        const int j = li & 3;
+                        const int qm = min(q0 + 4 * g + j, Tq - 1);
+                        const int mine = (int)dropout_hash(drop_key, (drow_base + (unsigned)qm * (unsigned)Tk + (unsigned)key[c]) >> 2);
+                        const unsigned sh = 8u * (unsigned)j;
+                        keep4[0] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[1] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[2] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[3] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xff, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                    }
+                    const bool kvalid = key[c] < Tk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]);
+                        pv = kvalid ? pv : 0.f;
+                        float pd = pv, dpr = dp[r];
+                        if constexpr (DROP) {
+                            pd = keep4[r] ? pv : 0.f;
+                            dpr = keep4[r] ? dpr : 0.f;
+                        }
+                        pp[c][qj][r] = pd;
+                        ds[c][qj][r] = pv * fmaf(dpr, dscale, -d4[r]);
+                    }
+                    // dS -> LDS [key][query]: the lane's 4 consecutive queries of its key = 8 bytes of chunk (32 half + 16 qj + 4 g) / 8
+                    const int chunk = half * 4 + 2 * qj + (g >> 1);
+                    *reinterpret_cast<u32x2*>(ds_lds + key[c] * V2_RB + ((chunk ^ (key[c] & 7)) << 4) + (g & 1) * 8) =
+                        u32x2{pack_bf16x2(ds[c][qj][0], ds[c][qj][1]), pack_bf16x2(ds[c][qj][2], ds[c][qj][3])};
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 dot = v2_tr_frag(do_lds, qb * 16, dt * 16, lane), qt = v2_tr_frag(q_lds, qb * 16, dt * 16, lane);
+#pragma unroll
+                for (int c = 0; c < CNT; ++c) {
+                    adv[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pack_frag(pp[c][0], pp[c][1]), adv[c][dt], 0, 0, 0);
+                    adk[c][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pack_frag(ds[c][0], ds[c][1]), adk[c][dt], 0, 0, 0);
+                }
+            }
+        }
+        // The two waves of a SIMD (w and w + 4) take their dQ tiles at DIFFERENT times -- the lower four right after the barrier, the
+        // upper four after their owner work on the NEXT chunk -- so that one wave's LDS-latency-bound contraction runs beside the other's
+        // VALU-bound softmax (in lockstep both sat in the contraction together and the SIMD idled: 53 % of wave-cycles parked).  The
+        // double buffer allows it: chunk i's half is next written after barrier i + 1.
+        if (w >= 4 && qb > 0) dq_tile(qb - 2);
+        __syncthreads();                                                     // the chunk's dS is complete (every key row, all owners)
+        if (w < 4) dq_tile(qb);
+    }
+    if (w >= 4) dq_tile(((qpad >> 4) - 1) & ~1);
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        if (key[c] < Tk) {
+            const unsigned grow = grow_k + (unsigned)key[c];
+            const float fk = (od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+            const float fv = (od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f) * dscale;
+            bf16_t* pk_ = dkb + (size_t)key[c] * dk_rs;
+            bf16_t* pv_ = dvb + (size_t)key[c] * dv_rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 a = adk[c][dt] * fk, b = adv[c][dt] * fv;
+                *reinterpret_cast<u32x2*>(pk_ + dt * 16 + 4 * g) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                *reinterpret_cast<u32x2*>(pv_ + dt * 16 + 4 * g) = u32x2{pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+            }
+        }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, bf16_t* __restrict__ dK, long dk_bs,
+                                                           int dk_rs, bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq, int Tk,
+                                                           unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned od_key,
+                                                           unsigned od_thr, float od_scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * V2_MAXROWS * V2_RB + 2 * V2_MAXROWS * 4];
+    unsigned char* q_lds = smem;
+    unsigned char* do_lds = smem + V2_MAXROWS * V2_RB;
+    unsigned char* k_lds = smem + 2 * V2_MAXROWS * V2_RB;
+    unsigned char* ds_lds = smem + 3 * V2_MAXROWS * V2_RB;
+    float* lse_l = reinterpret_cast<float*>(smem + 4 * V2_MAXROWS * V2_RB);
+    float* dl_l = lse_l + V2_MAXROWS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const bf16_t* qb_ = Q.p + (size_t)b * Q.bs + h * 64;
+    const bf16_t* dob = dO.p + (size_t)b * dO.bs + h * 64;
+    const bf16_t* ob = O.p + (size_t)b * O.bs + h * 64;
+    const bf16_t* kb_ = K.p + (size_t)b * K.bs + h * 64;
+    const int qpad = (Tq + 31) & ~31, kpad = (Tk + 31) & ~31;
+    b2_stage2(q_lds, do_lds, qb_, Q.rs, dob, dO.rs, Tq, qpad, tid);
+    for (int c = tid; c < V2_MAXROWS * 8; c += 512) {                        // K alone (zero rows past Tk), and a dS buffer of zeros: its
+        const int r = c >> 3, kc = c & 7;                                    // rows past the last owned key block are never written
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < Tk) v = *reinterpret_cast<const u32x4*>(kb_ + (size_t)r * K.rs + kc * 8);
+        const int off = r * V2_RB + ((kc ^ (r & 7)) << 4);
+        *reinterpret_cast<u32x4*>(k_lds + off) = v;
+        *reinterpret_cast<u32x4*>(ds_lds + off) = u32x4{0u, 0u, 0u, 0u};
+    }
+    const size_t stat_base = ((size_t)b * H + h) * Tq;
+    for (int r0 = 0; r0 < qpad; r0 += 64) {                                  // delta = rowsum(dO . O), lse in log2 units (attn_bwd2_kernel)
+        const int r = r0 + (tid >> 3), kc = tid & 7;
+        float s = 0.f;
+        if (r < Tq) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dob + (size_t)r * dO.rs + kc * 8), c = *reinterpret_cast<const u32x4*>(ob + (size_t)r * O.rs + kc * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(a[e]) * bf16lo(c[e]) + bf16hi(a[e]) * bf16hi(c[e]);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (kc == 0 && r < qpad) {
+            dl_l[r] = r < Tq ? s : 0.f;
+            lse_l[r] = r < Tq ? lse[stat_base + r] * LOG2E : INFINITY;
+        }
+    }
+    __syncthreads();
+    const float dscale = DROP ? drop_scale : 1.f;
+    const unsigned drow_base = ((unsigned)b * H + h) * (unsigned)Tq * (unsigned)Tk, grow_q = (unsigned)b * Tq, grow_k = (unsigned)b * Tk;
+    bf16_t* dqb = dQ + (size_t)b * dq_bs + h * 64;
+    bf16_t* dkb = dK + (size_t)b * dk_bs + h * 64;
+    bf16_t* dvb = dV + (size_t)b * dv_bs + h * 64;
+    const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
+    const int nkb = (Tk + 15) >> 4;
+    const int cnt = max(0, (nkb - w + 7) >> 3);                              // key blocks w, w + 8, ... < nkb
+#define B3_ARGS q_lds, k_lds, do_lds, ds_lds, lse_l, dl_l, vb, V.rs, w, Tq, Tk, drow_base, drop_key, drop_thr, dscale, dqb, dq_rs, dkb, dk_rs, dvb, dv_rs, \
+                od_key, od_thr, od_scale, grow_q, grow_k, lane
+    if (cnt == 0) b3_run<DROP, 0>(B3_ARGS);                                  // (every wave meets every barrier: same trip count in all four)
+    else if (cnt == 1) b3_run<DROP, 1>(B3_ARGS);
+    else if (cnt == 2) b3_run<DROP, 2>(B3_ARGS);
+    else b3_run<DROP, 3>(B3_ARGS);
+#undef B3_ARGS
+}
+
 // the resident-operand kernels cover dense, non-causal calls whose operands fit (the encoders); I2T_ATTN_V2=0 keeps the tiled ones
 bool v2_applies(int Tq, int Tk, int causal, const int* cu_q, const int* cu_k, unsigned drop_thr) {
     const char* e = getenv("I2T_ATTN_V2");                               // read per call: tests switch it inside one process
@@ -1137,7 +1338,20 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     AttnPtr DO{(const bf16_t*)d_o, do_bs, do_rs};
     const VarLen vl{cu_q, cu_k, total_q, B};
     const AttnPtr Ow{(const bf16_t*)o, o_bs, o_rs};
-    if (v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS && !(getenv("I2T_ATTN_BWD2") && getenv("I2T_ATTN_BWD2")[0] == '0')) {
+    // I2T_ATTN_BWD = 3 (default): the one-pass kernel | 2: the two-phase one (attn_bwd2) | 0: the tiled pair; I2T_ATTN_BWD2=0: as 0
+    const char* be = getenv("I2T_ATTN_BWD");
+    const int bmode = (getenv("I2T_ATTN_BWD2") && getenv("I2T_ATTN_BWD2")[0] == '0') ? 0 : (be ? atoi(be) : 3);
+    if (bmode == 3 && v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS) {
+        if (!drop_thr) hipLaunchKernelGGL((attn_bwd3_kernel<false>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
+                                          (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
+                                          out_drop_key, out_drop_thr, out_drop_scale);
+        else hipLaunchKernelGGL((attn_bwd3_kernel<true>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
+                                (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
+                                out_drop_key, out_drop_thr, out_drop_scale);
+        I2T_CHECK_LAUNCH("i2t_attention_bwd(v3)");
+        return I2T_OK;
+    }
+    if (bmode != 0 && v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS) {
         if (!drop_thr) hipLaunchKernelGGL((attn_bwd2_kernel<false>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
                                           (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
                                           out_drop_key, out_drop_thr, out_drop_scale);
