@@ -649,6 +649,105 @@ def test_falcon_decoder_forward_gradients_generate(tmp_path, monkeypatch, mode):
         assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same plugins at PRODUCTION WIDTH, one layer deep (the cases above are toy shapes): Llama-2-7B's block
+# (4096 wide, 32 heads of 128, SwiGLU 11008, vocabulary 32000), DeepSeek-R1-Distill-Qwen-1.5B's (1536, 12 heads of 128 on 2 K/V heads,
+# 8960, q / k / v biases, vocabulary 151936) and Falcon-7B's (4544 = 71 heads of 64 on ONE K/V head, 18176, vocabulary 65024: K is not a
+# multiple of 128, rows are wider than the one-wave LayerNorm).  Checker: the checkpoint's own transformers module, CPU, fp32.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _production_width_checkpoint(kind, tmp_path, monkeypatch):
+    import transformers
+    torch.manual_seed(3)
+    if kind == 'llama2-7b':
+        name, vocab = 'meta-llama/Llama-2-7b-1layer', 32000
+        hf = transformers.LlamaForCausalLM(transformers.LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
+                                                                     num_key_value_heads=32, vocab_size=vocab, max_position_embeddings=128, rms_norm_eps=1e-5))
+    elif kind == 'qwen2-1.5b':
+        name, vocab = 'Qwen2-1.5B-1layer', 151936
+        hf = transformers.Qwen2ForCausalLM(transformers.Qwen2Config(hidden_size=1536, intermediate_size=8960, num_hidden_layers=1, num_attention_heads=12,
+                                                                     num_key_value_heads=2, vocab_size=vocab, max_position_embeddings=128, rms_norm_eps=1e-6,
+                                                                     tie_word_embeddings=False))
+    else:
+        name, vocab = 'tiiuae/falcon-7b-1layer', 65024
+        hf = transformers.FalconForCausalLM(transformers.FalconConfig(hidden_size=4544, num_attention_heads=71, num_hidden_layers=1, vocab_size=vocab,
+                                                                       multi_query=True, parallel_attn=True, new_decoder_architecture=False, bias=False,
+                                                                       alibi=False, max_position_embeddings=128))
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if n_.endswith('.bias') or 'norm' in n_ or 'ln_f' in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    hf.save_pretrained(str(tmp_path / name))
+    monkeypatch.chdir(tmp_path)
+    return name, vocab
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('kind', ['llama2-7b', 'qwen2-1.5b', 'falcon-7b'])
+def test_hf_decoder_block_at_production_width(tmp_path, monkeypatch, kind):
+    import copy
+    from oracle import reference_model as orc
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    tag = f'hf_width.{kind}'
+    name, V = _production_width_checkpoint(kind, tmp_path, monkeypatch)
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=1, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=V, extra_tokens=0), use_cross_attn=False,
+                                     use_soft_prompting=True))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    m.decoder.tie_weights()
+    hf = copy.deepcopy(m.decoder.backbone).float().eval()
+    d = m.decoder.n_embd
+    esd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if not k.startswith('decoder.')}
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    m = m.to(dev()).train()
+    assert m.has_bridge and m._engine.dec.llama.d == d
+    images, labels = synthetic_batch(3, 32, 12, V, seed=17)
+    ids = labels.clamp(min=0)
+    n_p = cfg.vision_encoder_config.n_cls
+    embed = hf.get_input_embeddings()
+    g = torch.Generator().manual_seed(2)
+    wh = torch.randn(3, n_p + 12, d, generator=g) * 0.02
+    wl = torch.randn(3, 12, V, generator=g) * 0.01
+    out = m(images=images.to(dev()), ids=ids.to(dev()))
+    enc = orc.encode(esd, cfg, images, training=False)
+    ref = hf(inputs_embeds=torch.cat((enc, embed(ids)), dim=-2), output_hidden_states=True)
+    ologits, ohid = ref.logits[..., n_p:, :], ref.hidden_states[-1]
+    # bf16 operands over K = 1536 ... 18176 reductions: the error of a logit is noise of rel-L2 ~ 1 % (measured 1.1 % on the Llama block),
+    # and the max over 3 x 12 x V ~ 10^6 samples of it sits ~5 sigma out -- the bound that means something here is the rel-L2 one
+    # (<= 2e-2); the max-norm bound is 2e-2 x max|value| (the toy shapes above hold 1.25e-2)
+    for name_, got, want, tol in (('logits', out.logits, ologits, 2e-2), ('hidden', out.hidden_state, ohid, 2e-2)):
+        diff = got.float().cpu() - want.detach()
+        err, scale = float(diff.abs().max()), max(1.0, float(want.detach().abs().max()))
+        REPORT[f'{tag}.{name_}'] = {'max_abs_err': err, 'tol': tol * scale, 'rel_l2': float(diff.norm() / want.detach().norm())}
+        assert err <= tol * scale and float(diff.norm() / want.detach().norm()) <= 2e-2, (name_, err, tol * scale)
+    ((out.hidden_state * wh.to(dev())).sum() + (out.logits * wl.to(dev())).sum()).backward()
+    ((ohid * wh).sum() + (ologits * wl).sum()).backward()
+    ref_grads = {k: v.grad for k, v in esd.items() if v.grad is not None}
+    ref_grads.update({'decoder.backbone.' + k: p.grad for k, p in hf.named_parameters()})
+    fails, names = [], [n for n, _ in m.named_parameters()]
+    assert set(names) == set(ref_grads), set(names) ^ set(ref_grads)
+    for name_, p in m.named_parameters():
+        try:
+            grad_close(f'{tag}.{name_}', p.grad, ref_grads[name_].numpy(), rel=8e-2, cos=0.99)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, f'{len(fails)} gradients out of tolerance: ' + '; '.join(fails[:6])
+    # KV-cache generation (hipGraph) at this width: the first token against the checker's own argmax where its margin is clear
+    m.eval()
+    tok = fake_tokenizer(V)
+    with torch.no_grad():
+        prompt = torch.full((3, 1), tok.bos_token_id, dtype=torch.long, device=dev())
+        gen = m.generate(images.to(dev()), prompt, max_new_tokens=4, temperature=1.0, top_k=1)
+        l0 = hf(inputs_embeds=torch.cat((enc, embed(prompt.cpu())), dim=-2)).logits[:, -1].detach()
+        t2 = l0.topk(2, dim=-1).values
+        sure = (t2[:, 0] - t2[:, 1]) > 3e-2 * l0.abs().max()
+        REPORT[f'{tag}.generate_first_token'] = {'clear_margins': int(sure.sum()), 'of': 3}
+        assert bool((gen[:, 1].cpu()[sure] == l0.argmax(-1)[sure]).all())
+
+
 def test_llama_decoder_frozen_by_prepare_for_kbit_training(tmp_path, monkeypatch):
     """prepare_for_kbit_training: True without 4-bit loading (reference local/llama2-7b.yaml; peft freezes the base model): no decoder
     parameter receives a gradient, the weight-gradient GEMMs are skipped, and the encoder's gradients -- through the soft prompt rows of
