@@ -221,6 +221,11 @@ extern "C" int i2t_gemm_fp8(void* stream, const void* A8, int lda, const float* 
     I2T_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ALIGNED16(A8) && ALIGNED16(B8),
                 "i2t_gemm_fp8: operands must be 16-byte aligned with leading dimensions %% 16 == 0 and >= K (zero-padded rows)");
     I2T_REQUIRE(ldc >= N && ldc % 4 == 0 && ALIGNED16(C) && (!residual || (ldr % 4 == 0 && ALIGNED16(residual))), "i2t_gemm_fp8: C / residual alignment");
+    // enough 256 x 256 tiles and K % 256 == 0: the persistent LDS-DMA kernel of gemm.hip on fp8 operands (same results up to summation order)
+    if (i2t_g256_fp8_try((hipStream_t)stream, A8, lda, sa, B8, ldb, sb, C, ldc, c_is_f32, M, N, K, bias, residual, ldr)) {
+        I2T_CHECK_LAUNCH("i2t_gemm_fp8(256)");
+        return I2T_OK;
+    }
     F8Params p{(const unsigned char*)A8, (const unsigned char*)B8, sa, sb, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, c_is_f32};
     const long tiles = (long)((M + F8_BM - 1) / F8_BM) * ((N + F8_BN - 1) / F8_BN);
     I2T_REQUIRE(tiles < 2147483647L, "i2t_gemm_fp8: grid too large");

@@ -59,6 +59,8 @@ struct GemmParams {
     int g2_splits, g2_nk;     // 256^2 kernel: K slices per output tile and K-tiles per slice (even)
     int g2_gn;                // 256^2 kernel: column tiles per group of the tile order
     int g2_dbg;               // experiment (I2T_G256_DBG): 1 = epilogue without its global stores, 2 = no epilogue at all
+    const float* scale_a = nullptr;   // class 9 (fp8 operands, i2t_gemm_fp8): per-row scales of A [M] and of B [N] applied to the accumulators
+    const float* scale_b = nullptr;
     int g2_stagger, g2_stagger_groups;   // experiment: start delay (units of s_sleep 127) x (workgroup index within its XCD mod groups)
     // fused cross-attention (epilogue class 8, see xattn_epilogue): queries, outputs and shapes
     const bf16_t* xq; long xq_bs; int xq_rs;      // Q [B, T, >= 64 H] (batch stride used when xcu is null) or packed [rows, >= 64 H]
@@ -337,21 +339,23 @@ __device__ __forceinline__ bool epilogue_fast_ok(const GemmParams& p) {
 struct EpiPre {
     f32x4 bv[4], add[4];
     u32x2 ax[4];
+    f32x4 sb;            // class 9: the lane's 4 column scales (one vector per tile) and its 4 rows' scales
+    float sa[4];
 };
 template <int EPI>
 struct EpiFlags {
     static constexpr bool GEN = EPI == 0;
     bool f_bias, f_gelu, f_dgelu, f_auxout, f_drop1, f_drop2, f_res, f_acc, f_f32;
     __device__ __forceinline__ explicit EpiFlags(const GemmParams& p) {
-        f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7) ? (p.bias != nullptr) : false;
+        f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7 || EPI == 9) ? (p.bias != nullptr) : false;
         f_gelu = GEN ? (p.act == I2T_ACT_GELU || p.act == I2T_ACT_GELU_ERF) : (EPI == 2);        // (the erf flavours: generic class only)
         f_dgelu = GEN ? (p.act == I2T_ACT_DGELU || p.act == I2T_ACT_DGELU_ERF) : (EPI == 4);
         f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
         f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
         f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
-        f_res = (GEN || EPI == 3) ? (p.residual != nullptr) : false;
+        f_res = (GEN || EPI == 3 || EPI == 9) ? (p.residual != nullptr) : false;
         f_acc = (GEN || EPI == 5) ? (p.accumulate != 0) : false;
-        f_f32 = (GEN || EPI == 7) ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
+        f_f32 = (GEN || EPI == 7 || EPI == 9) ? (p.c_is_f32 != 0) : (EPI == 3 || EPI == 5);
     }
 };
 // EPI 7: the straddling quad loads bias from [N-1 .. N+2]: inside the 16-B padded vector
@@ -374,6 +378,10 @@ __device__ __forceinline__ void epilogue_loads4(const GemmParams& p, const int (
     if (F.f_dgelu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) L.ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
+    }
+    if constexpr (EPI == 9) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.sa[q] = p.scale_a[mc[q]];
     }
     // one set of addend registers serves residual and accumulate (both at once is rare: the second then waits on the first)
     if (F.f_res) {
@@ -405,6 +413,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         v[q] = a[q] * p.alpha;
+        if constexpr (EPI == 9) v[q] = v[q] * L.sa[q] * L.sb;          // fp8 operands: row scale of A x column scale of B
         if (F.f_bias) v[q] += L.bv[q];
     }
     if (F.f_auxout) {
@@ -535,7 +544,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
     const bool fast = EPI != 0 || epilogue_fast_ok(p);        // the launcher picks a specialised class only when fast_ok holds
     // classes that LOAD per element (residual, accumulate, GELU' input) run the loads G2_EPI_DEPTH row groups ahead
-    constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5;
+    constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5 || EPI == 9;
     constexpr int DEPTH = PIPE ? G2_EPI_DEPTH : 0, NB = DEPTH + 1;
     EpiPre L[NB];
     const int n4c = nbase + 4 * li;                           // after the transpose a lane's 4 quads share their columns
@@ -554,6 +563,11 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
             for (int s = 0; s < NB; ++s)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) L[s].bv[q] = b;
+        }
+        if constexpr (EPI == 9) {
+            const f32x4 sb = *reinterpret_cast<const f32x4*>(p.scale_b + (FULL ? n4c : epi_clamp_n(p, n4c)));
+#pragma unroll
+            for (int s = 0; s < NB; ++s) L[s].sb = sb;
         }
         static_for<DEPTH>([&](auto D_) {
             constexpr int d = decltype(D_)::value;
@@ -1137,6 +1151,84 @@ struct G2 {
         read_b<1>(rb0);
         read_a<0, 0>(ra);
     }
+
+    // ---- fp8 (e4m3) operands: the SAME bytes, units, slots and DMA schedule -- a 128-byte LDS row is 128 k values instead of 64 --
+    // on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), which consumes 32 bytes per lane and operand: the two 16-byte chunks
+    // the bf16 form reads for k-steps 0 and 1 of a K-tile (chunks g and 4 + g: the scaled MFMA pairs byte j of lane l in A with byte
+    // j of lane l in B, so any k assignment works as long as both operands use the same one).  8 MFMAs of 32 cycles per phase instead of
+    // 16 of 16: the K loop's time per byte is unchanged, its flops double.  One MFMA needs BOTH halves of a fragment, so the A set
+    // cannot be refilled by k-half behind the k-step-0 MFMAs as above: it is refilled by FRAGMENT -- after the two MFMAs that last use
+    // fragment i (in the phases after which the A subtile changes: 2, 4, 6, 8), ~6 MFMAs ahead of its next use.
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    template <int SLOT, int I>
+    __device__ __forceinline__ void f8_read_a(i32x8 (&fa)[4]) {
+        const u32x4 lo = __builtin_bit_cast(u32x4, dma_frag_read<false, false>(smem + phys(SLOT) * G2_UNIT, wr * 64 + I * 16, 0, lane));
+        const u32x4 hi = __builtin_bit_cast(u32x4, dma_frag_read<false, false>(smem + phys(SLOT) * G2_UNIT, wr * 64 + I * 16, 1, lane));
+        fa[I] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void f8_read_a_all(i32x8 (&fa)[4]) {
+        f8_read_a<SLOT, 0>(fa); f8_read_a<SLOT, 1>(fa); f8_read_a<SLOT, 2>(fa); f8_read_a<SLOT, 3>(fa);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void f8_read_b(i32x8 (&fb)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 lo = __builtin_bit_cast(u32x4, dma_frag_read<false, false>(smem + phys(SLOT) * G2_UNIT, wc * 32 + j * 16, 0, lane));
+            const u32x4 hi = __builtin_bit_cast(u32x4, dma_frag_read<false, false>(smem + phys(SLOT) * G2_UNIT, wc * 32 + j * 16, 1, lane));
+            fb[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+    }
+    template <int SUBA, int SUBB, int I>
+    __device__ __forceinline__ void f8_mma_i(f32x4 (&acc)[8][4], const i32x8 (&fa)[4], const i32x8 (&fb)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)          // swapped issue, as the bf16 form: lane holds C[16 i + (lane & 15)][16 j + 4 (lane >> 4) .. + 3]
+            // From inline asm, accumulator tied in place: through the builtin hipcc allocates this instruction's results away from its
+            // srcC (copies of accumulators, 98-120 spilled registers in this loop -- the same schedule on bf16 MFMAs: none).  What the
+            // compiler then no longer knows: the result latency (two_tiles_fp8's caller pads it before the epilogue reads acc; inside
+            // the loop an accumulator is next touched a K-tile later); s_waitcnt for the LDS reads feeding it is still its job.
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                         : "+v"(acc[SUBA * 4 + I][SUBB * 2 + j]) : "v"(fb[j]), "v"(fa[I]), "v"(0x7f7f7f7f));
+    }
+    template <int SUBA, int SUBB>
+    __device__ __forceinline__ void f8_mma(f32x4 (&acc)[8][4], const i32x8 (&fa)[4], const i32x8 (&fb)[2]) {
+        f8_mma_i<SUBA, SUBB, 0>(acc, fa, fb); f8_mma_i<SUBA, SUBB, 1>(acc, fa, fb); f8_mma_i<SUBA, SUBB, 2>(acc, fa, fb); f8_mma_i<SUBA, SUBB, 3>(acc, fa, fb);
+    }
+    // the phase whose A subtile changes afterwards: fragment i of the NEXT subtile (slot NSLOT) is read behind the MFMAs that last use i
+    template <int SUBA, int SUBB, int NSLOT, bool READ>
+    __device__ __forceinline__ void f8_mma_refill(f32x4 (&acc)[8][4], i32x8 (&fa)[4], const i32x8 (&fb)[2]) {
+        f8_mma_i<SUBA, SUBB, 0>(acc, fa, fb); if (READ) f8_read_a<NSLOT, 0>(fa);
+        f8_mma_i<SUBA, SUBB, 1>(acc, fa, fb); if (READ) f8_read_a<NSLOT, 1>(fa);
+        f8_mma_i<SUBA, SUBB, 2>(acc, fa, fb); if (READ) f8_read_a<NSLOT, 2>(fa);
+        f8_mma_i<SUBA, SUBB, 3>(acc, fa, fb); if (READ) f8_read_a<NSLOT, 3>(fa);
+    }
+    // LDS reads issued per phase: 4 (B) | 8 (A refill) | 0 | 12 -> the fence of the NEXT phase lets exactly those stay in flight (the reads
+    // of the phase before them -- the tenants of the slot this phase's DMA overwrites -- have then retired)
+    template <bool LAST>
+    __device__ __forceinline__ void two_tiles_fp8(int t, f32x4 (&acc)[8][4], i32x8 (&fa)[4], i32x8 (&fb0)[2], i32x8 (&fb1)[2]) {
+        // ---- even tile
+        fence<12>();  f8_read_b<2>(fb1);  stage<1, 2>(t + 1);
+        f8_mma<0, 0>(acc, fa, fb0);
+        fence<4>();   stage<1, 3>(t + 1);
+        f8_mma_refill<0, 1, 3, true>(acc, fa, fb1);
+        fence<8>();   stage<0, 0>(t + 2);
+        f8_mma<1, 1>(acc, fa, fb1);
+        fence<0>();   f8_read_b<5>(fb1);  stage<0, 1>(t + 2);
+        f8_mma_refill<1, 0, 4, true>(acc, fa, fb0);
+        // ---- odd tile
+        fence<12>();  f8_read_b<6>(fb0);  stage<0, 2>(t + 2);
+        f8_mma<0, 1>(acc, fa, fb1);
+        fence<4>();   stage<0, 3>(t + 2);
+        f8_mma_refill<0, 0, 7, true>(acc, fa, fb0);
+        fence<8>();   stage<1, 0>(t + 3);
+        f8_mma<1, 0>(acc, fa, fb0);
+        fence<0>();   if (!LAST) f8_read_b<1>(fb0);  stage<1, 1>(t + 3);
+        f8_mma_refill<1, 1, 0, !LAST>(acc, fa, fb1);
+    }
+    __device__ __forceinline__ void next_tile_reads_fp8(i32x8 (&fa)[4], i32x8 (&fb0)[2]) {
+        f8_read_b<1>(fb0);
+        f8_read_a_all<0>(fa);
+    }
 };
 
 // Persistent: gridDim.x = min(#CUs, tiles) workgroups, each walks tiles idx, idx + grid, ... ; the DMA stream runs 6
@@ -1159,6 +1251,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     g.cur = g.tile_desc(p, first, ntiles);
     g.nxt = g.tile_desc(p, first + G, ntiles);
     f32x4 acc[8][4];
+    if constexpr (EPI == 9) {            // fp8 operands (i2t_gemm_fp8): same pipeline, the fragment registers hold 32-byte operands
+        typename decltype(g)::i32x8 fa[4], fb0[2], fb1[2];
+        g.template stage<0, 0>(0); g.template stage<0, 1>(0); g.template stage<0, 2>(0); g.template stage<0, 3>(0);
+        g.template stage<1, 0>(1); g.template stage<1, 1>(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        g.next_tile_reads_fp8(fa, fb0);
+        for (int idx = first; idx < ntiles; idx += G) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < g.nk - 2; t += 2) g.template two_tiles_fp8<false>(t, acc, fa, fb0, fb1);
+            g.template two_tiles_fp8<true>(g.nk - 2, acc, fa, fb0, fb1);
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (8 passes each) before the epilogue reads acc
+            const int m0 = g.cur.m0, n0 = g.cur.n0;
+            g.cur = g.nxt;
+            g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
+            int lane_e = tid & 63;
+            asm volatile("" : "+v"(lane_e));
+            const int inside = __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= p.M && n0 + g.wc * 64 + 64 <= p.N) ? 1 : 0);
+            if (inside) epilogue_tile_tr<8, 9, true>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            else epilogue_tile_tr<8, 9, false>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            g.init_lane(p, tid);
+            g.next_tile_reads_fp8(fa, fb0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     bf16x8 ra[8], rb0[4], rb1[4];
 
     // prologue: units 0..5 (K-tile 0 and the first half of K-tile 1), then the reads that precede phase 0
@@ -1600,6 +1721,34 @@ void launch_g256(hipStream_t s, GemmParams p) {
     else if (cls == 4) hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
 }
+
+}  // namespace
+// fp8 operands on the persistent kernel (called by i2t_gemm_fp8, csrc/fp8.hip): A8 [M][lda] and B8 [N][ldb] e4m3 bytes, C = (A8 . B8^T)
+// sa[m] sb[n] (+ bias) (+ residual).  The kernel sees the byte matrices as bf16 matrices of half the width (same bytes per row and per
+// K-tile).  False = not eligible (the caller keeps its own 128 x 128 kernel): K % 256, alignment, fewer tiles than the hand-over point.
+bool i2t_g256_fp8_try(hipStream_t s, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
+                      int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr) {
+    const char* off = getenv("I2T_FP8_G256");
+    if (off && off[0] == '0') return false;
+    if (K % 256 != 0 || (lda & 15) || (ldb & 15) || (N & 3) || (ldc & 3) || (residual && (ldr & 3)) || !ALIGNED16(A8) || !ALIGNED16(B8) || !ALIGNED16(C) ||
+        (bias && !ALIGNED16(bias)) || !ALIGNED16(sb) || (size_t)M * lda >= (1ull << 32) || (size_t)N * ldb >= (1ull << 32))
+        return false;
+    if ((long)((M + 255) / 256) * ((N + 255) / 256) < 40) return false;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)A8; p.B = (const bf16_t*)B8; p.C = C;
+    p.M = M; p.N = N; p.K = K / 2; p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc;
+    p.alpha = 1.0f; p.bias = bias; p.act = I2T_ACT_NONE; p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32;
+    p.scale_a = sa; p.scale_b = sb;
+    p.g2_gn = 8;
+    const int n_cu = g256_cus();
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+    p.g2_splits = 1; p.g2_nk = p.K >> 6;                               // K % 256 == 0: an even number of 128-byte K-tiles
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<false, false, 9>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, s, p);
+    return true;
+}
+namespace {
 
 // dW = A^T . B accumulated into an fp32 C (both operands k-major): K slices spread over the CUs when the output has too
 // few 256^2 tiles, partial tiles combined with float atomics (C already holds the value to accumulate onto); with enough

@@ -51,7 +51,10 @@ def test_row_quantisation_is_ocp_e4m3(M, K, dtype):
     assert rel <= 2 ** -4 + 1e-3                                         # e4m3: 3 mantissa bits -> half an ulp of the row maximum's binade
 
 
-@pytest.mark.parametrize('M,N,K', [(200, 300, 768), (128, 128, 128), (1000, 1536, 4096), (50, 12, 256)])
+# (the last three: >= 40 tiles of 256 x 256 and K % 256 == 0 -> the persistent LDS-DMA kernel of gemm.hip on fp8 operands; ragged M and N edges,
+# a one-pair K loop (K = 256), the Llama-2-7B down-projection's K = 11008 = 43 x 256)
+@pytest.mark.parametrize('M,N,K', [(200, 300, 768), (128, 128, 128), (1000, 1536, 4096), (50, 12, 256), (4096, 4096, 1024), (3000, 3460, 256),
+                                   (2100, 4096, 11008)])
 def test_fp8_gemm_matches_the_product_of_its_quantised_operands(M, N, K):
     from image2text_amd import ops
     g = torch.Generator().manual_seed(K + N)
@@ -78,6 +81,14 @@ def test_fp8_gemm_matches_the_product_of_its_quantised_operands(M, N, K):
     outb = torch.empty(M, Np, dtype=BF16, device=dev())
     ops.gemm_fp8(x8, sx, w8, sw, outb, M, N, K)
     assert float((outb[:, :N].double() - ref_q).abs().max()) / scale <= 1e-2
+    # both kernels behind the entry point say the same (I2T_FP8_G256 is read per call): only the summation order differs
+    os.environ['I2T_FP8_G256'] = '0'
+    try:
+        out_small = torch.empty(M, Np, device=dev())
+        ops.gemm_fp8(x8, sx, w8, sw, out_small, M, N, K, bias=bias, residual=res)
+    finally:
+        del os.environ['I2T_FP8_G256']
+    assert float((out_small[:, :N] - out32[:, :N]).abs().max()) / scale <= 5e-5
     # the transposed weight image: dx = dy . W through quant_cols_fp8
     wt8, swt = torch.empty(K, (N + 15) // 16 * 16, dtype=torch.uint8, device=dev()), torch.empty(K, device=dev())
     ops.quant_cols_fp8(w, wt8, swt, N, K)
