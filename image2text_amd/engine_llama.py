@@ -136,8 +136,10 @@ class LlamaBlocks:
                     col0 += lo.r
                 row0 += rows[t]
             names = [nA] + ([nA + '.<pad>'] if a.entries[nA][2][0] < LPAD else [])
+            wn = getattr(self._llama_views(l).names, site)        # the adapted projection's base weight(s): frozen -> fp8 operands (I2T_FP8=1)
             v = self._sub_cache[key] = SimpleNamespace(K=K, N=row0, r=lo.r, scale=lo.scale, kind=f'lora_{site}', A=a.span('W', names, (LPAD, K)),
-                                                       GA=a.span('G', names, (LPAD, K)), parts=parts, nA=nA)
+                                                       GA=a.span('G', names, (LPAD, K)), parts=parts, nA=nA,
+                                                       wnames=[wn] if isinstance(wn, str) else list(wn))
         return v
 
     def rope_table(self):

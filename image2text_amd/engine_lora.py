@@ -54,6 +54,8 @@ class LoraAdapters:
         """out = epilogue([x | u] . [W | s B | 0]^T), u = dropout(x) . A^T.  x bf16 [M, K] contiguous, W bf16 [N, K].  Returns what
         the backward needs (u and s B, both [*, LPAD] bf16) when save."""
         K, N = ls.K, ls.N
+        if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames) and not epilogue.get('act') and epilogue.get('aux_out') is None:
+            return self._lora_gemm_fp8(ls, x, W, out, M, drop_l, save, **epilogue)
         xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
         xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
         ops.lora_stage(x, xcat, xd, M, K, drop_l)                    # one pass: x into the concatenated operand + its masked copy
@@ -64,6 +66,30 @@ class LoraAdapters:
         ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
         return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd) if save else None
+
+    def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, **_):
+        """The same layer with its FROZEN base weight on fp8 operands (I2T_FP8=1; engine_llama._fp8_*): the base product runs
+        at the fp8 MFMA rate, so the adapter leaves the K panel -- out = fp8(x) . fp8(W)^T (+ bias) (+ residual) + u . (s B)^T, the
+        rank-128 product added by a second, thin GEMM (in place on an fp32 output; ahead of the base GEMM, as its fp32 residual, when
+        the output is bf16).  No K-concatenated copies of x and W; one quantisation pass over x instead."""
+        K, N = ls.K, ls.N
+        xd = None
+        if drop_l is not None:
+            xd = x.clone()
+            ops.dropout_apply(xd, M, K, drop_l)                      # (the index space of lora_stage and of the backward's epilogue mask)
+        u = torch.empty(M, LPAD, dtype=BF16, device=x.device)
+        ops.gemm(xd if xd is not None else x, ls.A, u, M, LPAD, K)
+        panel = self._lora_panel(ls)
+        e = self._fp8_weight(ls.wnames, W)
+        x8, sx = self._fp8_rows(x, M, K)
+        if out.dtype == F32:
+            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=residual)
+            ops.gemm(u, panel, out, M, N, LPAD, residual=out)
+        else:
+            tmp = torch.empty(M, N, dtype=F32, device=x.device)
+            ops.gemm(u, panel, tmp, M, N, LPAD, residual=residual)
+            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=tmp)
+        return SimpleNamespace(u=u, sB=panel, xd=xd) if save else None
 
     def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
         """dY bf16 [M, N]: gradient w.r.t. the adapted linear's pre-epilogue output.  gW / gb: gradient views of the base weight /
@@ -82,7 +108,12 @@ class LoraAdapters:
         xd = sv_l.xd if sv_l.xd is not None else x
         ops.gemm(du, xd, ls.GA, LPAD, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dx = torch.empty(M, K, dtype=F32, device=dY.device)
-        ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)
+        if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames):      # frozen base weight: dx on fp8 operands too
+            e = self._fp8_weight(ls.wnames, W)
+            d8, sd = self._fp8_rows(dY, M, N)
+            ops.gemm_fp8(d8, sd, e.wt8, e.swt, dx, M, K, N)
+        else:
+            ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)
         ops.gemm(du, ls.A, dx, M, K, LPAD, b_kmajor=True, residual=dx, drop=drop_l)
         return dx
 

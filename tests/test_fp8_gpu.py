@@ -157,3 +157,61 @@ def test_frozen_llama_decoder_on_fp8_operands_against_transformers(tmp_path, mon
         worst = min(worst, c)
     REPORT['llama_frozen_fp8.encoder_gradient_min_cosine'] = worst
     assert worst >= 0.97
+
+
+@pytest.mark.parametrize('p_lora', [0.0, 0.25])
+def test_lora_on_a_frozen_llama_base_with_fp8_operands(tmp_path, monkeypatch, p_lora):
+    """LoRA adapters (targets of the reference's gpu/llama2-13b.yaml) on a base whose GEMMs take e4m3 operands: the adapter leaves the K panel
+    and is added by a thin second GEMM (engine_lora._lora_gemm_fp8), the base dx runs on fp8 as well.  Against the SAME model on the bf16 path
+    (itself checked against transformers in test_hf_decoder_gpu.py; the same dropout masks: same step seed): logits within the e4m3 bar,
+    every adapter gradient and the encoder's within the direction bar."""
+    from image2text_amd import ops
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.synth import det_init_, synthetic_batch, tiny_config
+    from test_host_cpu import _hf_decoder_config, _local_hf_llama
+    _, name, vocab = _local_hf_llama(tmp_path, monkeypatch, 'llama')
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=p_lora, target_modules=['q_proj', 'k_proj', 'v_proj', 'o_proj', 'up_proj', 'down_proj'])
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=0, lora_spec=spec),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for n, p in m.decoder.lora_params.items():
+            if n.endswith('_B'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    m = m.to(dev()).train()
+    eng = m._engine
+    images, labels = synthetic_batch(3, 32, 12, vocab, seed=17)
+    ids = labels.clamp(min=0)
+    wl = (torch.randn(3, 12, vocab, generator=torch.Generator().manual_seed(2)) * 0.01).to(dev())
+    runs = {}
+    for fp8 in (False, True):
+        eng.fp8 = fp8
+        torch.manual_seed(1234)                      # the step seed (dropout masks) derives from torch's seed: same masks in both runs
+        eng._seed_base = None
+        n8 = []
+        orig = ops.gemm_fp8
+        monkeypatch.setattr(ops, 'gemm_fp8', lambda *a, **k: (n8.append(1), orig(*a, **k))[1])
+        for p in m.parameters():
+            p.grad = None
+        out = m(images=images.to(dev()), ids=ids.to(dev()))
+        (out.logits * wl).sum().backward()
+        monkeypatch.setattr(ops, 'gemm_fp8', orig)
+        runs[fp8] = (out.logits.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}, len(n8))
+    assert runs[False][2] == 0 and runs[True][2] == 2 * (4 + 4)          # per layer: four adapted projections forward + their four dx GEMMs
+    rel = float((runs[True][0] - runs[False][0]).norm() / runs[False][0].norm())
+    REPORT[f'llama_lora_fp8.p{p_lora}.logits_rel_l2_vs_bf16_path'] = rel
+    assert rel <= 8e-2
+    assert set(runs[True][1]) == set(runs[False][1])
+    worst = 1.0
+    for n, g8 in runs[True][1].items():
+        gb = runs[False][1][n]
+        c = float(g8.double().ravel() @ gb.double().ravel() / (g8.double().norm() * gb.double().norm() + 1e-30))
+        worst = min(worst, c)
+    REPORT[f'llama_lora_fp8.p{p_lora}.gradient_min_cosine_vs_bf16_path'] = worst
+    assert worst >= 0.97

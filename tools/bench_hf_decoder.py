@@ -59,7 +59,7 @@ def main():
     ap.add_argument('--vit', default='none', choices=['none', 'frozen', 'refine'], help="encoder = the reference's PretrainedViT (torchvision ViT-B/16 "
                     "shape, randomly initialised: the SWAG checkpoint is not in the image) with the slot-MLP head of local/gpt2.yaml (n_cls 16, "
                     "gate_sizes [1024], n_embd_out_vit 768): BASELINE.json configs[2].  frozen = refine_base_model: False")
-    ap.add_argument('--fp8', action='store_true', help='I2T_FP8=1: e4m3 operands for the GEMMs of FROZEN decoder weights (use with --freeze-decoder; '
+    ap.add_argument('--fp8', action='store_true', help='I2T_FP8=1: e4m3 operands for the GEMMs of FROZEN decoder weights (use with --freeze-decoder or --lora; '
                     'BASELINE.json configs[4])')
     ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
                     "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
