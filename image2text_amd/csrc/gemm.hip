@@ -2053,7 +2053,10 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
             return I2T_OK;
         }
     }
-    if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
+    // N <= 128 (the LoRA adapters' rank-padded products u = x A^T, du = dY (s B)): a 256-column tile is half empty and M / 256 row tiles
+    // leave most CUs idle -- the 128^2 kernel runs twice the workgroups on full tiles (I2T_G256_NARROW=1: the old routing, for A/B)
+    static const bool narrow_256 = getenv("I2T_G256_NARROW") && getenv("I2T_G256_NARROW")[0] == '1';
+    if (splits == 1 && !no_g256 && g256_ok && !a_kmajor && (N > 128 || narrow_256) && (long)((M + 255) / 256) * ((N + 255) / 256) >= min_tiles) {
         if (b_kmajor) launch_g256<true>(s, p);
         else launch_g256<false>(s, p);
         I2T_CHECK_LAUNCH("i2t_gemm_bf16(256)");

@@ -61,6 +61,7 @@ def main():
                     "gate_sizes [1024], n_embd_out_vit 768): BASELINE.json configs[2].  frozen = refine_base_model: False")
     ap.add_argument('--fp8', action='store_true', help='I2T_FP8=1: e4m3 operands for the GEMMs of FROZEN decoder weights (use with --freeze-decoder or --lora; '
                     'BASELINE.json configs[4])')
+    ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape table of the bf16 GEMM launches of one step on stderr')
     ap.add_argument('--lora', action='store_true', help="GPT-2 sizes: the lora_spec of the reference's gpu/gpt2-xl.yaml (r 16, alpha 64, "
                     "dropout 0.1, c_attn / mlp.c_fc / mlp.c_proj, wpe / wte / crossattention / ln_cross_attn left trainable)")
     args = ap.parse_args()
@@ -168,6 +169,9 @@ def main():
     with GemmTimer(ops) as gt:
         step()
         gs = gt.summary()
+        if args.gemm_breakdown:
+            for line in gt.breakdown()[:24]:
+                print('[bench_hf_decoder] ' + line, file=sys.stderr, flush=True)
     ops.gemm_fp8 = f8orig
     if f8rec:
         torch.cuda.synchronize()
