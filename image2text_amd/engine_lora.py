@@ -41,6 +41,16 @@ class LoraAdapters:
                 B=a.P(nB), GB=a.G(nB), parts=[(0, N, 0, a.P(nB), a.G(nB))], nA=nA)
         return v
 
+    def _rank_gemm(self, a, b, out, M: int, K: int, b_kmajor: bool = False):
+        """out bf16 [M, LPAD] = a [M, K] . b (b: [LPAD, K], or [K, LPAD] when b_kmajor) -- the adapters' u = dropout(x) A^T and
+        du = dY (s B).  128 output columns are M / 256 half-empty tiles of the persistent kernel (12 820 rows: 51 workgroups, 1.4 TB/s);
+        for a long K the fp32 split-K form (atomics into a zeroed plane, ~4 slices) + one cast runs 2.2x faster (tools/ab_thin_gemm.py)."""
+        if K < 2048 or M < 2048:
+            return ops.gemm(a, b, out, M, LPAD, K, b_kmajor=b_kmajor)
+        plane = torch.zeros(M, LPAD, dtype=F32, device=out.device)
+        ops.gemm(a, b, plane, M, LPAD, K, b_kmajor=b_kmajor, accumulate=True)
+        return ops.cast_f32_bf16(plane, out)
+
     def _lora_panel(self, ls, dtype=BF16):
         """[N, LPAD] = the adapter's B matrices at their (row block, rank column block) -- ONE block for a plain linear, block-diagonal for
         a fused projection (q | k | v, gate | up: engine_llama) -- times the LoRA scale, zero elsewhere."""
@@ -59,13 +69,15 @@ class LoraAdapters:
         xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
         xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
         ops.lora_stage(x, xcat, xd, M, K, drop_l)                    # one pass: x into the concatenated operand + its masked copy
-        ops.gemm(xd if xd is not None else x, ls.A, xcat[:, K:], M, LPAD, K)
+        u = torch.empty(M, LPAD, dtype=BF16, device=x.device)
+        self._rank_gemm(xd if xd is not None else x, ls.A, u, M, K)
+        xcat[:, K:].copy_(u)
         wcat = torch.empty(N, K + LPAD, dtype=BF16, device=x.device)
         wcat[:, :K].copy_(W)
         wcat[:, K:].copy_(self._lora_panel(ls))
         ops.gemm(xcat, wcat, out, M, N, K + LPAD, **epilogue)
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
-        return SimpleNamespace(u=xcat[:, K:].contiguous(), sB=wcat[:, K:].contiguous(), xd=xd) if save else None
+        return SimpleNamespace(u=u, sB=wcat[:, K:].contiguous(), xd=xd) if save else None
 
     def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, **_):
         """The same layer with its FROZEN base weight on fp8 operands (I2T_FP8=1; engine_llama._fp8_*): the base product runs
@@ -78,7 +90,7 @@ class LoraAdapters:
             xd = x.clone()
             ops.dropout_apply(xd, M, K, drop_l)                      # (the index space of lora_stage and of the backward's epilogue mask)
         u = torch.empty(M, LPAD, dtype=BF16, device=x.device)
-        ops.gemm(xd if xd is not None else x, ls.A, u, M, LPAD, K)
+        self._rank_gemm(xd if xd is not None else x, ls.A, u, M, K)
         panel = self._lora_panel(ls)
         e = self._fp8_weight(ls.wnames, W)
         x8, sx = self._fp8_rows(x, M, K)
@@ -104,7 +116,7 @@ class LoraAdapters:
         for row0, nrows, col0, B, GB in ls.parts:             # (a fused projection: only the diagonal blocks are parameters)
             GB.add_(tmp[row0:row0 + nrows, col0:col0 + B.shape[1]], alpha=ls.scale)
         du = torch.empty(M, LPAD, dtype=BF16, device=dY.device)
-        ops.gemm(dY, sv_l.sB, du, M, LPAD, N, b_kmajor=True)
+        self._rank_gemm(dY, sv_l.sB, du, M, N, b_kmajor=True)
         xd = sv_l.xd if sv_l.xd is not None else x
         ops.gemm(du, xd, ls.GA, LPAD, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
         dx = torch.empty(M, K, dtype=F32, device=dY.device)

@@ -22,8 +22,16 @@ def main():
         u = torch.empty(M, 128, dtype=BF16, device=dev)
         t1 = timeit(lambda: ops.gemm(x, a, u, M, 128, K), reps=20)
         t2 = timeit(lambda: ops.gemm(x, bt, u, M, 128, K, b_kmajor=True), reps=20)
+        u32 = torch.zeros(M, 128, dtype=F32, device=dev)
+
+        def splitk(b, **kw):
+            u32.zero_()
+            ops.gemm(x, b, u32, M, 128, K, accumulate=True, **kw)
+            ops.cast_f32_bf16(u32, u)
+        t3 = timeit(lambda: splitk(a), reps=20)
+        t4 = timeit(lambda: splitk(bt, b_kmajor=True), reps=20)
         by = M * K * 2
-        print(f'narrow256={os.environ.get("I2T_G256_NARROW", "0")} M={M} N=128 K={K}: A.B^T {t1 * 1e6:7.1f} us ({by / t1 / 1e12:4.2f} TB/s)   A.B {t2 * 1e6:7.1f} us ({by / t2 / 1e12:4.2f} TB/s)', flush=True)
+        print(f'narrow256={os.environ.get("I2T_G256_NARROW", "0")} M={M} N=128 K={K}: A.B^T {t1 * 1e6:7.1f} us ({by / t1 / 1e12:4.2f} TB/s)   A.B {t2 * 1e6:7.1f} us ({by / t2 / 1e12:4.2f} TB/s)   split-K f32+cast: A.B^T {t3 * 1e6:7.1f} us  A.B {t4 * 1e6:7.1f} us', flush=True)
 
 
 if __name__ == '__main__':
