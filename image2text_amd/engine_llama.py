@@ -24,6 +24,10 @@ from .engine_lora import LPAD
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+def _f8pad(k: int) -> int:
+    return (k + 255) // 256 * 256
+
+
 class LlamaBlocks:
     """Mixin of engine.HotPath (uses its arena, ``_empty``, ``dec`` namespace and parameter prefix ``dp``)."""
 
@@ -79,16 +83,18 @@ class LlamaBlocks:
             self.arena.refresh_shadow()
             N, K = W.shape
             dev = W.device
+            # rows zero-padded to a multiple of 256 bytes: the GEMM then runs K' = the padded length (zeros contribute nothing) and every
+            # projection is eligible for the persistent fp8 kernel (K % 256 == 0; Falcon-7B: 4544 -> 4608)
             ent = SimpleNamespace(generation=version,
-                                  w8=torch.empty(N, (K + 15) // 16 * 16, dtype=torch.uint8, device=dev), sw=torch.empty(N, dtype=F32, device=dev),
-                                  wt8=torch.empty(K, (N + 15) // 16 * 16, dtype=torch.uint8, device=dev), swt=torch.empty(K, dtype=F32, device=dev))
+                                  w8=torch.empty(N, _f8pad(K), dtype=torch.uint8, device=dev), sw=torch.empty(N, dtype=F32, device=dev),
+                                  wt8=torch.empty(K, _f8pad(N), dtype=torch.uint8, device=dev), swt=torch.empty(K, dtype=F32, device=dev))
             ops.quant_rows_fp8(W, ent.w8, ent.sw, N, K)
             ops.quant_cols_fp8(W, ent.wt8, ent.swt, N, K)
             self._sub_cache[key] = ent
         return ent
 
     def _fp8_rows(self, x_bf, M: int, K: int):
-        x8 = torch.empty(M, (K + 15) // 16 * 16, dtype=torch.uint8, device=x_bf.device)
+        x8 = torch.empty(M, _f8pad(K), dtype=torch.uint8, device=x_bf.device)
         sx = self._empty(M)
         ops.quant_rows_fp8(x_bf, x8, sx, M, K)
         return x8, sx
@@ -98,7 +104,7 @@ class LlamaBlocks:
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
             x8, sx = self._fp8_rows(x_bf, M, K)
-            return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=residual)
+            return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, _f8pad(K), bias=bias, residual=residual)
         return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual)
 
     def _lin_dx(self, dy_bf, W, names, out, M, N, K):
@@ -106,7 +112,7 @@ class LlamaBlocks:
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
             d8, sd = self._fp8_rows(dy_bf, M, N)
-            return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, N)
+            return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, _f8pad(N))
         return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True)
 
     # ---- LoRA adapters on these blocks (reference models/utils.py:46-65 -> peft LoraModel over the transformers module; the targets of

@@ -95,12 +95,12 @@ class LoraAdapters:
         e = self._fp8_weight(ls.wnames, W)
         x8, sx = self._fp8_rows(x, M, K)
         if out.dtype == F32:
-            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=residual)
+            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, x8.shape[1], bias=bias, residual=residual)      # (K' = the zero-padded row length)
             ops.gemm(u, panel, out, M, N, LPAD, residual=out)
         else:
             tmp = torch.empty(M, N, dtype=F32, device=x.device)
             ops.gemm(u, panel, tmp, M, N, LPAD, residual=residual)
-            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, K, bias=bias, residual=tmp)
+            ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, x8.shape[1], bias=bias, residual=tmp)
         return SimpleNamespace(u=u, sB=panel, xd=xd) if save else None
 
     def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
@@ -123,7 +123,7 @@ class LoraAdapters:
         if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames):      # frozen base weight: dx on fp8 operands too
             e = self._fp8_weight(ls.wnames, W)
             d8, sd = self._fp8_rows(dY, M, N)
-            ops.gemm_fp8(d8, sd, e.wt8, e.swt, dx, M, K, N)
+            ops.gemm_fp8(d8, sd, e.wt8, e.swt, dx, M, K, d8.shape[1])
         else:
             ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)
         ops.gemm(du, ls.A, dx, M, K, LPAD, b_kmajor=True, residual=dx, drop=drop_l)
