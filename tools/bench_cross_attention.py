@@ -2,7 +2,7 @@
 """One decoder cross-attention layer forward at the bench shapes (packed caption rows x 64 memory rows per image, 12 heads x 64):
 q projection, k/v projection, packed-row attention, output projection + residual.  Time and TFLOP/s per part and for the block.
 
-    python tools/bench_cross_attention.py [B]          (also usable under rocprofv3 --pmc, see tools/profile_mfma.sh)
+    python tools/bench_cross_attention.py [B] [d]      (also usable under rocprofv3 --pmc, see tools/profile_mfma.sh)
 """
 import os
 import sys
@@ -19,7 +19,8 @@ dev = torch.device('cuda:0')
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    d, H, S = 768, 12, 64
+    d = int(sys.argv[2]) if len(sys.argv) > 2 else 768          # 1280: the decoder of the reference's gpu/nano.yaml (20 heads of 64)
+    H, S = d // 64, 64
     g = torch.Generator().manual_seed(0)
     lens = torch.randint(8, 65, (B,), generator=g)
     cu = torch.zeros(B + 1, dtype=torch.int32)
