@@ -41,7 +41,7 @@ void i2t_set_error(const char* fmt, ...);
 bool i2t_det();
 // gemm.hip: the persistent 256^2 kernel on fp8 operands (false = not eligible); used by fp8.hip
 bool i2t_g256_fp8_try(hipStream_t s, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
-                      int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr);
+                      int c_is_f32, int M, int N, int K, const float* bias, int act, const float* residual, int ldr);
 
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }

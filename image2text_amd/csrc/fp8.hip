@@ -93,7 +93,7 @@ struct F8Params {
     void* C;
     const float* bias;           // [N] or null
     const float* residual;       // f32 [M][ldr] or null
-    int M, N, K, lda, ldb, ldc, ldr, c_is_f32;
+    int M, N, K, lda, ldb, ldc, ldr, c_is_f32, act;
 };
 
 __device__ __forceinline__ void f8_stage_load(u32x4 (&r)[4], const unsigned char* base, int ld, int row0, int nrows, int k0, int K, int tid) {
@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Params p) {
             for (int e = 0; e < 4; ++e) {
                 const int ne = min(n + e, p.N - 1);
                 v[e] = acc[i][j][e] * sa * p.sb[ne] + (p.bias ? p.bias[ne] : 0.f);
+                if (p.act == I2T_ACT_GELU_ERF) v[e] = gelu_erf(v[e]);
+                else if (p.act == I2T_ACT_GELU) v[e] = gelu_tanh(v[e]);
             }
             if (n + 3 < p.N) {
                 if (p.residual) {
@@ -216,17 +218,18 @@ extern "C" int i2t_quant_cols_fp8(void* stream, const void* w, int ld, void* out
 }
 
 extern "C" int i2t_gemm_fp8(void* stream, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
-                            int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr) {
+                            int c_is_f32, int M, int N, int K, const float* bias, int act, const float* residual, int ldr) {
     I2T_REQUIRE(A8 && B8 && sa && sb && C && M > 0 && N > 0 && K > 0, "i2t_gemm_fp8: bad args");
+    I2T_REQUIRE(act == I2T_ACT_NONE || act == I2T_ACT_GELU || act == I2T_ACT_GELU_ERF, "i2t_gemm_fp8: act %d (0 none | 1 GELU tanh | 3 GELU erf)", act);
     I2T_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ALIGNED16(A8) && ALIGNED16(B8),
                 "i2t_gemm_fp8: operands must be 16-byte aligned with leading dimensions %% 16 == 0 and >= K (zero-padded rows)");
     I2T_REQUIRE(ldc >= N && ldc % 4 == 0 && ALIGNED16(C) && (!residual || (ldr % 4 == 0 && ALIGNED16(residual))), "i2t_gemm_fp8: C / residual alignment");
     // enough 256 x 256 tiles and K % 256 == 0: the persistent LDS-DMA kernel of gemm.hip on fp8 operands (same results up to summation order)
-    if (i2t_g256_fp8_try((hipStream_t)stream, A8, lda, sa, B8, ldb, sb, C, ldc, c_is_f32, M, N, K, bias, residual, ldr)) {
+    if (i2t_g256_fp8_try((hipStream_t)stream, A8, lda, sa, B8, ldb, sb, C, ldc, c_is_f32, M, N, K, bias, act, residual, ldr)) {
         I2T_CHECK_LAUNCH("i2t_gemm_fp8(256)");
         return I2T_OK;
     }
-    F8Params p{(const unsigned char*)A8, (const unsigned char*)B8, sa, sb, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, c_is_f32};
+    F8Params p{(const unsigned char*)A8, (const unsigned char*)B8, sa, sb, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, c_is_f32, act};
     const long tiles = (long)((M + F8_BM - 1) / F8_BM) * ((N + F8_BN - 1) / F8_BN);
     I2T_REQUIRE(tiles < 2147483647L, "i2t_gemm_fp8: grid too large");
     hipLaunchKernelGGL(gemm_fp8_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);

@@ -415,6 +415,15 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
         v[q] = a[q] * p.alpha;
         if constexpr (EPI == 9) v[q] = v[q] * L.sa[q] * L.sb;          // fp8 operands: row scale of A x column scale of B
         if (F.f_bias) v[q] += L.bv[q];
+        if constexpr (EPI == 9) {                                      // (forward-only users: a frozen backbone's MLP -- no pre-activation output)
+            if (p.act == I2T_ACT_GELU_ERF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q][r] = gelu_erf(v[q][r]);
+            } else if (p.act == I2T_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q][r] = gelu_tanh(v[q][r]);
+            }
+        }
     }
     if (F.f_auxout) {
 #pragma unroll
@@ -1727,7 +1736,7 @@ void launch_g256(hipStream_t s, GemmParams p) {
 // sa[m] sb[n] (+ bias) (+ residual).  The kernel sees the byte matrices as bf16 matrices of half the width (same bytes per row and per
 // K-tile).  False = not eligible (the caller keeps its own 128 x 128 kernel): K % 256, alignment, fewer tiles than the hand-over point.
 bool i2t_g256_fp8_try(hipStream_t s, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
-                      int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr) {
+                      int c_is_f32, int M, int N, int K, const float* bias, int act, const float* residual, int ldr) {
     const char* off = getenv("I2T_FP8_G256");
     if (off && off[0] == '0') return false;
     if (K % 256 != 0 || (lda & 15) || (ldb & 15) || (N & 3) || (ldc & 3) || (residual && (ldr & 3)) || !ALIGNED16(A8) || !ALIGNED16(B8) || !ALIGNED16(C) ||
@@ -1738,7 +1747,7 @@ bool i2t_g256_fp8_try(hipStream_t s, const void* A8, int lda, const float* sa, c
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)A8; p.B = (const bf16_t*)B8; p.C = C;
     p.M = M; p.N = N; p.K = K / 2; p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc;
-    p.alpha = 1.0f; p.bias = bias; p.act = I2T_ACT_NONE; p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32;
+    p.alpha = 1.0f; p.bias = bias; p.act = act; p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32;
     p.scale_a = sa; p.scale_b = sb;
     p.g2_gn = 8;
     const int n_cu = g256_cus();

@@ -99,13 +99,13 @@ class LlamaBlocks:
         ops.quant_rows_fp8(x_bf, x8, sx, M, K)
         return x8, sx
 
-    def _lin(self, x_bf, W, names, out, M, N, K, bias=None, residual=None):
-        """out = x W^T (+ bias) (+ residual): fp8 operands when the weight is frozen and I2T_FP8=1, else the bf16 GEMM"""
+    def _lin(self, x_bf, W, names, out, M, N, K, bias=None, residual=None, act=0):
+        """out = act(x W^T (+ bias)) (+ residual): fp8 operands when the weight is frozen and I2T_FP8=1, else the bf16 GEMM"""
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
             x8, sx = self._fp8_rows(x_bf, M, K)
-            return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, _f8pad(K), bias=bias, residual=residual)
-        return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual)
+            return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, _f8pad(K), bias=bias, residual=residual, act=act)
+        return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual, act=act)
 
     def _lin_dx(self, dy_bf, W, names, out, M, N, K):
         """out [M, K] = dy [M, N] . W [N, K]"""

@@ -64,19 +64,24 @@ class ViTEncoder:
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(q + 'ln_1.weight'), a.P(q + 'ln_1.bias'), ln1, m1, r1, M, d, eps=VIT_EPS)
         qkv = self._empty(M, 3 * d, dtype=BF16)
-        ops.gemm(ln1, a.W(q + 'self_attention.in_proj_weight'), qkv, M, 3 * d, d, bias=a.P(q + 'self_attention.in_proj_bias'))
+        # (self._lin: e4m3 operands when the backbone is frozen and I2T_FP8=1 -- forward-only GEMMs of weights that never change)
+        lin = (lambda x_, name, out, N_, K_, **kw: self._lin(x_, a.W(name), name, out, M, N_, K_, **kw))
+        lin(ln1, q + 'self_attention.in_proj_weight', qkv, 3 * d, d, bias=a.P(q + 'self_attention.in_proj_bias'))
         q3 = qkv.view(B, T, 3 * d)
         ao, lse = self._empty(B, T, d, dtype=BF16), self._empty(H * M)
         ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], ao, lse, B, H, T, T, False)
         x1 = self._empty(M, d)
-        ops.gemm(ao.view(M, d), a.W(q + 'self_attention.out_proj.weight'), x1, M, d, d, bias=a.P(q + 'self_attention.out_proj.bias'), residual=x)
+        lin(ao.view(M, d), q + 'self_attention.out_proj.weight', x1, d, d, bias=a.P(q + 'self_attention.out_proj.bias'), residual=x)
         ln2, m2, r2 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x1, a.P(q + 'ln_2.weight'), a.P(q + 'ln_2.bias'), ln2, m2, r2, M, d, eps=VIT_EPS)
         h = self._empty(M, ff, dtype=BF16)
         pre = self._empty(M, ff, dtype=BF16) if save else None
-        ops.gemm(ln2, a.W(q + 'mlp.0.weight'), h, M, ff, d, bias=a.P(q + 'mlp.0.bias'), act=ops.ACT_GELU_ERF, aux_out=pre)
+        if save:
+            ops.gemm(ln2, a.W(q + 'mlp.0.weight'), h, M, ff, d, bias=a.P(q + 'mlp.0.bias'), act=ops.ACT_GELU_ERF, aux_out=pre)
+        else:
+            lin(ln2, q + 'mlp.0.weight', h, ff, d, bias=a.P(q + 'mlp.0.bias'), act=ops.ACT_GELU_ERF)
         x2 = self._empty(M, d)
-        ops.gemm(h, a.W(q + 'mlp.3.weight'), x2, M, d, ff, bias=a.P(q + 'mlp.3.bias'), residual=x1)
+        lin(h, q + 'mlp.3.weight', x2, d, ff, bias=a.P(q + 'mlp.3.bias'), residual=x1)
         sv = SimpleNamespace(x=x, ln1=ln1, m1=m1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, ln2=ln2, m2=m2, r2=r2, h=h, pre=pre) if save else None
         return x2, sv
 
@@ -110,7 +115,7 @@ class ViTEncoder:
         patches = self._empty(B * e.P2, K0, dtype=BF16)
         ops.patchify(images, patches, B, 3, e.img, e.img, e.p)
         proj = self._empty(B * e.P2, d)
-        ops.gemm(patches, a.W(m + 'conv_proj.weight').view(d, K0), proj, B * e.P2, d, K0, bias=a.P(m + 'conv_proj.bias'))
+        self._lin(patches, a.W(m + 'conv_proj.weight').view(d, K0), m + 'conv_proj.weight', proj, B * e.P2, d, K0, bias=a.P(m + 'conv_proj.bias'))
         x = self._empty(B * T, d)
         ops.vit_tokens(proj, a.P(m + 'class_token'), a.P(m + 'encoder.pos_embedding'), x, B, T, d)
         saves = []

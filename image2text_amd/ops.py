@@ -642,10 +642,10 @@ def quant_cols_fp8(w, out, scale, N, K):
     return out
 
 
-def gemm_fp8(a8, sa, b8, sb, out, M, N, K, bias=None, residual=None):
-    """out[M, N] = (a8[M, K] . b8[N, K]^T) * sa[m] * sb[n] (+ bias) (+ residual f32); include/i2t.h::i2t_gemm_fp8."""
+def gemm_fp8(a8, sa, b8, sb, out, M, N, K, bias=None, residual=None, act=0):
+    """out[M, N] = act((a8[M, K] . b8[N, K]^T) * sa[m] * sb[n] (+ bias)) (+ residual f32); include/i2t.h::i2t_gemm_fp8."""
     _need_cuda(a8, b8, sa, sb, out)
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and out.dtype in (BF16, F32)
     _l.check(_lib().i2t_gemm_fp8(_stream(), _p(a8), a8.stride(0), _p(sa), _p(b8), b8.stride(0), _p(sb), _p(out), out.stride(0), int(out.dtype == F32),
-                                 M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0), 'i2t_gemm_fp8')
+                                 M, N, K, _p(bias), int(act), _p(residual), residual.stride(0) if residual is not None else 0), 'i2t_gemm_fp8')
     return out

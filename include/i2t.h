@@ -510,7 +510,8 @@ int i2t_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) operand path for frozen weights (BASELINE.json configs[4]; csrc/fp8.hip): C = (A8 . B8^T) * sa[m] * sb[n]
- * (+ bias[n]) (+ residual f32) on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales and per-row fp32 scales, fp32
+ * (+ bias[n]) (act: I2T_ACT_NONE | I2T_ACT_GELU | I2T_ACT_GELU_ERF, forward-only: no pre-activation output) (+ residual f32) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales and per-row fp32 scales, fp32
  * accumulate, C bf16 or f32.  Rows of both operands are K contiguous bytes, zero-padded to the leading dimension (% 16).
  *   i2t_quant_rows_fp8: x (bf16 or f32) [M][ld] -> out e4m3 [M][ld_out], scale[m] = amax(row m) / 448 (1 for a zero row)
  *   i2t_quant_cols_fp8: W bf16 [N][ld] -> out e4m3 [K][ld_out] = W^T with a scale per k: the operand of dx = dy . W
@@ -518,7 +519,7 @@ int i2t_deterministic(void);
 int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int ld, void* out, int ld_out, float* scale, int M, int K);
 int i2t_quant_cols_fp8(void* stream, const void* w, int ld, void* out, int ld_out, float* scale, int N, int K);
 int i2t_gemm_fp8(void* stream, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
-                 int c_is_f32, int M, int N, int K, const float* bias, const float* residual, int ldr);
+                 int c_is_f32, int M, int N, int K, const float* bias, int act, const float* residual, int ldr);
 
 #ifdef __cplusplus
 }

@@ -215,3 +215,39 @@ def test_lora_on_a_frozen_llama_base_with_fp8_operands(tmp_path, monkeypatch, p_
         worst = min(worst, c)
     REPORT[f'llama_lora_fp8.p{p_lora}.gradient_min_cosine_vs_bf16_path'] = worst
     assert worst >= 0.97
+
+
+def test_frozen_vit_backbone_on_fp8_operands(monkeypatch):
+    """PretrainedViT with refine_base_model: False and I2T_FP8=1: the backbone's forward-only GEMMs (patch projection, q|k|v, out-projection,
+    both MLP matrices -- the first with the exact-GELU epilogue of the fp8 classes) take e4m3 operands.  ViT-B/16 width, 2 layers, 224 x 224,
+    batch 56 (11 032 token rows: the persistent fp8 kernel for the wide GEMMs, the 128^2 one for the rest), against the same model on bf16:
+    features and encoder outputs reported and bounded (measured 8.5 % rel-L2 on these random-init weights after 9 e4m3 GEMMs -- each
+    carries ~3.7 %: per-row-scaled e4m3 has 3 mantissa bits; an opt-in speed / fidelity trade)."""
+    from image2text_amd import ops
+    monkeypatch.setenv('I2T_VIT_B16_CHECKPOINT', 'random')
+    from image2text_amd.synth import det_init_, synthetic_batch
+    from test_vit_gpu import build_model
+    spec = dict(image_size=224, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=3072)
+    vit_kw = dict(n_cls=8, n_embd_out_vit=128, gate_sizes=[256], refine_base_model=False)
+    m, cfg = build_model(vit_kw, spec, dec_d=128, dec_heads=2, dec_layers=1, block_size=48)
+    det_init_(m, seed=3)
+    m = m.to(dev()).eval()
+    eng = m._engine
+    images, _ = synthetic_batch(56, 224, 8, 384, seed=5)
+    outs = {}
+    for fp8 in (False, True):
+        eng.fp8 = fp8
+        n8 = []
+        orig = ops.gemm_fp8
+        monkeypatch.setattr(ops, 'gemm_fp8', lambda *a, **k: (n8.append(k.get('act', 0)), orig(*a, **k))[1])
+        with torch.no_grad():
+            eng.prepare(False)
+            feat, _ = eng.vit_backbone_fwd(images.to(dev()), False)
+            enc = m.encoder(images.to(dev()))
+        monkeypatch.setattr(ops, 'gemm_fp8', orig)
+        outs[fp8] = (feat.float().cpu(), enc.float().cpu(), n8)
+    assert outs[False][2] == [] and len(outs[True][2]) == 2 * (1 + 4 * 2) and outs[True][2].count(ops.ACT_GELU_ERF) == 2 * 2
+    rel_f = float((outs[True][0] - outs[False][0]).norm() / outs[False][0].norm())
+    rel_e = float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm())
+    REPORT['vit_frozen_fp8'] = {'features_rel_l2_vs_bf16_path': rel_f, 'encoder_output_rel_l2_vs_bf16_path': rel_e}
+    assert rel_f <= 1.2e-1 and rel_e <= 1.2e-1
