@@ -30,6 +30,22 @@ __global__ __launch_bounds__(256) void dgelu_erf_mul_kernel(const float* __restr
     }
 }
 
+// out = gelu(pre), both bf16 (tanh or exact form): the activation behind a projection whose GEMM has no activation epilogue with a
+// pre-activation output -- the fp8 classes (engine_llama's Falcon MLP on a frozen base, csrc/fp8.hip)
+template <bool ERF>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ out, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const u32x4 p = reinterpret_cast<const u32x4*>(pre)[i];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16lo(p[e]), b = bf16hi(p[e]);
+            o[e] = ERF ? pack_bf16x2(gelu_erf(a), gelu_erf(b)) : pack_bf16x2(gelu_tanh(a), gelu_tanh(b));
+        }
+        reinterpret_cast<u32x4*>(out)[i] = o;
+    }
+}
+
 // One pass over the adapted layer's input x [M][K] (bf16): copy it into the first K columns of the K-concatenated operand
 // xcat [M][ldc] and, when the adapter has input dropout, write the masked copy xd [M][K] next to it (mask index r * K + c: the index
 // space of i2t_dropout_apply and of the residual + dropout GEMM epilogue that applies the same mask in backward).
@@ -73,6 +89,17 @@ extern "C" int i2t_dgelu_erf_mul(void* stream, const float* dh, const void* pre,
     hipLaunchKernelGGL(dgelu_erf_mul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, dh,
                        (const bf16_t*)pre, (bf16_t*)out, n4);
     I2T_CHECK_LAUNCH("i2t_dgelu_erf_mul");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gelu_fwd(void* stream, const void* pre, void* out, long n, int erf) {
+    I2T_REQUIRE(pre && out && n > 0 && n % 8 == 0 && ALIGNED16(pre) && ALIGNED16(out), "i2t_gelu_fwd: bad args (n=%ld must be a multiple of 8)", n);
+    const long n8 = n >> 3;
+    const long blocks = (n8 + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+    if (erf) hipLaunchKernelGGL(gelu_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n8);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n8);
+    I2T_CHECK_LAUNCH("i2t_gelu_fwd");
     return I2T_OK;
 }
 

@@ -107,13 +107,13 @@ class LlamaBlocks:
             return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, _f8pad(K), bias=bias, residual=residual, act=act)
         return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual, act=act)
 
-    def _lin_dx(self, dy_bf, W, names, out, M, N, K):
-        """out [M, K] = dy [M, N] . W [N, K]"""
+    def _lin_dx(self, dy_bf, W, names, out, M, N, K, residual=None):
+        """out [M, K] = dy [M, N] . W [N, K] (+ residual f32; may be ``out`` itself)"""
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
             d8, sd = self._fp8_rows(dy_bf, M, N)
-            return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, _f8pad(N))
-        return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True)
+            return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, _f8pad(N), residual=residual)
+        return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True, residual=residual)
 
     # ---- LoRA adapters on these blocks (reference models/utils.py:46-65 -> peft LoraModel over the transformers module; the targets of
     # training_configs/gpu/llama2-13b.yaml: q_proj, k_proj, v_proj, o_proj, up_proj, down_proj).  The fused projections keep ONE GEMM:
@@ -293,6 +293,10 @@ class LlamaBlocks:
         h, pre = self._empty(M, ff, dtype=BF16), (self._empty(M, ff, dtype=BF16) if save else None)
         if lo['gu'] is not None:
             svlo['gu'] = self._lora_gemm(lo['gu'], n1, v.Wgu, h, M, ldrop('gu'), save, act=ops.ACT_GELU_ERF, aux_out=pre)
+        elif self._fp8_on(v.names.gu):                    # frozen base on fp8 operands: product -> pre-activation, one more pass applies the GELU
+            tgt = pre if pre is not None else h
+            self._lin(n1, v.Wgu, v.names.gu, tgt, M, ff, d)
+            ops.gelu_fwd(tgt, h, erf=True)
         else:
             ops.gemm(n1, v.Wgu, h, M, ff, d, act=ops.ACT_GELU_ERF, aux_out=pre)
         x2 = self._empty(M, d)
@@ -322,14 +326,19 @@ class LlamaBlocks:
         else:
             if tr(nm.dn):
                 ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
-            ops.gemm(dxb, v.Wdn, dpre, M, ff, d, b_kmajor=True, act=ops.ACT_DGELU_ERF, aux_in=sv.pre)
+            if self._fp8_on(nm.dn):
+                dh32 = self._empty(M, ff)
+                self._lin_dx(dxb, v.Wdn, nm.dn, dh32, M, d, ff)
+                ops.dgelu_mul(dh32, sv.pre, dpre, erf=True)
+            else:
+                ops.gemm(dxb, v.Wdn, dpre, M, ff, d, b_kmajor=True, act=ops.ACT_DGELU_ERF, aux_in=sv.pre)
         if 'gu' in svlo:
             dn1 = lora_bwd('gu', dpre, sv.n1, v.Wgu, nm.gu, v.Ggu)
         else:
             if tr(nm.gu):
                 ops.gemm(dpre, sv.n1, v.Ggu, ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
             dn1 = self._empty(M, d)
-            ops.gemm(dpre, v.Wgu, dn1, M, d, ff, b_kmajor=True)
+            self._lin_dx(dpre, v.Wgu, nm.gu, dn1, M, ff, d)
         # ---- attention branch: both branches read the same LayerNorm output, their input gradients add up in dn1
         dao = self._empty(M, H * hd, dtype=BF16)
         if 'o' in svlo:
@@ -350,7 +359,7 @@ class LlamaBlocks:
         else:
             if tr(nm.qkv):
                 ops.gemm(dqkv, sv.n1, v.Gqkv, v.nq, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)
-            ops.gemm(dqkv, v.Wqkv, dn1, M, d, v.nq, b_kmajor=True, residual=dn1)
+            self._lin_dx(dqkv, v.Wqkv, nm.qkv, dn1, M, v.nq, d, residual=dn1)
         ops.layernorm_bwd(dn1, sv.x, v.n1, sv.m1, sv.r1, dx, v.gn1 if tr(nm.n1) else None, v.gb1 if tr(nm.b1) else None, M, d,
                           dx_accumulate=True, dx_bf16=dxb)
 

@@ -64,7 +64,7 @@ class LoraAdapters:
         """out = epilogue([x | u] . [W | s B | 0]^T), u = dropout(x) . A^T.  x bf16 [M, K] contiguous, W bf16 [N, K].  Returns what
         the backward needs (u and s B, both [*, LPAD] bf16) when save."""
         K, N = ls.K, ls.N
-        if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames) and not epilogue.get('act') and epilogue.get('aux_out') is None:
+        if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames) and epilogue.get('act', 0) in (0, ops.ACT_GELU, ops.ACT_GELU_ERF):
             return self._lora_gemm_fp8(ls, x, W, out, M, drop_l, save, **epilogue)
         xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
         xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
@@ -79,12 +79,17 @@ class LoraAdapters:
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
         return SimpleNamespace(u=u, sB=wcat[:, K:].contiguous(), xd=xd) if save else None
 
-    def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, **_):
+    def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, act=0, aux_out=None, **_):
         """The same layer with its FROZEN base weight on fp8 operands (I2T_FP8=1; engine_llama._fp8_*): the base product runs
         at the fp8 MFMA rate, so the adapter leaves the K panel -- out = fp8(x) . fp8(W)^T (+ bias) (+ residual) + u . (s B)^T, the
         rank-128 product added by a second, thin GEMM (in place on an fp32 output; ahead of the base GEMM, as its fp32 residual, when
         the output is bf16).  No K-concatenated copies of x and W; one quantisation pass over x instead."""
         K, N = ls.K, ls.N
+        if act:          # GELU behind the layer (Falcon's dense_h_to_4h): the product goes to the pre-activation buffer, one more pass applies it
+            pre = aux_out if aux_out is not None else torch.empty(M, N, dtype=BF16, device=x.device)
+            sv = self._lora_gemm_fp8(ls, x, W, pre, M, drop_l, save, bias=bias, residual=residual)
+            ops.gelu_fwd(pre, out, erf=(act == ops.ACT_GELU_ERF))
+            return sv
         xd = None
         if drop_l is not None:
             xd = x.clone()

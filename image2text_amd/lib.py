@@ -79,6 +79,7 @@ SIGNATURES = {
     'i2t_swiglu_bwd': [P, P, P, I, P, I, I],
     'i2t_dgelu_mul': [P, P, P, P, L],
     'i2t_dgelu_erf_mul': [P, P, P, P, L],
+    'i2t_gelu_fwd': [P, P, P, L, I],
     'i2t_lora_stage': [P, P, P, I, P, L, I, U, U, F],
     'i2t_gemm_bf16_ws': [P, P, I, P, I, P, I, I, I, I, I, P, I, P, I, P, L],
     'i2t_patchify': [P, P, P, I, I, I, I, I],

@@ -384,6 +384,14 @@ def dgelu_mul(dh, pre, out, erf=False):
     return out
 
 
+def gelu_fwd(pre, out, erf=False):
+    """out (bf16) = gelu(pre (bf16)), contiguous (include/i2t.h::i2t_gelu_fwd)"""
+    _need_cuda(pre, out)
+    assert pre.dtype == BF16 and out.dtype == BF16 and pre.is_contiguous() and out.is_contiguous()
+    _l.check(_lib().i2t_gelu_fwd(_stream(), _p(pre), _p(out), pre.numel(), int(bool(erf))), 'i2t_gelu_fwd')
+    return out
+
+
 def lora_stage(x, xcat, xd, M, K, drop):
     """xcat[:, :K] = x and (xd not None) xd = dropout(x): include/i2t.h::i2t_lora_stage; drop = (1, key, thr, scale) | None"""
     _need_cuda(x, xcat)

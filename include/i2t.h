@@ -417,6 +417,9 @@ int i2t_swiglu_bwd(void* stream, const void* dh, const void* gate_up, int ld, vo
 int i2t_dgelu_mul(void* stream, const float* dh, const void* pre, void* out, long n);
 /* ... and behind an exact (erf) GELU (transformers' Falcon MLP, nn.GELU()): out = dh * gelu_erf'(pre). */
 int i2t_dgelu_erf_mul(void* stream, const float* dh, const void* pre, void* out, long n);
+/* out (bf16) = gelu(pre (bf16)), tanh form or (erf != 0) exact: the activation behind a projection whose GEMM cannot apply it while
+ * also writing the pre-activation (the fp8 classes of i2t_gemm_fp8). */
+int i2t_gelu_fwd(void* stream, const void* pre, void* out, long n, int erf);
 /* One pass over an adapted layer's input x bf16 [M][K]: xcat[m][0..K) = x[m] (xcat bf16 [M][ldc] is the K-concatenated operand
  * [x | u] of the layer's GEMM) and, when xd is not null, xd [M][K] = dropout(x) with the elementwise mask (key, thr, scale; index
  * m * K + k, the index space of i2t_dropout_apply) -- the adapter's input (peft's lora_dropout). */

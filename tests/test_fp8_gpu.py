@@ -251,3 +251,61 @@ def test_frozen_vit_backbone_on_fp8_operands(monkeypatch):
     rel_e = float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm())
     REPORT['vit_frozen_fp8'] = {'features_rel_l2_vs_bf16_path': rel_f, 'encoder_output_rel_l2_vs_bf16_path': rel_e}
     assert rel_f <= 1.2e-1 and rel_e <= 1.2e-1
+
+
+@pytest.mark.parametrize('mode', ['frozen', 'lora'])
+def test_falcon_decoder_on_fp8_operands(tmp_path, monkeypatch, mode):
+    """The falcon-7b block on a frozen base with e4m3 operands: every projection forward and dx, the MLP's first one through the
+    product -> pre-activation -> GELU pass route (the fp8 classes cannot write a pre-activation beside the activated output).  'frozen' =
+    prepare_for_kbit_training, 'lora' = the lora_spec of gpu/falcon-7b.yaml.  Against the same model on the bf16 path."""
+    from image2text_amd import ops
+    from image2text_amd.configs.models import LoraSpec
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.synth import det_init_, synthetic_batch, tiny_config
+    from test_host_cpu import _hf_decoder_config, _local_hf_falcon
+    _, name, vocab = _local_hf_falcon(tmp_path, monkeypatch)
+    V = vocab + 1
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=0.0, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h']) if mode == 'lora' else None
+    cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec,
+                                                                       prepare_for_kbit_training=mode == 'frozen'),
+                                     use_cross_attn=False, use_soft_prompting=True))
+    m = VisionEncoderDecoder(cfg)
+    keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
+    det_init_(m, seed=0)
+    m.decoder.load_state_dict(keep)
+    m.decoder.tie_weights()
+    if spec is not None:
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(9)
+            for n, p in m.decoder.lora_params.items():
+                if n.endswith('_B'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    m = m.to(dev()).train()
+    eng = m._engine
+    images, labels = synthetic_batch(3, 32, 12, V, seed=17)
+    ids = labels.clamp(min=0)
+    wl = (torch.randn(3, 12, V, generator=torch.Generator().manual_seed(2)) * 0.01).to(dev())
+    runs = {}
+    for fp8 in (False, True):
+        eng.fp8 = fp8
+        n8 = []
+        orig = ops.gemm_fp8
+        monkeypatch.setattr(ops, 'gemm_fp8', lambda *a, **k: (n8.append(1), orig(*a, **k))[1])
+        for p in m.parameters():
+            p.grad = None
+        out = m(images=images.to(dev()), ids=ids.to(dev()))
+        (out.logits * wl).sum().backward()
+        monkeypatch.setattr(ops, 'gemm_fp8', orig)
+        runs[fp8] = (out.logits.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}, len(n8))
+    assert runs[False][2] == 0 and runs[True][2] == 2 * (4 + 4), runs[True][2]       # per layer: four projections forward + their four dx GEMMs
+    rel = float((runs[True][0] - runs[False][0]).norm() / runs[False][0].norm())
+    REPORT[f'falcon_{mode}_fp8.logits_rel_l2_vs_bf16_path'] = rel
+    assert rel <= 8e-2
+    assert set(runs[True][1]) == set(runs[False][1]) and runs[True][1]
+    worst = 1.0
+    for n, g8 in runs[True][1].items():
+        gb = runs[False][1][n]
+        worst = min(worst, float(g8.double().ravel() @ gb.double().ravel() / (g8.double().norm() * gb.double().norm() + 1e-30)))
+    REPORT[f'falcon_{mode}_fp8.gradient_min_cosine_vs_bf16_path'] = worst
+    assert worst >= 0.97
