@@ -50,5 +50,32 @@ for (M, N, K) in shapes:
                 print(f'MISMATCH {form} M={M} N={N} K={K} iter {it}: {int((d > 0).sum())} elements, max {float(d.max()):.4g}', flush=True)
         torch.cuda.synchronize()
     print(f'M={M} N={N} K={K}: done', flush=True)
+# the same screen for the persistent kernel on fp8 operands (class 9: its own fragment-refill schedule and fence budgets)
+for (M, N, K) in [(12800, 4096, 4096), (16384, 2304, 768), (3000, 3460, 256), (8192, 4096, 11008)]:
+    x = torch.randn(M, K, device=dev).to(BF16)
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(BF16)
+    x8, sx = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, device=dev)
+    w8, sw = torch.empty(N, K, dtype=torch.uint8, device=dev), torch.empty(N, device=dev)
+    ops.quant_rows_fp8(x, x8, sx, M, K)
+    ops.quant_rows_fp8(w, w8, sw, N, K)
+    res = torch.randn(M, N, device=dev)
+    for form in ('bf16', 'f32res'):
+        def run8():
+            o = torch.empty(M, N, device=dev, dtype=BF16 if form == 'bf16' else F32)
+            ops.gemm_fp8(x8, sx, w8, sw, o, M, N, K, residual=res if form == 'f32res' else None)
+            return o
+        ref = run8()
+        torch.cuda.synchronize()
+        for it in range(40):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    noise_b.copy_(noise_a)
+            out = run8()
+            if not torch.equal(out, ref):
+                bad += 1
+                d = (out.float() - ref.float()).abs()
+                print(f'MISMATCH fp8 {form} M={M} N={N} K={K} iter {it}: {int((d > 0).sum())} elements, max {float(d.max()):.4g}', flush=True)
+        torch.cuda.synchronize()
+    print(f'fp8 M={M} N={N} K={K}: done', flush=True)
 print('mismatches:', bad)
 sys.exit(1 if bad else 0)
