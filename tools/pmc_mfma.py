@@ -15,7 +15,7 @@ import sys
 
 FAMILIES = (('gemm256_kernel<false, false, 8>', 'fused cross-attention (K/V projection + attention)'), ('gemm3_kernel', 'gemm3 (256x128, overlapped epilogue)'),
             ('gemm256_kernel', 'gemm256 (persistent 256^2)'), ('gemm_bf16_kernel', 'gemm 128^2'), ('gemm_skinny', 'gemm skinny'),
-            ('attn_fwd2', 'attention fwd (LDS-resident, encoder)'), ('attn_bwd2', 'attention bwd (LDS-resident, fused dQ/dK/dV, encoder)'),
+            ('attn_fwd2', 'attention fwd (LDS-resident, encoder)'), ('attn_bwd3', 'attention bwd (LDS-resident, one softmax pass, encoder)'), ('attn_bwd2', 'attention bwd (LDS-resident, two-phase, encoder)'),
             ('attn_fwd', 'attention fwd'), ('attn_bwd_dq', 'attention bwd dQ'), ('attn_bwd_dkv', 'attention bwd dK/dV'),
             ('conv_mfma_bwd_weight', 'conv bwd-weight'), ('conv_mfma_kernel', 'conv fwd / bwd-data'), ('ln_bwd', 'layernorm bwd'))
 N_SIMD = 256 * 4
