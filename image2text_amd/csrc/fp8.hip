@@ -60,6 +60,61 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const void* __restrict_
     }
 }
 
+// ---- the same in ONE pass over the row (K % 8 == 0, K <= TPR x 96): TPR threads per row keep their 16-byte chunks in registers between the
+// amax reduction and the conversion (the two-pass kernel above re-reads the row and moves 8 bytes per lane and trip: 2-3x off the HBM time
+// of its 3 bytes per element at the decoder widths).  TPR = 64: a wave per row (K <= 6144); TPR = 256: a workgroup per row (K <= 24576).
+template <bool IN_F32, int TPR>
+__global__ __launch_bounds__(256) void quant_rows1_kernel(const void* __restrict__ x, int ld, unsigned char* __restrict__ out, int ld_out,
+                                                          float* __restrict__ scale, int M, int K) {
+    constexpr int MAXI = 12, RPB = 256 / TPR;
+    __shared__ float red[16];
+    const int t = threadIdx.x % TPR, row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const bool live = row < M;
+    f32x4 v[MAXI][2];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = (t + TPR * i) * 8;
+        v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && c < K) {
+            if (IN_F32) {
+                const float* p = reinterpret_cast<const float*>(x) + (size_t)row * ld + c;
+                v[i][0] = *reinterpret_cast<const f32x4*>(p);
+                v[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            } else {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(x) + (size_t)row * ld + c);
+                v[i][0] = f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+                v[i][1] = f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][h][0]), fabsf(v[i][h][1]))), fmaxf(fabsf(v[i][h][2]), fabsf(v[i][h][3])));
+        }
+    }
+    if (TPR == 64) amax = wave_max(amax);
+    else amax = block_max(amax, red);
+    const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+    if (!live) return;
+    if (t == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = (t + TPR * i) * 8;
+        if (c >= ld_out) continue;                 // (ld_out % 16 == 0; chunks in [K, ld_out) are the zero padding)
+        unsigned pk[2] = {0u, 0u};
+        if (c < K) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = fminf(fmaxf(v[i][h][e] / sc, -E4M3_MAX), E4M3_MAX);
+                pk[h] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                pk[h] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], (int)pk[h], true);
+            }
+        }
+        *reinterpret_cast<u32x2*>(out + (size_t)row * ld_out + c) = u32x2{pk[0], pk[1]};
+    }
+}
+
 // ---- transposed quantisation of a weight W bf16 [N][K]: out8 [K][Np] with a scale per k (row of W^T): the dx = dy . W operand.
 // One workgroup per 64 k-columns: pass 1 column amax over all n, pass 2 convert and store 4 n at a time per k (tiny, once per version).
 __global__ __launch_bounds__(256) void quant_cols_kernel(const bf16_t* __restrict__ w, int ld, unsigned char* __restrict__ out, int ld_out,
@@ -204,8 +259,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Params p) {
 extern "C" int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int ld, void* out, int ld_out, float* scale, int M, int K) {
     I2T_REQUIRE(x && out && scale && M > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && ld_out % 16 == 0 && ld_out >= K && ALIGNED16(x) && ALIGNED16(out),
                 "i2t_quant_rows_fp8: bad args (K=%d %% 4, ld_out=%d %% 16 and >= K)", K, ld_out);
-    if (x_is_f32) hipLaunchKernelGGL(quant_rows_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)out, ld_out, scale, M, K);
-    else hipLaunchKernelGGL(quant_rows_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)out, ld_out, scale, M, K);
+    hipStream_t s_ = (hipStream_t)stream;
+    unsigned char* o_ = (unsigned char*)out;
+    // (K < 2048: a row is a fraction of a wave's 12 register chunks -- the two-pass kernel is the faster one there: 36 vs 50 us at K = 768)
+    const bool one_pass = K % 8 == 0 && K >= 2048 && ld % 8 == 0 && ld_out <= 24576 && !(getenv("I2T_FP8_QUANT1") && getenv("I2T_FP8_QUANT1")[0] == '0');
+    if (one_pass && ld_out <= 6144) {          // a wave per row
+        if (x_is_f32) hipLaunchKernelGGL((quant_rows1_kernel<true, 64>), dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
+        else hipLaunchKernelGGL((quant_rows1_kernel<false, 64>), dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
+    } else if (one_pass) {                     // a workgroup per row
+        if (x_is_f32) hipLaunchKernelGGL((quant_rows1_kernel<true, 256>), dim3(M), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
+        else hipLaunchKernelGGL((quant_rows1_kernel<false, 256>), dim3(M), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
+    } else if (x_is_f32) hipLaunchKernelGGL(quant_rows_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
+    else hipLaunchKernelGGL(quant_rows_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
     I2T_CHECK_LAUNCH("i2t_quant_rows_fp8");
     return I2T_OK;
 }

@@ -29,7 +29,9 @@ def dequant(q8, scale):
     return q8.view(torch.float8_e4m3fn).float() * scale[:, None]
 
 
-@pytest.mark.parametrize('M,K,dtype', [(37, 768, BF16), (130, 4096, F32), (5, 100, BF16)])
+# (K % 8 == 0: the one-pass kernel -- a wave per row up to 6144 columns, a workgroup per row beyond; K = 100: the two-pass one)
+@pytest.mark.parametrize('M,K,dtype', [(37, 768, BF16), (130, 4096, F32), (5, 100, BF16), (67, 11008, BF16), (9, 22016, BF16), (33, 4544, BF16),
+                                       (21, 8192, F32)])
 def test_row_quantisation_is_ocp_e4m3(M, K, dtype):
     from image2text_amd import ops
     g = torch.Generator().manual_seed(M)
