@@ -140,6 +140,108 @@ __global__ __launch_bounds__(256) void quant_cols_kernel(const bf16_t* __restric
     }
 }
 
+// ---- producers that emit the fp8 operand themselves (frozen Llama / Qwen2 blocks, engine_llama): the row is in registers anyway, so the
+// amax, the scale and the conversion ride along and the bf16 copy + the quantisation pass over it (3 bytes per element each way) disappear.
+// One workgroup per row; a thread owns chunks t + 256 i.  Scales and rounding as quant_rows (from the fp32 values, not from a bf16 copy).
+__device__ __forceinline__ float sigmoid_(float v) { return 1.f / (1.f + __expf(-v)); }       // (as csrc/llama.hip)
+__device__ __forceinline__ unsigned f8_pack4(const f32x4& v, float sc) {
+    unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0] / sc, -E4M3_MAX), E4M3_MAX), fminf(fmaxf(v[1] / sc, -E4M3_MAX), E4M3_MAX), 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2] / sc, -E4M3_MAX), E4M3_MAX), fminf(fmaxf(v[3] / sc, -E4M3_MAX), E4M3_MAX), (int)pk, true);
+}
+__device__ __forceinline__ float f8_amax4(float a, const f32x4& v) {
+    return fmaxf(fmaxf(a, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// RMSNorm: y = w x rsqrt(mean(x^2) + eps) -> e4m3 row + scale (+ rstd for the backward); d <= 8192
+__global__ __launch_bounds__(256) void rms_fwd_fp8_kernel(const float* __restrict__ x, const float* __restrict__ w, unsigned char* __restrict__ y8,
+                                                          int ld8, float* __restrict__ scale, float* __restrict__ rstd_out, int d, float eps) {
+    constexpr int MAXI = 8;
+    __shared__ float red[16];
+    const int row = blockIdx.x, t = threadIdx.x, nc = d >> 2;
+    f32x4 v[MAXI];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = t + 256 * i;
+        v[i] = c < nc ? reinterpret_cast<const f32x4*>(x + (size_t)row * d)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+    const float rs = rsqrtf(block_sum(ss, red) / d + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = t + 256 * i;
+        if (c < nc) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(w)[c];
+            v[i] = f32x4{v[i][0] * rs * g[0], v[i][1] * rs * g[1], v[i][2] * rs * g[2], v[i][3] * rs * g[3]};
+            amax = f8_amax4(amax, v[i]);
+        }
+    }
+    amax = block_max(amax, red);
+    const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+    if (t == 0) {
+        scale[row] = sc;
+        if (rstd_out) rstd_out[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = t + 256 * i;
+        if (c * 4 < ld8) *reinterpret_cast<unsigned*>(y8 + (size_t)row * ld8 + c * 4) = c < nc ? f8_pack4(v[i], sc) : 0u;
+    }
+}
+
+// SwiGLU forward: h = silu(gate) up -> e4m3 row + scale; ff <= 12288.  BWD: [d gate | d up] of the fused projection -> e4m3 row (2 ff) + scale
+template <bool BWD>
+__global__ __launch_bounds__(256) void swiglu_fp8_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu, int ld,
+                                                         unsigned char* __restrict__ out8, int ld8, float* __restrict__ scale, int ff) {
+    constexpr int MAXI = 6;
+    __shared__ float red[16];
+    const int row = blockIdx.x, t = threadIdx.x, n8 = ff >> 3;
+    f32x4 a[MAXI][2], b[BWD ? MAXI : 1][2];          // forward: a = h; backward: a = d gate, b = d up
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = t + 256 * i;
+        a[i][0] = a[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BWD) b[i][0] = b[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c >= n8) continue;
+        const u32x4 g = *reinterpret_cast<const u32x4*>(gu + (size_t)row * ld + c * 8);
+        const u32x4 u = *reinterpret_cast<const u32x4*>(gu + (size_t)row * ld + ff + c * 8);
+        u32x4 dv = {0u, 0u, 0u, 0u};
+        if (BWD) dv = *reinterpret_cast<const u32x4*>(dh + (size_t)row * ff + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gl = bf16lo(g[e]), gh = bf16hi(g[e]), sl = sigmoid_(gl), sh = sigmoid_(gh);
+            const float ul = bf16lo(u[e]), uh = bf16hi(u[e]);
+            if (!BWD) {
+                a[i][e >> 1][(e & 1) * 2] = gl * sl * ul;
+                a[i][e >> 1][(e & 1) * 2 + 1] = gh * sh * uh;
+            } else {
+                const float dl = bf16lo(dv[e]), dhh = bf16hi(dv[e]);
+                a[i][e >> 1][(e & 1) * 2] = dl * ul * (sl + gl * sl * (1.f - sl));
+                a[i][e >> 1][(e & 1) * 2 + 1] = dhh * uh * (sh + gh * sh * (1.f - sh));
+                b[i][e >> 1][(e & 1) * 2] = dl * gl * sl;
+                b[i][e >> 1][(e & 1) * 2 + 1] = dhh * gh * sh;
+            }
+        }
+        amax = f8_amax4(f8_amax4(amax, a[i][0]), a[i][1]);
+        if (BWD) amax = f8_amax4(f8_amax4(amax, b[i][0]), b[i][1]);
+    }
+    amax = block_max(amax, red);
+    const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+    if (t == 0) scale[row] = sc;
+    const int width = BWD ? 2 * ff : ff;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = t + 256 * i;
+        if (c < n8) {
+            *reinterpret_cast<u32x2*>(out8 + (size_t)row * ld8 + c * 8) = u32x2{f8_pack4(a[i][0], sc), f8_pack4(a[i][1], sc)};
+            if (BWD) *reinterpret_cast<u32x2*>(out8 + (size_t)row * ld8 + ff + c * 8) = u32x2{f8_pack4(b[i][0], sc), f8_pack4(b[i][1], sc)};
+        }
+    }
+    for (int c = width + t * 8; c < ld8; c += 2048) *reinterpret_cast<u32x2*>(out8 + (size_t)row * ld8 + c) = u32x2{0u, 0u};      // zero padding
+}
+
 struct F8Params {
     const unsigned char* A;      // [M][lda] e4m3
     const unsigned char* B;      // [N][ldb] e4m3
@@ -272,6 +374,32 @@ extern "C" int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int
     } else if (x_is_f32) hipLaunchKernelGGL(quant_rows_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
     else hipLaunchKernelGGL(quant_rows_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s_, x, ld, o_, ld_out, scale, M, K);
     I2T_CHECK_LAUNCH("i2t_quant_rows_fp8");
+    return I2T_OK;
+}
+
+extern "C" int i2t_rmsnorm_fwd_fp8(void* stream, const float* x, const float* w, void* y8, int ld8, float* scale, float* rstd, int M, int d, float eps) {
+    I2T_REQUIRE(x && w && y8 && scale && M > 0 && d > 0 && d % 4 == 0 && d <= 8192 && ld8 % 16 == 0 && ld8 >= d && ld8 <= 8192 && ALIGNED16(x) && ALIGNED16(y8),
+                "i2t_rmsnorm_fwd_fp8: bad args (d=%d <= 8192, ld8=%d %% 16)", d, ld8);
+    hipLaunchKernelGGL(rms_fwd_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, (unsigned char*)y8, ld8, scale, rstd, d, eps);
+    I2T_CHECK_LAUNCH("i2t_rmsnorm_fwd_fp8");
+    return I2T_OK;
+}
+
+extern "C" int i2t_swiglu_fwd_fp8(void* stream, const void* gate_up, int ld, void* h8, int ld8, float* scale, int M, int ff) {
+    I2T_REQUIRE(gate_up && h8 && scale && M > 0 && ff > 0 && ff % 8 == 0 && ff <= 12288 && ld >= 2 * ff && ld % 8 == 0 && ld8 % 16 == 0 && ld8 >= ff &&
+                    ALIGNED16(gate_up) && ALIGNED16(h8), "i2t_swiglu_fwd_fp8: bad args (ff=%d <= 12288)", ff);
+    hipLaunchKernelGGL(swiglu_fp8_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, (const bf16_t*)gate_up, ld,
+                       (unsigned char*)h8, ld8, scale, ff);
+    I2T_CHECK_LAUNCH("i2t_swiglu_fwd_fp8");
+    return I2T_OK;
+}
+
+extern "C" int i2t_swiglu_bwd_fp8(void* stream, const void* dh, const void* gate_up, int ld, void* dgu8, int ld8, float* scale, int M, int ff) {
+    I2T_REQUIRE(dh && gate_up && dgu8 && scale && M > 0 && ff > 0 && ff % 8 == 0 && ff <= 12288 && ld >= 2 * ff && ld % 8 == 0 && ld8 % 16 == 0 &&
+                    ld8 >= 2 * ff && ALIGNED16(gate_up) && ALIGNED16(dh) && ALIGNED16(dgu8), "i2t_swiglu_bwd_fp8: bad args (ff=%d <= 12288)", ff);
+    hipLaunchKernelGGL(swiglu_fp8_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)gate_up, ld,
+                       (unsigned char*)dgu8, ld8, scale, ff);
+    I2T_CHECK_LAUNCH("i2t_swiglu_bwd_fp8");
     return I2T_OK;
 }
 

@@ -99,19 +99,20 @@ class LlamaBlocks:
         ops.quant_rows_fp8(x_bf, x8, sx, M, K)
         return x8, sx
 
-    def _lin(self, x_bf, W, names, out, M, N, K, bias=None, residual=None, act=0):
-        """out = act(x W^T (+ bias)) (+ residual): fp8 operands when the weight is frozen and I2T_FP8=1, else the bf16 GEMM"""
+    def _lin(self, x_bf, W, names, out, M, N, K, bias=None, residual=None, act=0, xq=None):
+        """out = act(x W^T (+ bias)) (+ residual): fp8 operands when the weight is frozen and I2T_FP8=1, else the bf16 GEMM.
+        xq = (x8, scale): the producer already emitted the e4m3 operand (rmsnorm_fwd_fp8 / swiglu_fwd_fp8); x_bf may then be None."""
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
-            x8, sx = self._fp8_rows(x_bf, M, K)
+            x8, sx = xq if xq is not None else self._fp8_rows(x_bf, M, K)
             return ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, _f8pad(K), bias=bias, residual=residual, act=act)
         return ops.gemm(x_bf, W, out, M, N, K, bias=bias, residual=residual, act=act)
 
-    def _lin_dx(self, dy_bf, W, names, out, M, N, K, residual=None):
-        """out [M, K] = dy [M, N] . W [N, K] (+ residual f32; may be ``out`` itself)"""
+    def _lin_dx(self, dy_bf, W, names, out, M, N, K, residual=None, dq=None):
+        """out [M, K] = dy [M, N] . W [N, K] (+ residual f32; may be ``out`` itself); dq = (dy8, scale) from a fused producer"""
         if self._fp8_on(names):
             e = self._fp8_weight(names, W)
-            d8, sd = self._fp8_rows(dy_bf, M, N)
+            d8, sd = dq if dq is not None else self._fp8_rows(dy_bf, M, N)
             return ops.gemm_fp8(d8, sd, e.wt8, e.swt, out, M, K, _f8pad(N), residual=residual)
         return ops.gemm(dy_bf, W, out, M, K, N, b_kmajor=True, residual=residual)
 
@@ -164,14 +165,29 @@ class LlamaBlocks:
         cu, rpos = (vl.cu, vl.pos) if vl is not None else (None, None)
         v3 = (lambda t, w: t) if vl is not None else (lambda t, w: t.view(B, T, w))
         cs = self.rope_table()
-        n1, r1 = self._empty(M, d, dtype=BF16), self._empty(M)
-        ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
-        qkv = self._empty(M, v.nq, dtype=BF16)
         plan = self.dec_drop if save else None
         ldrop = (lambda site: plan.get(l, f'lora_{site}') if plan is not None else None)
         lo = {site: self._llama_lora(l, site) for site in ('qkv', 'o', 'gu', 'dn')}
         svlo = {}
-        if lo['qkv'] is not None:
+        # frozen projections on fp8 operands without adapters: the producing row kernel emits the e4m3 operand itself (csrc/fp8.hip) --
+        # no bf16 copy of n1 / n2 / h is written and no quantisation pass reads it (nothing else wants them: a frozen weight has no dW)
+        fuse = self.fp8 and self.fp8_fuse and d <= 8192 and ff <= 12288
+        f_qkv = fuse and lo['qkv'] is None and self._fp8_on(v.names.qkv)
+        f_gu = fuse and lo['gu'] is None and self._fp8_on(v.names.gu)
+        f_dn = fuse and lo['dn'] is None and self._fp8_on(v.names.dn)
+        r1 = self._empty(M)
+        qkv = self._empty(M, v.nq, dtype=BF16)
+        if f_qkv:
+            n1 = None
+            n1q = (torch.empty(M, _f8pad(d), dtype=torch.uint8, device=x.device), self._empty(M))
+            ops.rmsnorm_fwd_fp8(x, v.n1, n1q[0], n1q[1], r1, M, d, ls.eps)
+            self._lin(None, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv, xq=n1q)
+        else:
+            n1 = self._empty(M, d, dtype=BF16)
+            ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
+        if f_qkv:
+            pass
+        elif lo['qkv'] is not None:
             svlo['qkv'] = self._lora_gemm(lo['qkv'], n1, v.Wqkv, qkv, M, ldrop('qkv'), save, bias=v.bqkv)
         else:
             self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv)
@@ -185,20 +201,33 @@ class LlamaBlocks:
             svlo['o'] = self._lora_gemm(lo['o'], ao, v.Wo, x1, M, ldrop('o'), save, residual=x)
         else:
             self._lin(ao, v.Wo, v.names.o, x1, M, d, H * hd, residual=x)
-        n2, r2 = self._empty(M, d, dtype=BF16), self._empty(M)
-        ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
+        r2 = self._empty(M)
         gu = self._empty(M, 2 * ff, dtype=BF16)
-        if lo['gu'] is not None:
-            svlo['gu'] = self._lora_gemm(lo['gu'], n2, v.Wgu, gu, M, ldrop('gu'), save)
+        if f_gu:
+            n2 = None
+            n2q = (torch.empty(M, _f8pad(d), dtype=torch.uint8, device=x.device), self._empty(M))
+            ops.rmsnorm_fwd_fp8(x1, v.n2, n2q[0], n2q[1], r2, M, d, ls.eps)
+            self._lin(None, v.Wgu, v.names.gu, gu, M, 2 * ff, d, xq=n2q)
         else:
-            self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
-        h = self._empty(M, ff, dtype=BF16)
-        ops.swiglu_fwd(gu, h, M, ff)
+            n2 = self._empty(M, d, dtype=BF16)
+            ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
+            if lo['gu'] is not None:
+                svlo['gu'] = self._lora_gemm(lo['gu'], n2, v.Wgu, gu, M, ldrop('gu'), save)
+            else:
+                self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
         x2 = self._empty(M, d)
-        if lo['dn'] is not None:
-            svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1)
+        if f_dn:
+            h = None
+            hq = (torch.empty(M, _f8pad(ff), dtype=torch.uint8, device=x.device), self._empty(M))
+            ops.swiglu_fwd_fp8(gu, hq[0], hq[1], M, ff)
+            self._lin(None, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1, xq=hq)
         else:
-            self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
+            h = self._empty(M, ff, dtype=BF16)
+            ops.swiglu_fwd(gu, h, M, ff)
+            if lo['dn'] is not None:
+                svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1)
+            else:
+                self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
         return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h, lo=svlo,
                                     lo_drop={site: ldrop(site) for site in lo}) if save else None)
 
@@ -225,10 +254,18 @@ class LlamaBlocks:
             if tr(nm.dn):
                 ops.gemm(dxb, sv.h, v.Gdn, d, ff, M, a_kmajor=True, b_kmajor=True, accumulate=True)
             self._lin_dx(dxb, v.Wdn, nm.dn, dh, M, d, ff)
-        dgu = self._empty(M, 2 * ff, dtype=BF16)
-        ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
         dn = self._empty(M, d, dtype=BF16)
-        if 'gu' in svlo:
+        if 'gu' not in svlo and not tr(nm.gu) and self.fp8 and self.fp8_fuse and self._fp8_on(nm.gu) and ff <= 12288:
+            dguq = (torch.empty(M, _f8pad(2 * ff), dtype=torch.uint8, device=dh.device), self._empty(M))
+            ops.swiglu_bwd_fp8(dh, sv.gu, dguq[0], dguq[1], M, ff)             # [d gate | d up] straight to the e4m3 operand of dx = d(gu) . W
+            self._lin_dx(None, v.Wgu, nm.gu, dn, M, 2 * ff, d, dq=dguq)
+            dgu, dn2 = None, dn
+        else:
+            dgu = self._empty(M, 2 * ff, dtype=BF16)
+            ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
+        if dgu is None:
+            pass
+        elif 'gu' in svlo:
             dn2 = lora_bwd('gu', dgu, sv.n2, v.Wgu, nm.gu, (2 * ff, d))      # fp32: rmsnorm_bwd takes either
         else:
             if tr(nm.gu):

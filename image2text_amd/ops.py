@@ -650,6 +650,26 @@ def quant_cols_fp8(w, out, scale, N, K):
     return out
 
 
+def rmsnorm_fwd_fp8(x, w, y8, scale, rstd, M, d, eps):
+    """y8 (e4m3 [M, ld8]) , scale [M] = quantised RMSNorm(x); rstd [M] or None  (include/i2t.h::i2t_rmsnorm_fwd_fp8)"""
+    _need_cuda(x, w, y8, scale)
+    _l.check(_lib().i2t_rmsnorm_fwd_fp8(_stream(), _p(x), _p(w), _p(y8), y8.stride(0), _p(scale), _p(rstd), M, d, float(eps)), 'i2t_rmsnorm_fwd_fp8')
+    return y8
+
+
+def swiglu_fwd_fp8(gate_up, h8, scale, M, ff):
+    _need_cuda(gate_up, h8, scale)
+    _l.check(_lib().i2t_swiglu_fwd_fp8(_stream(), _p(gate_up), gate_up.stride(0), _p(h8), h8.stride(0), _p(scale), M, ff), 'i2t_swiglu_fwd_fp8')
+    return h8
+
+
+def swiglu_bwd_fp8(dh, gate_up, dgu8, scale, M, ff):
+    _need_cuda(dh, gate_up, dgu8, scale)
+    assert dh.is_contiguous()
+    _l.check(_lib().i2t_swiglu_bwd_fp8(_stream(), _p(dh), _p(gate_up), gate_up.stride(0), _p(dgu8), dgu8.stride(0), _p(scale), M, ff), 'i2t_swiglu_bwd_fp8')
+    return dgu8
+
+
 def gemm_fp8(a8, sa, b8, sb, out, M, N, K, bias=None, residual=None, act=0):
     """out[M, N] = act((a8[M, K] . b8[N, K]^T) * sa[m] * sb[n] (+ bias)) (+ residual f32); include/i2t.h::i2t_gemm_fp8."""
     _need_cuda(a8, b8, sa, sb, out)

@@ -311,3 +311,37 @@ def test_falcon_decoder_on_fp8_operands(tmp_path, monkeypatch, mode):
         worst = min(worst, float(g8.double().ravel() @ gb.double().ravel() / (g8.double().norm() * gb.double().norm() + 1e-30)))
     REPORT[f'falcon_{mode}_fp8.gradient_min_cosine_vs_bf16_path'] = worst
     assert worst >= 0.97
+
+
+def test_fused_fp8_producers_match_their_fp32_rows():
+    """i2t_rmsnorm_fwd_fp8 / i2t_swiglu_fwd_fp8 / i2t_swiglu_bwd_fp8: the e4m3 row + scale each emits dequantises to the fp32 row of the
+    plain op within half an e4m3 ulp of the row's binade (amax / 448 scale, round-to-nearest), the padding is zero, rstd is RMSNorm's."""
+    from image2text_amd import ops
+    g = torch.Generator().manual_seed(4)
+    M, d, ff = 70, 4096, 11008
+    x = (torch.randn(M, d, generator=g) * torch.logspace(-1, 1, M)[:, None]).to(dev())
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
+    y8, sy, rstd = torch.full((M, 4096), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    ops.rmsnorm_fwd_fp8(x, w, y8, sy, rstd, M, d, 1e-5)
+    ref_rstd = torch.rsqrt((x * x).mean(dim=1) + 1e-5)
+    ref = x * ref_rstd[:, None] * w
+    assert torch.allclose(rstd, ref_rstd, rtol=1e-5)
+
+    def close(q8, s, ref, width):
+        amax = ref.abs().amax(dim=1)
+        assert torch.allclose(s, amax / 448.0, rtol=1e-5)
+        err = (dequant(q8[:, :width], s) - ref).abs().amax(dim=1) / amax
+        assert float(err.max()) <= 2 ** -4 + 1e-3, float(err.max())
+        assert int(q8[:, width:].sum()) == 0
+    close(y8, sy, ref, d)
+    gu = (torch.randn(M, 2 * ff, generator=g) * 1.5).to(BF16).to(dev())
+    dh = torch.randn(M, ff, generator=g).to(BF16).to(dev())
+    guf, dhf = gu.float(), dh.float()
+    gate, up = guf[:, :ff], guf[:, ff:]
+    s_ = torch.sigmoid(gate)
+    h8, sh = torch.full((M, 11264), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    ops.swiglu_fwd_fp8(gu, h8, sh, M, ff)
+    close(h8, sh, gate * s_ * up, ff)
+    d8, sd = torch.full((M, 22016), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    ops.swiglu_bwd_fp8(dh, gu, d8, sd, M, ff)
+    close(d8, sd, torch.cat((dhf * up * (s_ + gate * s_ * (1 - s_)), dhf * gate * s_), dim=1), 2 * ff)
