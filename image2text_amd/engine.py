@@ -356,7 +356,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         # reference wrapper.py:68-71,197-198: forward_m draws fresh torch RNG) must not repeat this model's masks
         self.seed_salt = 0
         # fp8 (e4m3) operands for the GEMMs of FROZEN decoder weights (engine_llama._lin; BASELINE.json configs[4]); off unless I2T_FP8=1
-        self.fp8 = os.environ.get('I2T_FP8', '0') not in ('', '0')
+        self.fp8 = os.environ.get('I2T_FP8', '0') not in ('', '0') or bool(getattr(model.decoder, 'fp8_request', False))
         self.fp8_fuse = os.environ.get('I2T_FP8_FUSE', '1') != '0'      # producers emit the e4m3 operand themselves (engine_llama, csrc/fp8.hip)
 
     def _refresh_sparse_sets(self):

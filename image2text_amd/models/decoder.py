@@ -403,8 +403,11 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
 
     def __init__(self, config: HuggingfaceDecoderConfig):
         super().__init__()
-        if config.load_in_4bit:
-            raise NotImplementedError('4-bit loading (bitsandbytes) is outside the HIP hot path')
+        import os
+        if config.load_in_4bit and os.environ.get('I2T_4BIT_AS_FP8') != '1':
+            raise NotImplementedError('4-bit loading (bitsandbytes NF4) is outside the HIP hot path: bitsandbytes is not in this image.  '
+                                      'I2T_4BIT_AS_FP8=1 runs such a config with the quantised base held as e4m3 fp8 operands instead '
+                                      '(frozen block linears on the fp8 MFMA path, DESIGN 4h) -- a different 8-bit format, not NF4')
         if config.use_cross_attn:
             raise ValueError("Don't know how to use cross attention with this model. Suggest you try a different config!!!")
         from transformers import AutoModelForCausalLM
@@ -417,6 +420,15 @@ class _LlamaFamilyHuggingfaceDecoder(Decoder):
         if config.enable_gradient_checkpointing:
             pass            # the hot path keeps what its hand-written backward needs; nothing to switch on (decoder.py:322-323)
         self.backbone = hf
+        # load_in_4bit under I2T_4BIT_AS_FP8=1: what bitsandbytes would quantise -- every nn.Linear of the blocks (not the head) -- is frozen
+        # (4-bit parameters never train) and the engine runs those GEMMs on e4m3 operands
+        self.fp8_request = bool(config.load_in_4bit)
+        if config.load_in_4bit:
+            blocks = hf.get_submodule(self._BLOCKS)
+            for mod in blocks.modules():
+                if isinstance(mod, nn.Linear):
+                    for p in mod.parameters():
+                        p.requires_grad = False
         if config.prepare_for_kbit_training:
             _freeze_like_prepare_for_kbit_training(self)
         self.lora = None

@@ -255,7 +255,7 @@ def test_frozen_vit_backbone_on_fp8_operands(monkeypatch):
     assert rel_f <= 1.2e-1 and rel_e <= 1.2e-1
 
 
-@pytest.mark.parametrize('mode', ['frozen', 'lora'])
+@pytest.mark.parametrize('mode', ['frozen', 'lora', 'lora4bit'])
 def test_falcon_decoder_on_fp8_operands(tmp_path, monkeypatch, mode):
     """The falcon-7b block on a frozen base with e4m3 operands: every projection forward and dx, the MLP's first one through the
     product -> pre-activation -> GELU pass route (the fp8 classes cannot write a pre-activation beside the activated output).  'frozen' =
@@ -267,12 +267,16 @@ def test_falcon_decoder_on_fp8_operands(tmp_path, monkeypatch, mode):
     from test_host_cpu import _hf_decoder_config, _local_hf_falcon
     _, name, vocab = _local_hf_falcon(tmp_path, monkeypatch)
     V = vocab + 1
-    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=0.0, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h']) if mode == 'lora' else None
+    spec = LoraSpec(r=4, lora_alpha=16, lora_dropout=0.0, target_modules=['query_key_value', 'dense', 'dense_h_to_4h', 'dense_4h_to_h']) if mode != 'frozen' else None
+    four = mode == 'lora4bit'          # load_in_4bit under I2T_4BIT_AS_FP8=1 (the decoder_config of gpu/falcon-7b.yaml): the engine turns fp8 on by itself
+    if four:
+        monkeypatch.setenv('I2T_4BIT_AS_FP8', '1')
     cfg = tiny_config(dec_d=256, dec_heads=4, dec_layers=2, block_size=64)
-    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec,
-                                                                       prepare_for_kbit_training=mode == 'frozen'),
+    cfg = cfg.model_copy(update=dict(decoder_config=_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, lora_spec=spec, load_in_4bit=four,
+                                                                       prepare_for_kbit_training=mode == 'frozen' or four),
                                      use_cross_attn=False, use_soft_prompting=True))
     m = VisionEncoderDecoder(cfg)
+    assert m._engine.fp8 == four
     keep = {k: v.detach().clone() for k, v in m.decoder.state_dict().items()}
     det_init_(m, seed=0)
     m.decoder.load_state_dict(keep)

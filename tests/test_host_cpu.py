@@ -561,6 +561,15 @@ def test_falcon_huggingface_decoder_plugin(tmp_path, monkeypatch):
         Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, use_cross_attn=True))
     with pytest.raises(NotImplementedError, match='4-bit'):              # gpu/falcon-7b.yaml loads in 4 bits (bitsandbytes: not in this image)
         Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, load_in_4bit=True))
+    # ... unless the caller opts into the fp8 stand-in: the decoder_config of gpu/falcon-7b.yaml:46-60 as shipped (4-bit, kbit preparation,
+    # LoRA on the four linears, embeddings / head left trainable)
+    monkeypatch.setenv('I2T_4BIT_AS_FP8', '1')
+    d4 = Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab, extra_tokens=1, load_in_4bit=True, prepare_for_kbit_training=True,
+                                                 enable_gradient_checkpointing=True, lora_spec=spec))
+    assert d4.fp8_request and d4.lora is not None
+    on4 = {n for n, p in d4.named_parameters() if p.requires_grad}
+    assert on4 == {n for n, _ in d4.named_parameters() if n.startswith('lora_params.')} | {'backbone.transformer.word_embeddings.weight'}
+    monkeypatch.delenv('I2T_4BIT_AS_FP8')
     _local_hf_falcon(tmp_path, monkeypatch, alibi=True)
     with pytest.raises(NotImplementedError, match='alibi'):
         Decoder.from_config(_hf_decoder_config(name=name, vocab_size=vocab))
