@@ -154,7 +154,8 @@ __device__ __forceinline__ float f8_amax4(float a, const f32x4& v) {
 
 // RMSNorm: y = w x rsqrt(mean(x^2) + eps) -> e4m3 row + scale (+ rstd for the backward); d <= 8192
 __global__ __launch_bounds__(256) void rms_fwd_fp8_kernel(const float* __restrict__ x, const float* __restrict__ w, unsigned char* __restrict__ y8,
-                                                          int ld8, float* __restrict__ scale, float* __restrict__ rstd_out, int d, float eps) {
+                                                          int ld8, float* __restrict__ scale, float* __restrict__ rstd_out, int d, float eps,
+                                                          bf16_t* __restrict__ y16) {
     constexpr int MAXI = 8;
     __shared__ float red[16];
     const int row = blockIdx.x, t = threadIdx.x, nc = d >> 2;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void rms_fwd_fp8_kernel(const float* __restric
             const f32x4 g = reinterpret_cast<const f32x4*>(w)[c];
             v[i] = f32x4{v[i][0] * rs * g[0], v[i][1] * rs * g[1], v[i][2] * rs * g[2], v[i][3] * rs * g[3]};
             amax = f8_amax4(amax, v[i]);
+            if (y16) reinterpret_cast<u32x2*>(y16 + (size_t)row * d)[c] = u32x2{pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3])};
         }
     }
     amax = block_max(amax, red);
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(256) void rms_fwd_fp8_kernel(const float* __restric
 // SwiGLU forward: h = silu(gate) up -> e4m3 row + scale; ff <= 12288.  BWD: [d gate | d up] of the fused projection -> e4m3 row (2 ff) + scale
 template <bool BWD>
 __global__ __launch_bounds__(256) void swiglu_fp8_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu, int ld,
-                                                         unsigned char* __restrict__ out8, int ld8, float* __restrict__ scale, int ff) {
+                                                         unsigned char* __restrict__ out8, int ld8, float* __restrict__ scale, int ff,
+                                                         bf16_t* __restrict__ out16, int ld16) {
     constexpr int MAXI = 6;
     __shared__ float red[16];
     const int row = blockIdx.x, t = threadIdx.x, n8 = ff >> 3;
@@ -226,6 +229,12 @@ __global__ __launch_bounds__(256) void swiglu_fp8_kernel(const bf16_t* __restric
         }
         amax = f8_amax4(f8_amax4(amax, a[i][0]), a[i][1]);
         if (BWD) amax = f8_amax4(f8_amax4(amax, b[i][0]), b[i][1]);
+        if (out16) {         // (an adapter's rank GEMMs want the bf16 row as well: LoRA on a frozen fp8 base)
+            *reinterpret_cast<u32x4*>(out16 + (size_t)row * ld16 + c * 8) =
+                u32x4{pack_bf16x2(a[i][0][0], a[i][0][1]), pack_bf16x2(a[i][0][2], a[i][0][3]), pack_bf16x2(a[i][1][0], a[i][1][1]), pack_bf16x2(a[i][1][2], a[i][1][3])};
+            if (BWD) *reinterpret_cast<u32x4*>(out16 + (size_t)row * ld16 + ff + c * 8) =
+                u32x4{pack_bf16x2(b[i][0][0], b[i][0][1]), pack_bf16x2(b[i][0][2], b[i][0][3]), pack_bf16x2(b[i][1][0], b[i][1][1]), pack_bf16x2(b[i][1][2], b[i][1][3])};
+        }
     }
     amax = block_max(amax, red);
     const float sc = amax > 0.f ? amax / E4M3_MAX : 1.0f;
@@ -377,28 +386,30 @@ extern "C" int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int
     return I2T_OK;
 }
 
-extern "C" int i2t_rmsnorm_fwd_fp8(void* stream, const float* x, const float* w, void* y8, int ld8, float* scale, float* rstd, int M, int d, float eps) {
+extern "C" int i2t_rmsnorm_fwd_fp8(void* stream, const float* x, const float* w, void* y8, int ld8, float* scale, float* rstd, int M, int d, float eps,
+                                   void* y_bf16) {
     I2T_REQUIRE(x && w && y8 && scale && M > 0 && d > 0 && d % 4 == 0 && d <= 8192 && ld8 % 16 == 0 && ld8 >= d && ld8 <= 8192 && ALIGNED16(x) && ALIGNED16(y8),
                 "i2t_rmsnorm_fwd_fp8: bad args (d=%d <= 8192, ld8=%d %% 16)", d, ld8);
-    hipLaunchKernelGGL(rms_fwd_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, (unsigned char*)y8, ld8, scale, rstd, d, eps);
+    hipLaunchKernelGGL(rms_fwd_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, (unsigned char*)y8, ld8, scale, rstd, d, eps, (bf16_t*)y_bf16);
     I2T_CHECK_LAUNCH("i2t_rmsnorm_fwd_fp8");
     return I2T_OK;
 }
 
-extern "C" int i2t_swiglu_fwd_fp8(void* stream, const void* gate_up, int ld, void* h8, int ld8, float* scale, int M, int ff) {
+extern "C" int i2t_swiglu_fwd_fp8(void* stream, const void* gate_up, int ld, void* h8, int ld8, float* scale, int M, int ff, void* h_bf16) {
     I2T_REQUIRE(gate_up && h8 && scale && M > 0 && ff > 0 && ff % 8 == 0 && ff <= 12288 && ld >= 2 * ff && ld % 8 == 0 && ld8 % 16 == 0 && ld8 >= ff &&
                     ALIGNED16(gate_up) && ALIGNED16(h8), "i2t_swiglu_fwd_fp8: bad args (ff=%d <= 12288)", ff);
     hipLaunchKernelGGL(swiglu_fp8_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, (const bf16_t*)gate_up, ld,
-                       (unsigned char*)h8, ld8, scale, ff);
+                       (unsigned char*)h8, ld8, scale, ff, (bf16_t*)h_bf16, ff);
     I2T_CHECK_LAUNCH("i2t_swiglu_fwd_fp8");
     return I2T_OK;
 }
 
-extern "C" int i2t_swiglu_bwd_fp8(void* stream, const void* dh, const void* gate_up, int ld, void* dgu8, int ld8, float* scale, int M, int ff) {
+extern "C" int i2t_swiglu_bwd_fp8(void* stream, const void* dh, const void* gate_up, int ld, void* dgu8, int ld8, float* scale, int M, int ff,
+                                  void* dgu_bf16) {
     I2T_REQUIRE(dh && gate_up && dgu8 && scale && M > 0 && ff > 0 && ff % 8 == 0 && ff <= 12288 && ld >= 2 * ff && ld % 8 == 0 && ld8 % 16 == 0 &&
                     ld8 >= 2 * ff && ALIGNED16(gate_up) && ALIGNED16(dh) && ALIGNED16(dgu8), "i2t_swiglu_bwd_fp8: bad args (ff=%d <= 12288)", ff);
     hipLaunchKernelGGL(swiglu_fp8_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)gate_up, ld,
-                       (unsigned char*)dgu8, ld8, scale, ff);
+                       (unsigned char*)dgu8, ld8, scale, ff, (bf16_t*)dgu_bf16, 2 * ff);
     I2T_CHECK_LAUNCH("i2t_swiglu_bwd_fp8");
     return I2T_OK;
 }

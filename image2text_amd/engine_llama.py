@@ -183,12 +183,16 @@ class LlamaBlocks:
             ops.rmsnorm_fwd_fp8(x, v.n1, n1q[0], n1q[1], r1, M, d, ls.eps)
             self._lin(None, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv, xq=n1q)
         else:
-            n1 = self._empty(M, d, dtype=BF16)
-            ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
+            n1, n1q = self._empty(M, d, dtype=BF16), None
+            if fuse and lo['qkv'] is not None and self._fp8_on(v.names.qkv):      # LoRA on a frozen fp8 base: the bf16 row (adapter) AND the e4m3 one
+                n1q = (torch.empty(M, _f8pad(d), dtype=torch.uint8, device=x.device), self._empty(M))
+                ops.rmsnorm_fwd_fp8(x, v.n1, n1q[0], n1q[1], r1, M, d, ls.eps, y_bf16=n1)
+            else:
+                ops.rmsnorm_fwd(x, v.n1, n1, r1, M, d, ls.eps)
         if f_qkv:
             pass
         elif lo['qkv'] is not None:
-            svlo['qkv'] = self._lora_gemm(lo['qkv'], n1, v.Wqkv, qkv, M, ldrop('qkv'), save, bias=v.bqkv)
+            svlo['qkv'] = self._lora_gemm(lo['qkv'], n1, v.Wqkv, qkv, M, ldrop('qkv'), save, bias=v.bqkv, xq=n1q)
         else:
             self._lin(n1, v.Wqkv, v.names.qkv, qkv, M, v.nq, d, bias=v.bqkv)
         ops.rope(qkv, v.nq, 0, H + G, hd, cs, M, pos=rpos, pos_offset=pos_offset, T=T)      # q heads and k heads are adjacent columns
@@ -209,10 +213,14 @@ class LlamaBlocks:
             ops.rmsnorm_fwd_fp8(x1, v.n2, n2q[0], n2q[1], r2, M, d, ls.eps)
             self._lin(None, v.Wgu, v.names.gu, gu, M, 2 * ff, d, xq=n2q)
         else:
-            n2 = self._empty(M, d, dtype=BF16)
-            ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
+            n2, n2q = self._empty(M, d, dtype=BF16), None
+            if fuse and lo['gu'] is not None and self._fp8_on(v.names.gu):
+                n2q = (torch.empty(M, _f8pad(d), dtype=torch.uint8, device=x.device), self._empty(M))
+                ops.rmsnorm_fwd_fp8(x1, v.n2, n2q[0], n2q[1], r2, M, d, ls.eps, y_bf16=n2)
+            else:
+                ops.rmsnorm_fwd(x1, v.n2, n2, r2, M, d, ls.eps)
             if lo['gu'] is not None:
-                svlo['gu'] = self._lora_gemm(lo['gu'], n2, v.Wgu, gu, M, ldrop('gu'), save)
+                svlo['gu'] = self._lora_gemm(lo['gu'], n2, v.Wgu, gu, M, ldrop('gu'), save, xq=n2q)
             else:
                 self._lin(n2, v.Wgu, v.names.gu, gu, M, 2 * ff, d)
         x2 = self._empty(M, d)
@@ -222,10 +230,14 @@ class LlamaBlocks:
             ops.swiglu_fwd_fp8(gu, hq[0], hq[1], M, ff)
             self._lin(None, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1, xq=hq)
         else:
-            h = self._empty(M, ff, dtype=BF16)
-            ops.swiglu_fwd(gu, h, M, ff)
+            h, hq = self._empty(M, ff, dtype=BF16), None
+            if fuse and lo['dn'] is not None and self._fp8_on(v.names.dn):
+                hq = (torch.empty(M, _f8pad(ff), dtype=torch.uint8, device=x.device), self._empty(M))
+                ops.swiglu_fwd_fp8(gu, hq[0], hq[1], M, ff, h_bf16=h)
+            else:
+                ops.swiglu_fwd(gu, h, M, ff)
             if lo['dn'] is not None:
-                svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1)
+                svlo['dn'] = self._lora_gemm(lo['dn'], h, v.Wdn, x2, M, ldrop('dn'), save, residual=x1, xq=hq)
             else:
                 self._lin(h, v.Wdn, v.names.dn, x2, M, d, ff, residual=x1)
         return x2, (SimpleNamespace(x=x, n1=n1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, n2=n2, r2=r2, gu=gu, h=h, lo=svlo,
@@ -244,9 +256,9 @@ class LlamaBlocks:
         svlo = getattr(sv, 'lo', None) or {}
         span_g = (lambda names, shape: self.arena.span('G', names, shape) if tr(names) else None)
 
-        def lora_bwd(site, dY, x_in, W, names, shape, gb=None):          # -> fp32 dx (engine_lora._lora_bwd), base dW only when trainable
+        def lora_bwd(site, dY, x_in, W, names, shape, gb=None, dq=None):          # -> fp32 dx (engine_lora._lora_bwd), base dW only when trainable
             return self._lora_bwd(self._llama_lora(l, site), svlo[site], dY, x_in, W, span_g([names] if isinstance(names, str) else names, shape),
-                                  gb, M, sv.lo_drop.get(site))
+                                  gb, M, sv.lo_drop.get(site), dq=dq)
         dh = self._empty(M, ff, dtype=BF16)
         if 'dn' in svlo:
             ops.cast_f32_bf16(lora_bwd('dn', dxb, sv.h, v.Wdn, nm.dn, (d, ff)), dh)
@@ -261,12 +273,16 @@ class LlamaBlocks:
             self._lin_dx(None, v.Wgu, nm.gu, dn, M, 2 * ff, d, dq=dguq)
             dgu, dn2 = None, dn
         else:
-            dgu = self._empty(M, 2 * ff, dtype=BF16)
-            ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
+            dgu, dguq = self._empty(M, 2 * ff, dtype=BF16), None
+            if 'gu' in svlo and self.fp8 and self.fp8_fuse and self._fp8_on(nm.gu) and ff <= 12288:
+                dguq = (torch.empty(M, _f8pad(2 * ff), dtype=torch.uint8, device=dh.device), self._empty(M))
+                ops.swiglu_bwd_fp8(dh, sv.gu, dguq[0], dguq[1], M, ff, dgu_bf16=dgu)
+            else:
+                ops.swiglu_bwd(dh, sv.gu, dgu, M, ff)
         if dgu is None:
             pass
         elif 'gu' in svlo:
-            dn2 = lora_bwd('gu', dgu, sv.n2, v.Wgu, nm.gu, (2 * ff, d))      # fp32: rmsnorm_bwd takes either
+            dn2 = lora_bwd('gu', dgu, sv.n2, v.Wgu, nm.gu, (2 * ff, d), dq=dguq)      # fp32: rmsnorm_bwd takes either
         else:
             if tr(nm.gu):
                 ops.gemm(dgu, sv.n2, v.Ggu, 2 * ff, d, M, a_kmajor=True, b_kmajor=True, accumulate=True)

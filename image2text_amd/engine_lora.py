@@ -66,6 +66,7 @@ class LoraAdapters:
         K, N = ls.K, ls.N
         if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames) and epilogue.get('act', 0) in (0, ops.ACT_GELU, ops.ACT_GELU_ERF):
             return self._lora_gemm_fp8(ls, x, W, out, M, drop_l, save, **epilogue)
+        epilogue.pop('xq', None)
         xcat = torch.empty(M, K + LPAD, dtype=BF16, device=x.device)
         xd = torch.empty(M, K, dtype=BF16, device=x.device) if drop_l is not None else None
         ops.lora_stage(x, xcat, xd, M, K, drop_l)                    # one pass: x into the concatenated operand + its masked copy
@@ -79,7 +80,7 @@ class LoraAdapters:
         # (the masked copy of x is kept for dA = du^T dropout(x): re-making it in backward cost two more passes over [M, K])
         return SimpleNamespace(u=u, sB=wcat[:, K:].contiguous(), xd=xd) if save else None
 
-    def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, act=0, aux_out=None, **_):
+    def _lora_gemm_fp8(self, ls, x, W, out, M: int, drop_l, save: bool, bias=None, residual=None, act=0, aux_out=None, xq=None, **_):
         """The same layer with its FROZEN base weight on fp8 operands (I2T_FP8=1; engine_llama._fp8_*): the base product runs
         at the fp8 MFMA rate, so the adapter leaves the K panel -- out = fp8(x) . fp8(W)^T (+ bias) (+ residual) + u . (s B)^T, the
         rank-128 product added by a second, thin GEMM (in place on an fp32 output; ahead of the base GEMM, as its fp32 residual, when
@@ -87,7 +88,7 @@ class LoraAdapters:
         K, N = ls.K, ls.N
         if act:          # GELU behind the layer (Falcon's dense_h_to_4h): the product goes to the pre-activation buffer, one more pass applies it
             pre = aux_out if aux_out is not None else torch.empty(M, N, dtype=BF16, device=x.device)
-            sv = self._lora_gemm_fp8(ls, x, W, pre, M, drop_l, save, bias=bias, residual=residual)
+            sv = self._lora_gemm_fp8(ls, x, W, pre, M, drop_l, save, bias=bias, residual=residual, xq=xq)
             ops.gelu_fwd(pre, out, erf=(act == ops.ACT_GELU_ERF))
             return sv
         xd = None
@@ -98,7 +99,7 @@ class LoraAdapters:
         self._rank_gemm(xd if xd is not None else x, ls.A, u, M, K)
         panel = self._lora_panel(ls)
         e = self._fp8_weight(ls.wnames, W)
-        x8, sx = self._fp8_rows(x, M, K)
+        x8, sx = xq if xq is not None else self._fp8_rows(x, M, K)          # (xq: the producer of x emitted the e4m3 row beside the bf16 one)
         if out.dtype == F32:
             ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, x8.shape[1], bias=bias, residual=residual)      # (K' = the zero-padded row length)
             ops.gemm(u, panel, out, M, N, LPAD, residual=out)
@@ -108,7 +109,7 @@ class LoraAdapters:
             ops.gemm_fp8(x8, sx, e.w8, e.sw, out, M, N, x8.shape[1], bias=bias, residual=tmp)
         return SimpleNamespace(u=u, sB=panel, xd=xd) if save else None
 
-    def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l):
+    def _lora_bwd(self, ls, sv_l, dY, x, W, gW, gb, M: int, drop_l, dq=None):
         """dY bf16 [M, N]: gradient w.r.t. the adapted linear's pre-epilogue output.  gW / gb: gradient views of the base weight /
         bias or None (frozen).  Accumulates every parameter gradient; returns dx fp32 [M, K] = dY . W + dropout(du . A)."""
         K, N = ls.K, ls.N
@@ -127,7 +128,7 @@ class LoraAdapters:
         dx = torch.empty(M, K, dtype=F32, device=dY.device)
         if getattr(ls, 'wnames', None) is not None and self._fp8_on(ls.wnames):      # frozen base weight: dx on fp8 operands too
             e = self._fp8_weight(ls.wnames, W)
-            d8, sd = self._fp8_rows(dY, M, N)
+            d8, sd = dq if dq is not None else self._fp8_rows(dY, M, N)
             ops.gemm_fp8(d8, sd, e.wt8, e.swt, dx, M, K, d8.shape[1])
         else:
             ops.gemm(dY, W, dx, M, K, N, b_kmajor=True)

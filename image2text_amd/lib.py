@@ -94,9 +94,9 @@ SIGNATURES = {
     'i2t_lsh_embed_bwd': [P, P, P, P, L, P, I, I, I, I, I],
     'i2t_quant_rows_fp8': [P, P, I, I, P, I, P, I, I],
     'i2t_quant_cols_fp8': [P, P, I, P, I, P, I, I],
-    'i2t_rmsnorm_fwd_fp8': [P, P, P, P, I, P, P, I, I, F],
-    'i2t_swiglu_fwd_fp8': [P, P, I, P, I, P, I, I],
-    'i2t_swiglu_bwd_fp8': [P, P, P, I, P, I, P, I, I],
+    'i2t_rmsnorm_fwd_fp8': [P, P, P, P, I, P, P, I, I, F, P],
+    'i2t_swiglu_fwd_fp8': [P, P, I, P, I, P, I, I, P],
+    'i2t_swiglu_bwd_fp8': [P, P, P, I, P, I, P, I, I, P],
     'i2t_gemm_fp8': [P, P, I, P, P, I, P, P, I, I, I, I, I, P, I, P, I],
     'i2t_set_deterministic': [I],
     'i2t_deterministic': [],

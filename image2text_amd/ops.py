@@ -650,23 +650,27 @@ def quant_cols_fp8(w, out, scale, N, K):
     return out
 
 
-def rmsnorm_fwd_fp8(x, w, y8, scale, rstd, M, d, eps):
-    """y8 (e4m3 [M, ld8]) , scale [M] = quantised RMSNorm(x); rstd [M] or None  (include/i2t.h::i2t_rmsnorm_fwd_fp8)"""
+def rmsnorm_fwd_fp8(x, w, y8, scale, rstd, M, d, eps, y_bf16=None):
+    """y8 (e4m3 [M, ld8]) , scale [M] = quantised RMSNorm(x); rstd [M] or None; y_bf16: optional contiguous bf16 copy  (include/i2t.h)"""
     _need_cuda(x, w, y8, scale)
-    _l.check(_lib().i2t_rmsnorm_fwd_fp8(_stream(), _p(x), _p(w), _p(y8), y8.stride(0), _p(scale), _p(rstd), M, d, float(eps)), 'i2t_rmsnorm_fwd_fp8')
+    assert y_bf16 is None or (y_bf16.dtype == BF16 and y_bf16.is_contiguous())
+    _l.check(_lib().i2t_rmsnorm_fwd_fp8(_stream(), _p(x), _p(w), _p(y8), y8.stride(0), _p(scale), _p(rstd), M, d, float(eps), _p(y_bf16)),
+             'i2t_rmsnorm_fwd_fp8')
     return y8
 
 
-def swiglu_fwd_fp8(gate_up, h8, scale, M, ff):
+def swiglu_fwd_fp8(gate_up, h8, scale, M, ff, h_bf16=None):
     _need_cuda(gate_up, h8, scale)
-    _l.check(_lib().i2t_swiglu_fwd_fp8(_stream(), _p(gate_up), gate_up.stride(0), _p(h8), h8.stride(0), _p(scale), M, ff), 'i2t_swiglu_fwd_fp8')
+    assert h_bf16 is None or (h_bf16.dtype == BF16 and h_bf16.is_contiguous())
+    _l.check(_lib().i2t_swiglu_fwd_fp8(_stream(), _p(gate_up), gate_up.stride(0), _p(h8), h8.stride(0), _p(scale), M, ff, _p(h_bf16)), 'i2t_swiglu_fwd_fp8')
     return h8
 
 
-def swiglu_bwd_fp8(dh, gate_up, dgu8, scale, M, ff):
+def swiglu_bwd_fp8(dh, gate_up, dgu8, scale, M, ff, dgu_bf16=None):
     _need_cuda(dh, gate_up, dgu8, scale)
-    assert dh.is_contiguous()
-    _l.check(_lib().i2t_swiglu_bwd_fp8(_stream(), _p(dh), _p(gate_up), gate_up.stride(0), _p(dgu8), dgu8.stride(0), _p(scale), M, ff), 'i2t_swiglu_bwd_fp8')
+    assert dh.is_contiguous() and (dgu_bf16 is None or (dgu_bf16.dtype == BF16 and dgu_bf16.is_contiguous()))
+    _l.check(_lib().i2t_swiglu_bwd_fp8(_stream(), _p(dh), _p(gate_up), gate_up.stride(0), _p(dgu8), dgu8.stride(0), _p(scale), M, ff, _p(dgu_bf16)),
+             'i2t_swiglu_bwd_fp8')
     return dgu8
 
 

@@ -523,10 +523,13 @@ int i2t_quant_rows_fp8(void* stream, const void* x, int x_is_f32, int ld, void* 
 int i2t_quant_cols_fp8(void* stream, const void* w, int ld, void* out, int ld_out, float* scale, int N, int K);
 /* Producers that emit the e4m3 operand of the next i2t_gemm_fp8 themselves (no bf16 copy, no quantisation pass): RMSNorm forward
  * (d <= 8192; rstd for i2t_rmsnorm_bwd may be null), SwiGLU forward (h [M][ff]) and backward ([d gate | d up] [M][2 ff]); ff <= 12288.
- * Rows zero-padded to ld8 (% 16); scale[m] = amax(row m) / 448 as i2t_quant_rows_fp8, taken from the fp32 values. */
-int i2t_rmsnorm_fwd_fp8(void* stream, const float* x, const float* w, void* y8, int ld8, float* scale, float* rstd, int M, int d, float eps);
-int i2t_swiglu_fwd_fp8(void* stream, const void* gate_up, int ld, void* h8, int ld8, float* scale, int M, int ff);
-int i2t_swiglu_bwd_fp8(void* stream, const void* dh, const void* gate_up, int ld, void* dgu8, int ld8, float* scale, int M, int ff);
+ * Rows zero-padded to ld8 (% 16); scale[m] = amax(row m) / 448 as i2t_quant_rows_fp8, taken from the fp32 values.  The last argument: an
+ * optional contiguous bf16 copy of the same row ([M][d] / [M][ff] / [M][2 ff]) for consumers that are not fp8 GEMMs (LoRA's rank products). */
+int i2t_rmsnorm_fwd_fp8(void* stream, const float* x, const float* w, void* y8, int ld8, float* scale, float* rstd, int M, int d, float eps,
+                        void* y_bf16);
+int i2t_swiglu_fwd_fp8(void* stream, const void* gate_up, int ld, void* h8, int ld8, float* scale, int M, int ff, void* h_bf16);
+int i2t_swiglu_bwd_fp8(void* stream, const void* dh, const void* gate_up, int ld, void* dgu8, int ld8, float* scale, int M, int ff,
+                       void* dgu_bf16);
 int i2t_gemm_fp8(void* stream, const void* A8, int lda, const float* sa, const void* B8, int ldb, const float* sb, void* C, int ldc,
                  int c_is_f32, int M, int N, int K, const float* bias, int act, const float* residual, int ldr);
 
