@@ -317,15 +317,16 @@ def test_falcon_decoder_on_fp8_operands(tmp_path, monkeypatch, mode):
     assert worst >= 0.97
 
 
-def test_fused_fp8_producers_match_their_fp32_rows():
+@pytest.mark.parametrize('M,d,ff', [(70, 4096, 11008), (33, 1536, 8960), (5, 256, 512)])
+def test_fused_fp8_producers_match_their_fp32_rows(M, d, ff):
     """i2t_rmsnorm_fwd_fp8 / i2t_swiglu_fwd_fp8 / i2t_swiglu_bwd_fp8: the e4m3 row + scale each emits dequantises to the fp32 row of the
     plain op within half an e4m3 ulp of the row's binade (amax / 448 scale, round-to-nearest), the padding is zero, rstd is RMSNorm's."""
     from image2text_amd import ops
     g = torch.Generator().manual_seed(4)
-    M, d, ff = 70, 4096, 11008
+    pad = lambda k: (k + 255) // 256 * 256
     x = (torch.randn(M, d, generator=g) * torch.logspace(-1, 1, M)[:, None]).to(dev())
     w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
-    y8, sy, rstd = torch.full((M, 4096), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev()), torch.empty(M, device=dev())
+    y8, sy, rstd = torch.full((M, pad(d)), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev()), torch.empty(M, device=dev())
     ops.rmsnorm_fwd_fp8(x, w, y8, sy, rstd, M, d, 1e-5)
     ref_rstd = torch.rsqrt((x * x).mean(dim=1) + 1e-5)
     ref = x * ref_rstd[:, None] * w
@@ -343,9 +344,12 @@ def test_fused_fp8_producers_match_their_fp32_rows():
     guf, dhf = gu.float(), dh.float()
     gate, up = guf[:, :ff], guf[:, ff:]
     s_ = torch.sigmoid(gate)
-    h8, sh = torch.full((M, 11264), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    h8, sh = torch.full((M, pad(ff)), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
     ops.swiglu_fwd_fp8(gu, h8, sh, M, ff)
     close(h8, sh, gate * s_ * up, ff)
-    d8, sd = torch.full((M, 22016), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
-    ops.swiglu_bwd_fp8(dh, gu, d8, sd, M, ff)
-    close(d8, sd, torch.cat((dhf * up * (s_ + gate * s_ * (1 - s_)), dhf * gate * s_), dim=1), 2 * ff)
+    d8, sd = torch.full((M, pad(2 * ff)), 0x55, dtype=torch.uint8, device=dev()), torch.empty(M, device=dev())
+    dgu16 = torch.empty(M, 2 * ff, dtype=BF16, device=dev())
+    ops.swiglu_bwd_fp8(dh, gu, d8, sd, M, ff, dgu_bf16=dgu16)
+    want = torch.cat((dhf * up * (s_ + gate * s_ * (1 - s_)), dhf * gate * s_), dim=1)
+    close(d8, sd, want, 2 * ff)
+    assert torch.allclose(dgu16.float(), want, rtol=2 ** -7, atol=1e-6)          # the optional bf16 copy: the same fp32 row, bf16-rounded
