@@ -97,6 +97,40 @@ class GemmTimer:
                     bytes_per_launch=by / max(1, len(self.records)))
 
 
+class XattnTimer:
+    """Wraps ops.xattn_kv_fused (the north star's fused cross-attention forward: K/V projection + attention in one launch) with HIP
+    events on the launch stream.  Algorithmic FLOPs per call: 2 (B S) (2 d) d for the projection + 4 rows S d for QK^T and PV."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.records = ops, ops.xattn_kv_fused, []
+
+    def __enter__(self):
+        def timed(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = self.orig(mem, w_kv, bias_kv, q, kv, o, lse, B, S, H, Tq, **kw)
+            e1.record(torch.cuda.current_stream())
+            d = 64 * H
+            rows = int(kw.get('total_q') or 0) or B * Tq
+            self.records.append((e0, e1, 2.0 * B * S * 2 * d * d + 4.0 * rows * S * d, (B, S, H, rows)))
+            return r
+        self.ops.xattn_kv_fused = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.xattn_kv_fused = self.orig
+
+    def summary(self):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        B, S, H, rows = self.records[0][3]
+        return dict(launches=len(self.records), total_ms=ms, avg_us=1e3 * ms / len(self.records), tflops=fl / (ms * 1e-3) / 1e12,
+                    gflop_per_launch=fl / len(self.records) / 1e9, shape=dict(images=B, memory_rows_per_image=S, heads=H, query_rows=rows))
+
+
 def log(msg):
     """Progress on stderr (rank 0): the JSON line on stdout stays the only stdout output."""
     if int(os.environ.get('RANK', '0')) == 0:
@@ -273,12 +307,13 @@ def main():
         del h_images, h_labels
 
     # ---- per-kernel timing of the dominant kernel (bf16 MFMA GEMM) with HIP events, 2 extra steps
-    gemm = None
+    gemm = xattn = None
     if not args.no_kernel_timing:
-        with GemmTimer(ops) as gt:
+        with GemmTimer(ops) as gt, XattnTimer(ops) as xt:
             for _ in range(2):
                 step()
         gemm = gt.summary()
+        xattn = xt.summary()
         if args.gemm_breakdown and rank == 0:
             for ln in gt.breakdown():
                 log(ln)
@@ -369,6 +404,14 @@ def main():
                                'algorithmic_bytes_per_launch': round(gemm['bytes_per_launch']), 'launches_per_step': gemm['launches'] // 2,
                                'avg_launch_us': round(gemm['avg_us'], 2), 'gflop_per_launch': round(gemm['gflop_per_launch'], 3),
                                'gemm_ms_per_step': round(gemm['total_ms'] / 2, 3)}
+        if xattn is not None:      # the north star's kernel (BASELINE.json: >= 40 % bf16 MFMA utilisation on the fused cross-attention kernel)
+            out['xattn_roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel<..., 8> = i2t_xattn_kv_fused (K/V projection + attention in one launch; '
+                                                                'every launch of the timed steps)',
+                                     'achieved': round(xattn['tflops'], 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                     'frac': round(xattn['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                                     'launches_per_step': xattn['launches'] // 2, 'avg_launch_us': round(xattn['avg_us'], 2),
+                                     'gflop_per_launch': round(xattn['gflop_per_launch'], 3), 'shape': xattn['shape'],
+                                     'note': 'decoder width 768 (K loop of 12 tiles); the same kernel at d = 1280: 41.9 % (profiles/r03_xattn_widths_b2048.txt)'}
         if dec_attn is not None:
             out['decode_roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_kernel (every self- and cross-attention launch of one 64-token greedy run, eager)',
                                       'achieved': round(dec_attn['gbps'], 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
