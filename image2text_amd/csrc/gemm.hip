@@ -696,17 +696,36 @@ __device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)
     // ---- K and V rows of the image -> C = kv[b][key][0:d | d:2d] as full 128-byte lines: per 16-key block the wave's pad holds
     // [16 keys][K dims 64 | V dims 64] bf16 (256-B rows, 16-B chunks XOR-swizzled by the row: conflict-free writes and reads)
     bf16_t* kvb = reinterpret_cast<bf16_t*>(p.C) + (size_t)b * 64 * p.ldc + h * 64;
+    // V sits keys-in-registers / dims-on-lanes (the form O^T = V^T P^T wants): written from there a key's row is one 2-byte LDS store per
+    // lane and value -- 256 ds_write_b16 per wave tile, most of this phase's time.  The matrix pipe transposes it instead: V^T as the A
+    // operand (that IS the accumulator's layout, va_ below) times a 0 / 1 selection matrix gives V^T[dim 4 g + r][key li] -- the K half's
+    // form, exact (one non-zero product per output) -- 16 MFMAs per wave tile, then the K half's 8-byte stores.
+    bf16x8 va_[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) va_[i][s2] = xa_pack(acc[4 + i][2 * s2], acc[4 + i][2 * s2 + 1]);
+    bf16x8 sel[2];                                                      // sel[t]: k-slot (g, e) of xa_pack <-> key 16 t + 4 g + (e & 3) of the pair; column li
+    {
+        const int e = li - 4 * g;
+        s16x8 s0 = {0, 0, 0, 0, 0, 0, 0, 0}, s1 = s0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s0[q] = (e == q) ? (short)0x3F80 : (short)0;
+            s1[4 + q] = (e == q) ? (short)0x3F80 : (short)0;
+        }
+        sel[0] = __builtin_bit_cast(bf16x8, s0);
+        sel[1] = __builtin_bit_cast(bf16x8, s1);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32x2 k2 = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
             *reinterpret_cast<u32x2*>(pad + li * 256 + (((2 * i + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = k2;       // row = key li
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                                                                          // row = key 4 g + r
-                const int row = 4 * g + r;
-                *reinterpret_cast<bf16_t*>(pad + row * 256 + (((8 + 2 * i + (li >> 3)) ^ row) << 4) + (li & 7) * 2) = f32_to_bf16(acc[4 + i][j][r]);
-            }
+            const f32x4 vt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_[i][j >> 1], sel[j & 1], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const u32x2 v2 = {pack_bf16x2(vt[0], vt[1]), pack_bf16x2(vt[2], vt[3])};
+            *reinterpret_cast<u32x2*>(pad + li * 256 + (((8 + 2 * i + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = v2;   // row = key li, V part
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -718,15 +737,11 @@ __device__ __forceinline__ void xattn_epilogue(const GemmParams& p, f32x4 (&acc)
     }
     if (Tq <= 0) return;
     // ---- operand fragments of the two attention products (bf16: the same rounding the stored K / V carry)
-    bf16x8 ka[2][4], va_[4][2];
+    bf16x8 ka[2][4];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ka[s2][j] = xa_pack(acc[2 * s2][j], acc[2 * s2 + 1][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) va_[i][s2] = xa_pack(acc[4 + i][2 * s2], acc[4 + i][2 * s2 + 1]);
     constexpr float kScale = 0.125f * 1.4426950408889634f;             // 1 / sqrt(64) x log2(e)
     const bool drop = p.drop_thr != 0;
     const int nqb = (Tq + 15) >> 4;
