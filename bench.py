@@ -214,6 +214,49 @@ class DecodeAttnTimer:
                     bytes_per_launch=by / n)
 
 
+def xattn_width_leg(ops, dev, images=2048, d=1280, dropout=0.1, reps=20):
+    """The north star's kernel on the decoder of the reference's own GPU config (training_configs/gpu/nano.yaml:70-89: n_embd 1280,
+    20 heads of 64, cross-attention over the encoder's 64 output tokens): ONE cross-attention layer's fused K/V projection +
+    attention launch (i2t_xattn_kv_fused) over `images` images with packed 8..63-row caption queries, timed with HIP events on the
+    launch stream -- with the step's probability dropout and without.  Returns {variant: dict(avg_us, tflops, gflop_per_launch)}."""
+    from image2text_amd import rng
+    BF16 = torch.bfloat16
+    H, S = d // 64, 64
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(8, 64, (images,), generator=g)
+    cu = torch.zeros(images + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    M = int(cu[-1])
+    cu = cu.to(dev)
+    mem = torch.randn(images * S, d, device=dev).to(BF16)
+    w_kv = (torch.randn(2 * d, d, device=dev) * 0.03).to(BF16)
+    b_kv = torch.randn(2 * d, device=dev) * 0.1
+    q = torch.randn(M, d, device=dev).to(BF16)
+    kv = torch.empty(images, S, 2 * d, dtype=BF16, device=dev)
+    o = torch.empty(M, d, dtype=BF16, device=dev)
+    lse = torch.empty(H * M, device=dev)
+    flops = 2.0 * images * S * 2 * d * d + 4.0 * M * S * d
+    out = {}
+    for name, p in (('dropout', dropout), ('no_dropout', 0.0)):
+        thr = rng.threshold(p) if p > 0 else 0
+        drop = (1, rng.site_key(1234, 99), thr, rng.scale(thr)) if p > 0 else None
+        run = lambda: ops.xattn_kv_fused(mem, w_kv, b_kv, q, kv, o, lse, images, S, H, 64, drop=drop, cu_q=cu, total_q=M)
+        for _ in range(5):
+            run()
+        evs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            run()
+            e1.record(torch.cuda.current_stream())
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+        out[name] = dict(avg_us=1e3 * ms, tflops=flops / (ms * 1e-3) / 1e12, gflop_per_launch=flops / 1e9, launches=reps,
+                         shape=dict(images=images, memory_rows_per_image=S, heads=H, width=d, query_rows=M))
+    return out
+
+
 def main():
     args = parse()
     # stdout carries exactly one JSON line: libraries that write to fd 1 (RCCL prints a version banner when the first
@@ -227,10 +270,18 @@ def main():
     if world > 1 or os.environ.get('I2T_FORCE_DP') == '1':
         from image2text_amd.training.dp import configure_rccl_env
         configure_rccl_env()          # NCCL_MAX_NCHANNELS must be in the environment BEFORE the communicator is created
+    # Control plane of the N > 1 run (rendezvous, barriers, the timing reductions): a gloo group on the HOST.  The gradient exchange runs
+    # on the package's own RCCL communicator (csrc/comm.cpp, created by DataParallelGrads; its unique id travels through this group's
+    # store): each process then holds exactly ONE RCCL communicator, the one NCCL_MAX_NCHANNELS is meant for.  I2T_BENCH_PG=nccl: the
+    # old arrangement (torch's RCCL group beside it), for A/B runs.
+    pg_backend = os.environ.get('I2T_BENCH_PG', 'gloo')
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if pg_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -250,7 +301,10 @@ def main():
     force_dp = world == 1 and os.environ.get('I2T_FORCE_DP') == '1' and 'RANK' in os.environ
     if force_dp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if pg_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
     dp = DataParallelGrads(wrapper.model) if (world > 1 or force_dp) else None
     images, labels = synthetic_batch(args.batch, 224, 64, V, seed=1 + rank)      # each rank draws its own shard
     images, labels = images.to(dev), labels.to(dev)
@@ -286,8 +340,9 @@ def main():
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.detach())
     log(f'train: {1e3 * elapsed / args.steps:.2f} ms/step')
+    red_dev = dev if pg_backend == 'nccl' else 'cpu'           # the timing reductions travel on the control plane
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     img_s = world * args.batch * args.steps / elapsed
@@ -317,6 +372,11 @@ def main():
         if args.gemm_breakdown and rank == 0:
             for ln in gt.breakdown():
                 log(ln)
+    fence()
+    xattn_wide = None
+    if not args.no_kernel_timing and rank == 0:
+        log('xattn: one cross-attention layer of the gpu/nano.yaml decoder (d = 1280, 2048 images)')
+        xattn_wide = xattn_width_leg(ops, dev, dropout=args.dropout)
     fence()
 
     # ---- greedy decode: B captions x 64 new tokens per run (encoder + KV-cache decode under hipGraph replay)
@@ -354,10 +414,10 @@ def main():
         dt = time.perf_counter() - t0
         n_caps = float(Bd * S * args.decode_reps)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
-            c = torch.tensor([n_caps], dtype=torch.float64, device=dev)
+            c = torch.tensor([n_caps], dtype=torch.float64, device=red_dev)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             n_caps = float(c)
         cap_s = n_caps / dt
@@ -411,7 +471,18 @@ def main():
                                      'frac': round(xattn['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                                      'launches_per_step': xattn['launches'] // 2, 'avg_launch_us': round(xattn['avg_us'], 2),
                                      'gflop_per_launch': round(xattn['gflop_per_launch'], 3), 'shape': xattn['shape'],
-                                     'note': 'decoder width 768 (K loop of 12 tiles); the same kernel at d = 1280: 41.9 % (profiles/r03_xattn_widths_b2048.txt)'}
+                                     'note': 'decoder width 768 (K loop of 12 tiles), timed inside the training step; the same kernel on the '
+                                             'decoder of the reference\'s gpu/nano.yaml: xattn_roofline_d1280'}
+        if xattn_wide is not None:      # the same kernel, one layer of the reference's GPU-config decoder (training_configs/gpu/nano.yaml:70-89)
+            xw, xn = xattn_wide['dropout'], xattn_wide['no_dropout']
+            out['xattn_roofline_d1280'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel<..., 8> = i2t_xattn_kv_fused, decoder width 1280 (20 heads of 64), '
+                                                                      'stand-alone launches with the step\'s probability dropout',
+                                           'achieved': round(xw['tflops'], 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                           'frac': round(xw['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None, 'launches': xw['launches'],
+                                           'avg_launch_us': round(xw['avg_us'], 2), 'gflop_per_launch': round(xw['gflop_per_launch'], 3),
+                                           'shape': xw['shape'], 'without_dropout': {'achieved': round(xn['tflops'], 1),
+                                                                                     'frac': round(xn['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                                                     'avg_launch_us': round(xn['avg_us'], 2)}}
         if dec_attn is not None:
             out['decode_roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_kernel (every self- and cross-attention launch of one 64-token greedy run, eager)',
                                       'achieved': round(dec_attn['gbps'], 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -431,6 +502,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dropout=args.dropout)
         print(json.dumps(out), file=json_out, flush=True)
+    if dp is not None:
+        dp.close()                      # destroys the package's RCCL communicator (collective teardown) before the control plane goes
     if world > 1 or force_dp:
         dist.destroy_process_group()
 

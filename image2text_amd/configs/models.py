@@ -16,7 +16,8 @@ from pydantic import BaseModel
 
 
 class LoraSpec(BaseModel):
-    """LoRA adapter request (reference configs/models.py:9-14). Parsed, never executed on the hot path."""
+    """LoRA adapter request (reference configs/models.py:9-14).  Executed by ``engine_lora.LoraAdapters`` on the Hugging Face decoder plugins
+    (GPT-2, Llama-2 / Qwen2, Falcon); refused by name on the GPT-2-imported nanoGPT decoder and on the encoder."""
     r: int = 16
     lora_alpha: int = 64
     lora_dropout: float = 0.1
@@ -125,7 +126,8 @@ class VisionTransformerEncoderConfig(EncoderConfig):
 
 
 class PretrainedViTConfig(EncoderConfig):
-    """torchvision ViT-B/16 backbone + heads (reference configs/models.py:91-96). Out of hot-path scope."""
+    """torchvision ViT-B/16 backbone + heads (reference configs/models.py:91-96): ``models/encoder.py::PretrainedViT`` on
+    ``engine_vit.ViTEncoder`` (slot-MLP / PEER / LSH heads; learnable LSH projections are refused)."""
     refine_base_model: bool = True
     n_embd_out_vit: int
     peer_config: Optional[PeerConfig] = None
@@ -158,7 +160,8 @@ class TransformerDecoderConfig(DecoderConfig):
 
 
 class HuggingfaceDecoderConfig(DecoderConfig):
-    """HF causal-LM decoders (reference configs/models.py:122-128). Out of hot-path scope."""
+    """HF causal-LM decoders (reference configs/models.py:122-128): the GPT-2, Llama-2 / Qwen2 and Falcon plugins of ``models/decoder.py``
+    run on the hot path (``engine.py``, ``engine_llama.py``); ``load_in_4bit`` (bitsandbytes NF4) is refused unless I2T_4BIT_AS_FP8=1."""
     use_cross_attn: bool
     model_str: str
     extra_tokens: int

@@ -358,6 +358,10 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         # fp8 (e4m3) operands for the GEMMs of FROZEN decoder weights (engine_llama._lin; BASELINE.json configs[4]); off unless I2T_FP8=1
         self.fp8 = os.environ.get('I2T_FP8', '0') not in ('', '0') or bool(getattr(model.decoder, 'fp8_request', False))
         self.fp8_fuse = os.environ.get('I2T_FP8_FUSE', '1') != '0'      # producers emit the e4m3 operand themselves (engine_llama, csrc/fp8.hip)
+        # a frozen PretrainedViT backbone on e4m3 operands is its OWN opt-in (I2T_FP8_VIT=1): `fp8` above covers decoder weights only, as the
+        # reference's 4-bit loading does (models/decoder.py:292-299 touches the decoder); 12 backbone layers of e4m3 GEMMs cost feature
+        # fidelity (tests/test_fp8_gpu.py::test_frozen_vit_backbone_on_fp8_operands bounds it against oracle/vit.py)
+        self.fp8_vit = os.environ.get('I2T_FP8_VIT', '0') not in ('', '0')
 
     def _refresh_sparse_sets(self):
         """(Re-)read the sparse layers' position sets when their buffers changed (they are part of the state dict: a checkpoint

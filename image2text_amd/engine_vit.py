@@ -59,13 +59,24 @@ class ViTEncoder:
         return {n for n in self.arena.entries if n.startswith(f'{self.ep}model.')}
 
     # ------------------------------------------------------------------------------------------------ backbone
+    def _vit_lin(self, x_bf, W, names, out, M, N, K, **kw):
+        """A backbone GEMM: e4m3 operands only under the backbone's own switch (``fp8_vit``, I2T_FP8_VIT=1) and only for frozen weights;
+        the decoder's switch (``fp8``: I2T_FP8 / a load_in_4bit request) never reaches the encoder."""
+        if self.fp8_vit and all(not self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names)):
+            fp8, self.fp8 = self.fp8, True
+            try:
+                return self._lin(x_bf, W, names, out, M, N, K, **kw)
+            finally:
+                self.fp8 = fp8
+        return ops.gemm(x_bf, W, out, M, N, K, **kw)
+
     def _vit_block_fwd(self, q: str, x, B, T, d, H, ff, save: bool):
         a, M = self.arena, B * T
         ln1, m1, r1 = self._empty(M, d, dtype=BF16), self._empty(M), self._empty(M)
         ops.layernorm_fwd(x, a.P(q + 'ln_1.weight'), a.P(q + 'ln_1.bias'), ln1, m1, r1, M, d, eps=VIT_EPS)
         qkv = self._empty(M, 3 * d, dtype=BF16)
-        # (self._lin: e4m3 operands when the backbone is frozen and I2T_FP8=1 -- forward-only GEMMs of weights that never change)
-        lin = (lambda x_, name, out, N_, K_, **kw: self._lin(x_, a.W(name), name, out, M, N_, K_, **kw))
+        # (self._vit_lin: e4m3 operands when the backbone is frozen and I2T_FP8_VIT=1 -- forward-only GEMMs of weights that never change, DESIGN 4h)
+        lin = (lambda x_, name, out, N_, K_, **kw: self._vit_lin(x_, a.W(name), name, out, M, N_, K_, **kw))
         lin(ln1, q + 'self_attention.in_proj_weight', qkv, 3 * d, d, bias=a.P(q + 'self_attention.in_proj_bias'))
         q3 = qkv.view(B, T, 3 * d)
         ao, lse = self._empty(B, T, d, dtype=BF16), self._empty(H * M)
@@ -115,7 +126,7 @@ class ViTEncoder:
         patches = self._empty(B * e.P2, K0, dtype=BF16)
         ops.patchify(images, patches, B, 3, e.img, e.img, e.p)
         proj = self._empty(B * e.P2, d)
-        self._lin(patches, a.W(m + 'conv_proj.weight').view(d, K0), m + 'conv_proj.weight', proj, B * e.P2, d, K0, bias=a.P(m + 'conv_proj.bias'))
+        self._vit_lin(patches, a.W(m + 'conv_proj.weight').view(d, K0), m + 'conv_proj.weight', proj, B * e.P2, d, K0, bias=a.P(m + 'conv_proj.bias'))
         x = self._empty(B * T, d)
         ops.vit_tokens(proj, a.P(m + 'class_token'), a.P(m + 'encoder.pos_embedding'), x, B, T, d)
         saves = []

@@ -60,53 +60,112 @@ class _Done:
         torch.cuda.current_stream().wait_event(self.event)
 
 
-class RcclComm:
-    """The C-ABI communicator (include/i2t.h ``i2t_comm_*``): created collectively by all ranks of ``group``."""
+def _exchange_unique_id(group, uid: Optional[bytes]) -> bytes:
+    """Rank 0 of ``group`` hands RCCL's 128-byte unique id to the others WITHOUT a device collective: through the process group's
+    store (``TCPStore.set`` / ``get``; the get blocks until the key exists), else as a pickled host object.  A device
+    ``dist.broadcast`` would make torch create an RCCL communicator of its own just for these 128 bytes -- with it every process
+    held two communicators (two sets of channels and proxy threads on the same xGMI links)."""
+    rank = dist.get_rank(group)
+    RcclComm._created += 1
+    key = f'i2t_comm_uid/{dist.get_world_size(group)}/{RcclComm._created}'      # every rank creates its communicators in the same order
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if group is not None and group is not dist.group.WORLD:
+            key += '/' + '-'.join(str(r) for r in dist.get_process_group_ranks(group))
+        if rank == 0:
+            store.set(key, uid)
+            return uid
+        return bytes(store.get(key))
+    except Exception:                       # no reachable store (a custom rendezvous): one host-side object broadcast
+        box = [uid]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return bytes(box[0])
 
-    def __init__(self, group, device):
+
+def _all_agree(group, ok: bool, device) -> bool:
+    """True iff ``ok`` holds on EVERY rank (a MIN all-reduce over the existing group: host tensor under gloo)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+class RcclComm:
+    """The C-ABI communicator (include/i2t.h ``i2t_comm_*``): created collectively by all ranks of ``group``.  ``group`` is only
+    the control plane (unique id, agreement on success): it may be a gloo group -- then this is the process's ONLY RCCL communicator
+    and NCCL_MAX_NCHANNELS caps the one that matters (bench.py runs that way)."""
+    _created = 0
+
+    def __init__(self, group, device, max_floats: int = 0):
         import ctypes as C
         from .. import lib as _l
         self._l, self._lib = _l, _l.load()
-        if not self._lib.i2t_comm_available():
-            raise RuntimeError('RCCL is not available in this process')
+        self.handle = None
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
+        err = None
+        uid = None
+        if not self._lib.i2t_comm_available():
+            err = 'RCCL is not available in this process'
+        elif rank == 0:
             buf = C.create_string_buffer(128)
-            _l.check(self._lib.i2t_comm_unique_id(buf, 128), 'i2t_comm_unique_id')
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        uid = uid.to(device)
-        dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if self._lib.i2t_comm_unique_id(buf, 128) != 0:
+                err = 'i2t_comm_unique_id failed'
+            uid = bytes(buf.raw)
+        # every rank must take the same branch from here on: ncclCommInitRank is collective, a rank that skipped it would leave
+        # the others waiting in it forever
+        if not _all_agree(group, err is None, device):
+            raise RuntimeError(err or 'RCCL is unavailable on another rank')
+        uid = _exchange_unique_id(group, uid)
         handle = C.c_void_p()
         with torch.cuda.device(device):
-            _l.check(self._lib.i2t_comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank, C.byref(handle)), 'i2t_comm_init')
+            rc = self._lib.i2t_comm_init(uid, world, rank, C.byref(handle))
+        if not _all_agree(group, rc == 0, device):
+            if rc == 0:
+                self._lib.i2t_comm_destroy(handle)
+            raise RuntimeError('i2t_comm_init failed' + ('' if rc == 0 else f' on this rank: {_l.last_error()}') + ' (no rank keeps a communicator)')
         self.handle, self.world, self.device = handle, world, device
         self.stream = torch.cuda.Stream(device=device)
         self.wire_bf16 = os.environ.get('I2T_DP_WIRE', 'f32') == 'bf16'
+        # bf16 wire image: ONE buffer for the communicator's lifetime, sized for the largest span it will ever carry (the arena).
+        # (Re-allocating it when a later span is larger would hand the old block back to the caching allocator while a collective
+        # on the side stream may still be reading it.)
         self._staging = None
+        self._max_floats = int(max_floats)
 
-    def all_reduce_mean_async(self, t: torch.Tensor):
-        """Mean over ranks of the fp32 tensor ``t`` (contiguous view of the arena), in place, on the side stream."""
-        assert t.dtype == torch.float32 and t.is_contiguous()
+    def _staging_for(self, n: int, device):
+        if self._staging is None or self._staging.numel() < n:
+            if self._staging is not None:
+                self._staging.record_stream(self.stream)           # the allocator may reuse it only after the side stream is done with it
+            self._staging = torch.empty(max(n, self._max_floats), dtype=torch.bfloat16, device=device)
+        return self._staging
+
+    def all_reduce_async(self, t: torch.Tensor, mean: bool = True):
+        """Mean (or sum) over ranks of the fp32 tensor ``t`` (contiguous view of the arena), in place, on the side stream."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and self.handle is not None
         n = t.numel()
-        staging = None
-        if self.wire_bf16 and n % 4 == 0:
-            if self._staging is None or self._staging.numel() < n:
-                self._staging = torch.empty(n, dtype=torch.bfloat16, device=t.device)
-            staging = self._staging
+        staging = self._staging_for(n, t.device) if (self.wire_bf16 and mean and n % 4 == 0) else None
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self.stream.wait_event(ready)                      # the gradients being sent are final on the compute stream
-        self._l.check(self._lib.i2t_comm_allreduce(self.handle, self.stream.cuda_stream, t.data_ptr(), n, 1,
+        self._l.check(self._lib.i2t_comm_allreduce(self.handle, self.stream.cuda_stream, t.data_ptr(), n, 1 if mean else 0,
                                                    staging.data_ptr() if staging is not None else None), 'i2t_comm_allreduce')
         done = torch.cuda.Event()
         done.record(self.stream)
         return _Done(done)
 
+    def all_reduce_mean_async(self, t: torch.Tensor):
+        return self.all_reduce_async(t, mean=True)
+
     def close(self):
         if self.handle is not None:
+            self.stream.synchronize()
             self._lib.i2t_comm_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DataParallelGrads:
@@ -117,7 +176,7 @@ class DataParallelGrads:
         self.overlap = overlap
         self.comm = None                # RcclComm, created with the first exchange on a GPU arena (see _transport)
         self._comm_tried = False
-        self._pending = []              # (work, tensor view, needs division by world)
+        self._pending = []              # (work, tensor view, finishing step or None)
         self._reduced_upto = None       # arena offset from which the current window's gradients are already in flight/reduced
         self._reserved = False
         self._sync = True               # False inside no_sync(): accumulate locally, exchange nothing
@@ -155,14 +214,15 @@ class DataParallelGrads:
         return lo, min(hi, arena.total)
 
     def _transport(self, t: torch.Tensor):
-        """The package's RCCL communicator for GPU arenas under the nccl backend (created once, collectively: every rank reaches
-        its first exchange together); None = torch.distributed (gloo on CPU, I2T_DP_COMM=torch, or RCCL not bindable)."""
+        """The package's RCCL communicator for GPU arenas (created once, collectively: every rank reaches its first exchange
+        together; the process group -- nccl OR gloo -- is only its control plane); None = torch.distributed (a CPU arena over gloo,
+        I2T_DP_COMM=torch, or RCCL not bindable on some rank: the ranks agree on the outcome, so all of them take the same transport)."""
         if not self._comm_tried:
             self._comm_tried = True
-            if t.is_cuda and dist.get_backend(self.group) == 'nccl' and os.environ.get('I2T_DP_COMM', 'rccl') != 'torch':
+            if t.is_cuda and os.environ.get('I2T_DP_COMM', 'rccl') != 'torch':
                 try:
-                    self.comm = RcclComm(self.group, t.device)
-                except Exception as e:      # (every rank fails alike: the library is the same on all of them)
+                    self.comm = RcclComm(self.group, t.device, max_floats=self._arena().total)
+                except Exception as e:      # (raised on EVERY rank or on none: RcclComm agrees on each step before the collective init)
                     import warnings
                     warnings.warn(f'image2text_amd: C-ABI RCCL communicator unavailable ({e}); using torch.distributed.all_reduce')
         return self.comm
@@ -181,20 +241,27 @@ class DataParallelGrads:
         return [(a, b) for a, b in spans]
 
     def _reduce(self, t: torch.Tensor, async_op: bool):
+        """Start the mean over ranks of ``t`` in place.  Returns (work, post): ``post`` (or None) finishes the mean after ``work.wait()``."""
         backend = dist.get_backend(self.group)
         comm = self._transport(t)
         if comm is not None:
-            return comm.all_reduce_mean_async(t), False
+            return comm.all_reduce_mean_async(t), None
+        if os.environ.get('I2T_DP_WIRE', 'f32') == 'bf16':
+            # the bf16 wire form on torch.distributed (what csrc/comm.cpp does around ncclAllReduce: round, sum in bf16, widen x 1/world)
+            wire = t.to(torch.bfloat16)
+            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            return work, (lambda: t.copy_(wire.to(torch.float32) / self.world))
         if backend == 'nccl':
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), (lambda: t.div_(self.world))
 
     def _drain(self):
         """Wait for every collective in flight, finish its mean, release the CU reservation, close the window."""
-        for work, t, need_div in self._pending:
-            work.wait()
-            if need_div:
-                t.div_(self.world)
+        for work, _, post in self._pending:
+            if work is not None:
+                work.wait()
+            if post is not None:
+                post()
         self._pending.clear()
         self._reduced_upto = None
         if self._reserved:
@@ -214,13 +281,13 @@ class DataParallelGrads:
         lo, hi = self._split(arena)
         if hi <= lo:
             return
-        if arena.g32.is_cuda and dist.get_backend(self.group) == 'nccl' and RCCL_CUS > 0:
+        if arena.g32.is_cuda and RCCL_CUS > 0 and (self._transport(arena.g32) is not None or dist.get_backend(self.group) == 'nccl'):
             from .. import ops
             ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
             self._reserved = True
         for a, b in self._spans(arena, lo, hi):
-            work, need_div = self._reduce(arena.g32[a:b], async_op=True)
-            self._pending.append((work, arena.g32[a:b], need_div))
+            work, post = self._reduce(arena.g32[a:b], async_op=True)
+            self._pending.append((work, arena.g32[a:b], post))
         self._reduced_upto = (lo, hi)
 
     def all_reduce_mean(self):
@@ -229,8 +296,8 @@ class DataParallelGrads:
         lo, hi = self._reduced_upto if self._reduced_upto is not None else (0, 0)
         for a0, b0 in ((0, lo), (hi, arena.total)):      # everything the 'decoder' hook has not already put on the wire
             for a, b in self._spans(arena, a0, b0):
-                work, need_div = self._reduce(arena.g32[a:b], async_op=True)
-                self._pending.append((work, arena.g32[a:b], need_div))
+                work, post = self._reduce(arena.g32[a:b], async_op=True)
+                self._pending.append((work, arena.g32[a:b], post))
         self._drain()
 
     def broadcast_parameters(self, src: int = 0):
@@ -238,5 +305,28 @@ class DataParallelGrads:
         backward (its gradients are the caller's to discard: zero_grad)."""
         self._drain()
         arena = self._arena()
-        dist.broadcast(arena.p32, src=src, group=self.group)
+        comm = self._transport(arena.p32)
+        if comm is not None:
+            # on the package's own communicator: every rank but ``src`` contributes zeros to a SUM (exact: x + 0 + ... + 0)
+            if dist.get_rank(self.group) != src:
+                arena.p32.zero_()
+            comm.all_reduce_async(arena.p32, mean=False).wait()
+        else:
+            dist.broadcast(arena.p32, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
         arena._versions = None          # force a bf16 shadow refresh on the next forward
+        arena.generation += 1           # parameter VALUES changed under every cache keyed on them (fp8 weight images, merged LoRA weights)
+        eng = getattr(self.model, '_engine', None)
+        if eng is not None and hasattr(eng, '_sub_cache'):
+            for k in [k for k in eng._sub_cache if isinstance(k, tuple) and k and k[0] == 'fp8w']:
+                del eng._sub_cache[k]
+
+    def close(self):
+        """Finish whatever is in flight and destroy the communicator (collective teardown: call on every rank, before
+        ``dist.destroy_process_group``)."""
+        self._drain()
+        eng = getattr(self.model, '_engine', None)
+        if eng is not None and self._on_grads_ready in getattr(eng, 'grad_ready_hooks', []):
+            eng.grad_ready_hooks.remove(self._on_grads_ready)
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None

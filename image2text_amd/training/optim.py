@@ -62,15 +62,23 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         dw.copy_(torch.tensor(wds, dtype=torch.float32), non_blocking=True)
         self._tables = (ends, dl, dw, n, hyper)
 
+    def _has_state(self, arena, name: str) -> bool:
+        """An arena entry the kernels update (lr >= 0): a trainable parameter that some backward writes.  Frozen / ``skip_grad``
+        segments (LoRA's base weights, a frozen backbone or decoder) never get moments: none are saved, none are expected."""
+        p = arena.params.get(name)
+        return p is not None and p.requires_grad and name not in getattr(arena, 'skip_grad', ())
+
     def state_dict(self):
         """torch's layout plus the flat moments: ``state`` maps an arena entry name to its (exp_avg, exp_avg_sq) slices, ``step`` is
-        the launch-wide step count -- so ``accelerator.save_state`` / a resumed run keep the moments and the bias correction."""
+        the launch-wide step count -- so ``accelerator.save_state`` / a resumed run keep the moments and the bias correction.
+        Only segments the optimizer actually updates are emitted, as HOST copies (no second device copy of the moments at save time:
+        a frozen 7-B decoder would otherwise add ~54 GB of zeros to the device and to every checkpoint)."""
         sd = super().state_dict()
         sd['i2t_step'] = self._step
         if self._arena is not None:
             a = self._arena
-            sd['i2t_moments'] = {name: (self._m[o:o + n].detach().clone(), self._v[o:o + n].detach().clone())
-                                 for name, (o, n, _) in a.entries.items() if name in a.params}
+            sd['i2t_moments'] = {name: (self._m[o:o + n].detach().to('cpu', copy=True), self._v[o:o + n].detach().to('cpu', copy=True))
+                                 for name, (o, n, _) in a.entries.items() if self._has_state(a, name)}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -84,8 +92,11 @@ class _ArenaOptimizer(torch.optim.Optimizer):
 
     def _apply_pending_moments(self, arena):
         pm = getattr(self, '_pending_moments', None)
-        if not pm:
+        if pm is None:
             return
+        # names the checkpoint does not carry (frozen at save time, or new) start from zero moments, as a fresh optimizer would
+        self._m.zero_()
+        self._v.zero_()
         for name, (m, v) in pm.items():
             e = arena.entries.get(name)
             if e is not None and e[1] == m.numel():

@@ -170,3 +170,67 @@ def test_world2_overlap_priming_and_accumulation(tmp_path):
         want = (r[0]['local'][name] + r[1]['local'][name]) / 2      # mean over ranks of each rank's accumulated window
         got = r[0]['g'][off:off + n].view(shape)
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-8), name
+
+
+def _span_worker(rank, world, port, out_dir):
+    """A model with FROZEN stretches in its arena (a frozen backbone + frozen decoder base weights, as under LoRA /
+    prepare_for_kbit_training) on the bf16 wire: only the coalesced spans of trainable entries travel."""
+    from types import SimpleNamespace
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), I2T_DP_WIRE='bf16')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from image2text_amd.engine import ParamArena
+    from image2text_amd.models.vision_encoder_decoder import VisionEncoderDecoder
+    from image2text_amd.training import dp as dpm
+    dpm.GAP_FLOATS = 64                              # (the tiny model's entries are far smaller than the production 1 MB gap rule)
+    cfg = tiny_config()
+    model = VisionEncoderDecoder(cfg)
+    det_init_(model, seed=0)
+    frozen = [n for n, _ in model.named_parameters() if '.mlp.' in n or n.startswith('encoder.') and '.attn.' in n]
+    for n, p in model.named_parameters():
+        if n in frozen:
+            p.requires_grad_(False)
+    arena = ParamArena(model, torch.device('cpu'))
+    eng = SimpleNamespace(arena=arena, grad_ready_hooks=[])
+    dp = dpm.DataParallelGrads(SimpleNamespace(_engine=eng), overlap=True)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(arena.total, generator=g)
+    sentinel = 7.0 + rank
+    for name, (off, n, _) in arena.entries.items():
+        if name in arena.params and not arena.trainable(name):
+            local[off:off + n] = sentinel            # what a frozen segment's (never written) gradient slot holds: must not travel
+    arena.g32.copy_(local)
+    lo, hi = dp._split(arena)
+    spans = dp._spans(arena, 0, arena.total)
+    assert len(spans) > 2, spans                     # the frozen stretches really split the arena
+    for h in eng.grad_ready_hooks:
+        h('decoder')
+    assert dp._pending and dp._reduced_upto == (lo, hi)
+    dp.all_reduce_mean()
+    torch.save({'g': arena.g32.clone(), 'local': local, 'entries': arena.entries, 'spans': spans,
+                'frozen': [n for n in arena.entries if n in arena.params and not arena.trainable(n)]}, os.path.join(out_dir, f'r{rank}.pt'))
+    dp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_trainable_spans_on_the_bf16_wire(tmp_path):
+    world = 2
+    mp.spawn(_span_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'r{i}.pt', weights_only=False) for i in range(world)]
+    assert r[0]['spans'] == r[1]['spans'] and r[0]['frozen']
+    covered = torch.zeros(r[0]['g'].numel(), dtype=torch.bool)
+    for a, b in r[0]['spans']:
+        covered[a:b] = True
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    want = bf(bf(r[0]['local']) + bf(r[1]['local'])) / 2            # rounded onto the wire, summed in bf16, mean in fp32 on arrival
+    for i in range(world):
+        assert torch.equal(r[i]['g'][covered], want[covered]), 'trainable spans: the bf16-wire mean, identical on every rank'
+        assert torch.equal(r[i]['g'][~covered], r[i]['local'][~covered]), 'everything outside the spans stays local'
+    true_mean = (r[0]['local'] + r[1]['local']) / 2
+    err = (r[0]['g'][covered] - true_mean[covered]).abs().max() / true_mean[covered].abs().max()
+    assert float(err) < 2 ** -6
+    for name in r[0]['frozen']:                       # every frozen entry larger than the gap rule stayed off the wire
+        off, n, _ = r[0]['entries'][name]
+        if n > 64 + 16:
+            assert not bool(covered[off:off + n].all()), name
