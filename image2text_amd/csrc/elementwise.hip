@@ -202,6 +202,96 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(bf16_t* __restrict__
     }
 }
 
+// Single-pass form for training steps: the row (V <= 65536 bf16 = 16 x 16-byte chunks per thread of a 512-thread workgroup) is read
+// ONCE into registers, reduced to its logsumexp, and overwritten with the UN-scaled gradient w/T (softmax(z/T) - onehot) -- the
+// loss term and lse leave as in ce_fwd.  ce_fwd + ce_bwd read the logits twice and write them once (11 GB each way at the
+// benchmark's 110 k x 50 257 logits: 2.1 + 4.3 ms); this reads once and writes once.  The upstream gradient (a device scalar, 1.0
+// for a plain loss.backward()) is applied afterwards by scale_bf16_kernel, which returns at once when it is 1.
+// NCH = 16-byte chunks per thread (compile-time: the row lives in 4 NCH registers); WPS = waves per SIMD the register budget must
+// leave room for -- 3 workgroups per CU at NCH = 13 (the GPT-2 vocabulary), so that one workgroup's load phase runs beside
+// another's exp / store phase (two per CU ran 4.2 TB/s against the 5.1 of the streaming ce_bwd)
+constexpr int CE_FUSED_CHUNKS = 16;
+template <int NCH, int WPS>
+__global__ __launch_bounds__(CE_THREADS, WPS) void ce_fused_kernel(bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                              const float* __restrict__ w, float inv_temp, int64_t ignore_index,
+                                                              float* __restrict__ lse, float* __restrict__ loss, int V) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int64_t lab = labels[row];
+    bf16_t* r = logits + (size_t)row * ld;
+    const int v8 = V >> 3;
+    if (lab == ignore_index || lab < 0 || lab >= V) {   // block-uniform: a dead row's gradient is zero
+        for (int c = tid; c < v8; c += CE_THREADS) reinterpret_cast<u32x4*>(r)[c] = u32x4{0u, 0u, 0u, 0u};
+        for (int c = v8 * 8 + tid; c < V; c += CE_THREADS) r[c] = (bf16_t)0;
+        if (tid == 0) lse[row] = 0.f;
+        return;
+    }
+    const float zlab = bf16_to_f32(r[lab]) * inv_temp;                 // (every thread: read before anyone overwrites the row)
+    u32x4 pk[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = tid + k * CE_THREADS;
+        pk[k] = c < v8 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r) + c) : u32x4{0u, 0u, 0u, 0u};
+    }
+    const int ct = v8 * 8 + tid;                                       // the V % 8 tail: one element for threads 0 .. (V & 7) - 1
+    const float tail = (tid < (V & 7)) ? bf16_to_f32(r[ct]) * inv_temp : -INFINITY;
+    // max first, then ONE exp per element (the online form spends an exp per element per running-max update)
+    float m = tail;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (tid + k * CE_THREADS < v8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(bf16lo(pk[k][e]), bf16hi(pk[k][e])) * inv_temp);
+        }
+    }
+    const float bm = block_max(m, red);
+    float s = (tid < (V & 7)) ? __expf(tail - bm) : 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (tid + k * CE_THREADS < v8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += __expf(bf16lo(pk[k][e]) * inv_temp - bm) + __expf(bf16hi(pk[k][e]) * inv_temp - bm);
+        }
+    }
+    const float bs = block_sum(s, red);
+    const float l = bm + __logf(bs);
+    const float wr = w[row];
+    if (tid == 0) {
+        lse[row] = l;
+        atomicAdd(loss, wr * (l - zlab));
+    }
+    const float coef = wr * inv_temp;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = tid + k * CE_THREADS;
+        if (c < v8) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = c * 8 + 2 * e;
+                const float a = coef * (__expf(bf16lo(pk[k][e]) * inv_temp - l) - (col == lab ? 1.f : 0.f));
+                const float b = coef * (__expf(bf16hi(pk[k][e]) * inv_temp - l) - (col + 1 == lab ? 1.f : 0.f));
+                o[e] = pack_bf16x2(a, b);
+            }
+            reinterpret_cast<u32x4*>(r)[c] = o;
+        }
+    }
+    if (tid < (V & 7)) r[ct] = f32_to_bf16(coef * (__expf(tail - l) - (ct == lab ? 1.f : 0.f)));
+}
+
+// x[0 .. n) *= *scale (bf16, in place); nothing is touched when the scale is exactly 1 (the common upstream gradient)
+__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x, long n8, long n, const float* __restrict__ scale) {
+    const float sc = *scale;
+    if (sc == 1.0f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        u32x4 v = reinterpret_cast<u32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(bf16lo(v[e]) * sc, bf16hi(v[e]) * sc);
+        reinterpret_cast<u32x4*>(x)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) x[n8 * 8 + threadIdx.x] = f32_to_bf16(bf16_to_f32(x[n8 * 8 + threadIdx.x]) * sc);
+}
+
 // Momentum-distillation form of the loss (reference training/wrapper.py:134-144): the target of a labelled row is
 // alpha * softmax(teacher / T) + (1 - alpha) * onehot(label), so
 //   loss_row = lse(z/T) - (1 - alpha) z[label]/T - alpha/T * sum_v softmax(teacher/T)[v] z[v]
@@ -592,6 +682,31 @@ extern "C" int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* lab
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (bf16_t*)logits, ld, labels, w,
                        inv_temp, ignore_index, lse, gscale_ptr, V);
     I2T_CHECK_LAUNCH("i2t_ce_bwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_ce_fwd_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+                              int64_t ignore_index, float* lse, float* loss, int M, int V) {
+    I2T_REQUIRE(logits && labels && w && lse && loss && M > 0 && V > 0, "i2t_ce_fwd_bwd: bad args");
+    I2T_REQUIRE(ld % 8 == 0 && ld >= V && ALIGNED16(logits), "i2t_ce_fwd_bwd: ld=%d must be a multiple of 8 and >= V", ld);
+    I2T_REQUIRE((V >> 3) <= CE_FUSED_CHUNKS * CE_THREADS, "i2t_ce_fwd_bwd: V=%d exceeds the one-pass form's %d columns (use i2t_ce_fwd + i2t_ce_bwd)", V,
+                8 * CE_FUSED_CHUNKS * CE_THREADS);
+    const int nch = ((V >> 3) + CE_THREADS - 1) / CE_THREADS;
+#define CE_FUSED_LAUNCH(N_, W_) hipLaunchKernelGGL((ce_fused_kernel<N_, W_>), dim3(M), dim3(CE_THREADS), 0, (hipStream_t)stream, (bf16_t*)logits, ld, \
+                                                   labels, w, inv_temp, ignore_index, lse, loss, V)
+    if (nch <= 4) CE_FUSED_LAUNCH(4, 8);
+    else if (nch <= 8) CE_FUSED_LAUNCH(8, 8);
+    else if (nch <= 13) CE_FUSED_LAUNCH(13, 6);
+    else CE_FUSED_LAUNCH(16, 4);
+#undef CE_FUSED_LAUNCH
+    I2T_CHECK_LAUNCH("i2t_ce_fwd_bwd");
+    return I2T_OK;
+}
+
+extern "C" int i2t_scale_bf16(void* stream, void* x, long n, const float* scale_ptr) {
+    I2T_REQUIRE(x && scale_ptr && n > 0 && ALIGNED16(x), "i2t_scale_bf16: bad args");
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n >> 3, 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n >> 3, n, scale_ptr);
+    I2T_CHECK_LAUNCH("i2t_scale_bf16");
     return I2T_OK;
 }
 

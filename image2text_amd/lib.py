@@ -29,6 +29,8 @@ SIGNATURES = {
     'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I, P],
     'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
     'i2t_ce_bwd': [P, P, I, P, P, F, I64, P, P, I, I],
+    'i2t_ce_fwd_bwd': [P, P, I, P, P, F, I64, P, P, I, I],
+    'i2t_scale_bf16': [P, P, L, P],
     'i2t_ce_distill_fwd': [P, P, I, P, I, F, P, P, F, I64, P, P, P, I, I],
     'i2t_ce_distill_bwd': [P, P, I, P, I, F, P, P, F, I64, P, P, P, I, I],
     'i2t_ema_update': [P, P, P, P, L, F],

@@ -302,6 +302,23 @@ def ce_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, gscale, M, V):
                                _p(gscale), M, V), 'i2t_ce_bwd')
 
 
+def ce_fwd_bwd(logits, ld, labels, w, inv_temp, ignore_index, lse, loss, M, V):
+    """One pass: lse / loss as ce_fwd, and the rows overwritten with the un-scaled gradient (include/i2t.h::i2t_ce_fwd_bwd)."""
+    _need_cuda(logits, labels, w, lse, loss)
+    _l.check(_lib().i2t_ce_fwd_bwd(_stream(), _p(logits), ld, _p(labels), _p(w), float(inv_temp), int(ignore_index), _p(lse),
+                                   _p(loss), M, V), 'i2t_ce_fwd_bwd')
+
+
+CE_ONE_PASS_MAX_V = 8 * 16 * 512
+
+
+def scale_bf16(x, n, scale):
+    """x[0 .. n) *= scale[0] in place (bf16 x, device scalar); a no-op launch when the scale is exactly 1."""
+    _need_cuda(x, scale)
+    assert x.dtype == BF16 and scale.dtype == F32
+    _l.check(_lib().i2t_scale_bf16(_stream(), _p(x), int(n), _p(scale)), 'i2t_scale_bf16')
+
+
 def ce_distill_fwd(logits, ld, teacher, ld_t, alpha, labels, w, inv_temp, ignore_index, lse, lse_t, loss, M, V):
     _need_cuda(logits, teacher, labels, w, lse, lse_t, loss)
     _l.check(_lib().i2t_ce_distill_fwd(_stream(), _p(logits), ld, _p(teacher), ld_t, float(alpha), _p(labels), _p(w), float(inv_temp),

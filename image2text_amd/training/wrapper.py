@@ -15,6 +15,8 @@ Trainer options (configs/trainer.py:7-15):
 """
 from typing import Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,18 @@ from ..configs.trainer import TrainerWrapperConfig
 from ..engine import BF16, F32, HotPath
 from ..models.vision_encoder_decoder import VisionEncoderDecoder
 from .. import ops
+
+
+def _ce_forward(ctx, eng, logits, lab, w, inv_t, ignore_index, lse, loss, M, save) -> bool:
+    """The weighted cross-entropy of a step.  A forward that will be differentiated (``save``) takes the one-pass kernel: every row is
+    read once and overwritten with its gradient on the spot (the logits of a training step have no other reader) -- True tells the
+    backward that only the upstream scalar is left to apply.  I2T_CE_ONE_PASS=0 / a vocabulary past the kernel's 65 536 columns: the
+    two-kernel form (ce_fwd now, ce_bwd in the backward)."""
+    if save and eng.dec.V <= ops.CE_ONE_PASS_MAX_V and os.environ.get('I2T_CE_ONE_PASS', '1') != '0':
+        ops.ce_fwd_bwd(logits, eng.dec.Vp, lab, w, inv_t, ignore_index, lse, loss, M, eng.dec.V)
+        return True
+    ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, ignore_index, lse, loss, M, eng.dec.V)
+    return False
 
 
 class _LMLossFunction(torch.autograd.Function):
@@ -51,7 +65,7 @@ class _LMLossFunction(torch.autograd.Function):
             lse = torch.empty(M, dtype=F32, device=a.device)
             loss = torch.zeros(1, dtype=F32, device=a.device)
             inv_t = 1.0 / wrapper.temperature
-            ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, eng.dec.V)
+            ctx.ce_done = _ce_forward(ctx, eng, logits, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, save)
             ctx.pack = (wrapper, enc_ctx, dctx, logits, lab, w, lse, inv_t, B, M, ncls, None, None, None) if save else None
             return loss[0], torch.zeros((), dtype=F32, device=a.device)
         vl = wrapper._pack_rows(labels[:, :T], B, T) if (wrapper.pack_rows and eng.dec.causal) else None      # (dead rows are dead under a causal mask only)
@@ -70,6 +84,7 @@ class _LMLossFunction(torch.autograd.Function):
         loss = torch.zeros(1, dtype=F32, device=a.device)
         inv_t = 1.0 / wrapper.temperature
         teacher = lse_t = None
+        ctx.ce_done = False
         if distill:
             # the momentum twin on the same (packed) rows, never differentiated; training-mode dropout as in the reference, whose
             # forward_m runs under no_grad but with the module in train() (wrapper.py:68-71)
@@ -83,7 +98,7 @@ class _LMLossFunction(torch.autograd.Function):
             ops.ce_distill_fwd(logits, eng.dec.Vp, teacher, em.dec.Vp, wrapper.alpha, lab, w, inv_t, wrapper.ignore_index, lse, lse_t, loss,
                                M, eng.dec.V)
         else:
-            ops.ce_fwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, eng.dec.V)
+            ctx.ce_done = _ce_forward(ctx, eng, logits, lab, w, inv_t, wrapper.ignore_index, lse, loss, M, save)
         con = None
         loss_c = torch.zeros(1, dtype=F32, device=a.device)
         if wrapper.add_contrastive_loss:
@@ -104,6 +119,8 @@ class _LMLossFunction(torch.autograd.Function):
         if teacher is not None:
             ops.ce_distill_bwd(logits, eng.dec.Vp, teacher, teacher.stride(0), wrapper.alpha, lab, w, inv_t, wrapper.ignore_index, lse, lse_t,
                                gscale, M, eng.dec.V)
+        elif getattr(ctx, 'ce_done', False):     # the forward's one-pass kernel already left w/T (softmax - onehot) in place: apply the upstream scalar
+            ops.scale_bf16(logits, M * eng.dec.Vp, gscale)
         else:
             ops.ce_bwd(logits, eng.dec.Vp, lab, w, inv_t, wrapper.ignore_index, lse, gscale, M, eng.dec.V)
         dmem = torch.zeros(B * ncls, eng.dec.d, dtype=F32, device=a.device)

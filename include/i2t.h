@@ -190,6 +190,12 @@ int i2t_ce_fwd(void* stream, const void* logits, int ld, const int64_t* labels, 
                int64_t ignore_index, float* lse, float* loss, int M, int V);
 int i2t_ce_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
                int64_t ignore_index, const float* lse, const float* gscale_ptr, int M, int V);
+/* One-pass form for training steps (V <= 65536): reads every live row ONCE, leaves lse[m] and the loss term as i2t_ce_fwd does and
+ * overwrites the row with the UN-scaled gradient bf16(w[m]/T (softmax(z/T) - onehot)) (dead rows: zeros).  The upstream gradient is
+ * applied afterwards with i2t_scale_bf16 (x[0..n) *= *scale_ptr in place; returns without touching x when the scale is exactly 1). */
+int i2t_ce_fwd_bwd(void* stream, void* logits, int ld, const int64_t* labels, const float* w, float inv_temp,
+                   int64_t ignore_index, float* lse, float* loss, int M, int V);
+int i2t_scale_bf16(void* stream, void* x, long n, const float* scale_ptr);
 /* Momentum-distillation loss (reference training/wrapper.py:134-144): targets alpha * softmax(teacher/T) + (1 - alpha) * onehot.
  * teacher = the momentum twin's logits of the same rows (bf16 [M][ld_t], constant); lse_t [M] keeps its row lse for backward.
  *   fwd: loss += sum_m w[m] (lse[m] - (1 - alpha) z[m][label]/T - alpha/T sum_v softmax(teacher[m]/T)[v] z[m][v])

@@ -453,6 +453,41 @@ def test_cross_entropy(ops, M, V, ld, temp):
         assert float(logits[:, V:].float().abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,V,ld,temp', [(37, 1000, 1000, 1.0), (19, 50257, 50264, 0.7), (5, 65536, 65536, 1.0), (9, 13, 16, 2.0)])
+def test_cross_entropy_one_pass(ops, M, V, ld, temp):
+    """i2t_ce_fwd_bwd (the training step's form): loss and lse of i2t_ce_fwd, rows overwritten with the gradient at upstream scale 1
+    (dead rows zero, pad columns untouched); i2t_scale_bf16 then applies the upstream scalar -- and leaves the buffer bit for bit alone at 1."""
+    logits = torch.zeros(M, ld, dtype=BF16, device=dev())
+    logits[:, :V] = rnd(M, V, dtype=BF16, seed=28, scale=2.0)
+    labels = torch.randint(0, V, (M,), device=dev())
+    labels[::5] = -100
+    labels[1] = V - 1                                  # a label in the V % 8 tail
+    w = torch.rand(M, device=dev())
+    w[labels == -100] = 0
+    lr = logits[:, :V].float().requires_grad_(True)
+    ce = F.cross_entropy(lr / temp, labels, ignore_index=-100, reduction='none')
+    ref_loss = (ce * w).sum()
+    ref_loss.backward()
+    two = logits.clone()
+    lse2, loss2 = torch.empty(M, device=dev()), torch.zeros(1, device=dev())
+    ops.ce_fwd(two, ld, labels, w, 1.0 / temp, -100, lse2, loss2, M, V)
+    ops.ce_bwd(two, ld, labels, w, 1.0 / temp, -100, lse2, torch.ones(1, device=dev()), M, V)
+    lse, loss = torch.empty(M, device=dev()), torch.zeros(1, device=dev())
+    ops.ce_fwd_bwd(logits, ld, labels, w, 1.0 / temp, -100, lse, loss, M, V)
+    check('ce one-pass loss', loss[0], ref_loss, 1e-4, 1e-4)
+    check('ce one-pass lse', lse, lse2, 1e-5, 1e-5)
+    check('ce one-pass dlogits', logits[:, :V], lr.grad, 1e-6, 1 / 128)
+    check('ce one-pass vs two-pass', logits[:, :V], two[:, :V].float(), 1e-6, 1 / 128)
+    if ld > V:
+        assert float(logits[:, V:].float().abs().max()) == 0.0
+    keep = logits.clone()
+    ops.scale_bf16(logits, M * ld, torch.ones(1, device=dev()))
+    assert torch.equal(keep, logits)
+    ops.scale_bf16(logits, M * ld, torch.full((1,), 0.25, device=dev()))
+    assert torch.equal(logits.float(), keep.float() * 0.25)          # a power of two: exact in bf16
+
+
 def test_grad_normalize(ops):
     for n in (1000, 64 * 128 * 768 + 3):
         g = rnd(n, seed=29) * 3
