@@ -17,13 +17,24 @@
 //       (ds_read_b64_tr_b16, any 4-row set); a workgroup sweeps a row of 14 tiles keeping dW in registers, then adds
 //       its partial with contiguous float atomics into a [co][tap][ci] scratch that a tiny kernel folds into dW.
 #include "common.h"
+#include <utility>
 
 namespace {
+
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl_c(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_c(F&& f) { static_for_impl_c<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 constexpr int TS = 16;            // output tile edge
 constexpr int KS = 6;             // kernel size
 constexpr int PW = TS + KS - 1;   // 21: patch edge
 constexpr int NTAP = KS * KS;
+#ifdef I2T_CONV_NOGELU          // timing experiment (tools/build_variant.sh): the staging GELU left out -- WRONG results, prices its VALU share
+#define CONV_GELU(x) (x)
+#else
+#define CONV_GELU(x) gelu_tanh(x)
+#endif
 
 enum { SRC_NCHW_F32 = 0, SRC_NCHW_BF16 = 1, SRC_NHWC_BF16 = 2 };
 
@@ -47,13 +58,13 @@ __global__ void conv_repack_kernel(const float* __restrict__ w, bf16_t* __restri
 }
 
 // stage the (PW x PW) halo patch around tile (y0, x0) into LDS as [py][px][CP] bf16 (zero outside the image / pads)
-template <int CP, int SRC, bool IN_GELU>
+template <int CP, int SRC, bool IN_GELU, int NTH = 256>
 __device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void* __restrict__ src, int b, int C, int H, int W,
                                             int y0, int x0, int pad_before, int tid) {
     if (SRC == SRC_NHWC_BF16) {
         constexpr int CH = CP / 8;                                   // 16-byte chunks per pixel
         const bf16_t* s = reinterpret_cast<const bf16_t*>(src) + (size_t)b * H * W * CP;
-        for (int i = tid; i < PW * PW * CH; i += 256) {
+        for (int i = tid; i < PW * PW * CH; i += NTH) {
             const int ch = i % CH, px = (i / CH) % PW, py = i / (CH * PW);
             const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -61,14 +72,14 @@ __device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void*
                 v = *reinterpret_cast<const u32x4*>(s + ((size_t)gy * W + gx) * CP + ch * 8);
                 if (IN_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(gelu_tanh(bf16lo(v[e])), gelu_tanh(bf16hi(v[e])));
+                    for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(CONV_GELU(bf16lo(v[e])), CONV_GELU(bf16hi(v[e])));
                 }
             }
             *reinterpret_cast<u32x4*>(pl + (py * PW + px) * CP + ch * 8) = v;
         }
     } else {
         const size_t plane = (size_t)H * W;
-        for (int i = tid; i < CP * PW * PW; i += 256) {
+        for (int i = tid; i < CP * PW * PW; i += NTH) {
             const int px = i % PW, py = (i / PW) % PW, c = i / (PW * PW);
             const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
             float v = 0.f;
@@ -76,7 +87,7 @@ __device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void*
                 const size_t off = ((size_t)b * C + c) * plane + (size_t)gy * W + gx;
                 v = (SRC == SRC_NCHW_F32) ? reinterpret_cast<const float*>(src)[off]
                                           : bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[off]);
-                if (IN_GELU) v = gelu_tanh(v);
+                if (IN_GELU) v = CONV_GELU(v);
             }
             pl[(py * PW + px) * CP + c] = f32_to_bf16(v);
         }
@@ -85,19 +96,19 @@ __device__ __forceinline__ void stage_patch(bf16_t* __restrict__ pl, const void*
 
 // NHWC source: the same staging in two halves, so that the next tile's patch is in flight (registers) while the current
 // tile is being computed -- a tile is only ~1 us of MFMA work, less than the latency of its own halo gather.
-template <int CP>
+template <int CP, int NTH = 256>
 struct PatchRegs {
-    static constexpr int N = (PW * PW * (CP / 8) + 255) / 256;
+    static constexpr int N = (PW * PW * (CP / 8) + NTH - 1) / NTH;
     u32x4 v[N];
 };
-template <int CP, bool IN_GELU>
-__device__ __forceinline__ void patch_load(PatchRegs<CP>& pr, const void* __restrict__ src, int b, int H, int W, int y0, int x0,
+template <int CP, bool IN_GELU, int NTH = 256>
+__device__ __forceinline__ void patch_load(PatchRegs<CP, NTH>& pr, const void* __restrict__ src, int b, int H, int W, int y0, int x0,
                                            int pad_before, int tid) {
     constexpr int CH = CP / 8;
     const bf16_t* s = reinterpret_cast<const bf16_t*>(src) + (size_t)b * H * W * CP;
 #pragma unroll
-    for (int u = 0; u < PatchRegs<CP>::N; ++u) {
-        const int i = tid + 256 * u;
+    for (int u = 0; u < PatchRegs<CP, NTH>::N; ++u) {
+        const int i = tid + NTH * u;
         const int ch = i % CH, px = (i / CH) % PW, py = i / (CH * PW);
         const int gy = y0 + py - pad_before, gx = x0 + px - pad_before;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -106,18 +117,30 @@ __device__ __forceinline__ void patch_load(PatchRegs<CP>& pr, const void* __rest
         pr.v[u] = v;
     }
 }
-template <int CP, bool IN_GELU>
-__device__ __forceinline__ void patch_store(const PatchRegs<CP>& pr, bf16_t* __restrict__ pl, int tid) {
+// CP = 32 (64-byte pixels): 16 consecutive pixels of one 8-channel chunk -- what a B-fragment read touches -- sit 64 B apart, four
+// lanes of a ds_read_b128 lane group per 16-byte bank slot pair-wise (2-way conflict on 9 of the 15 reads per k-step group: the
+// backward-data kernel of the last layer is LDS-bound).  Chunk ch of patch pixel px is therefore kept at ch ^ (((px >> 2) & 1) << 1):
+// conflict-free for every horizontal tap offset (enumerated over the four lane groups x six kx).
+template <int CP>
+__device__ __forceinline__ int patch_chunk(int px, int ch) { return CP == 32 ? (ch ^ (((px >> 2) & 1) << 1)) : ch; }
+
+template <int CP, bool IN_GELU, int NTH = 256>
+__device__ __forceinline__ void patch_store(const PatchRegs<CP, NTH>& pr, bf16_t* __restrict__ pl, int tid) {
 #pragma unroll
-    for (int u = 0; u < PatchRegs<CP>::N; ++u) {
-        const int i = tid + 256 * u;
+    for (int u = 0; u < PatchRegs<CP, NTH>::N; ++u) {
+        const int i = tid + NTH * u;
         if (i >= PW * PW * (CP / 8)) continue;
         u32x4 v = pr.v[u];
         if (IN_GELU) {        // gelu(0) = 0: the zero halo stays zero
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(gelu_tanh(bf16lo(v[e])), gelu_tanh(bf16hi(v[e])));
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(CONV_GELU(bf16lo(v[e])), CONV_GELU(bf16hi(v[e])));
         }
-        *reinterpret_cast<u32x4*>(pl + (size_t)i * 8) = v;          // [py][px][ch] is exactly chunk order i
+        if (CP == 32) {
+            const int ch = i % 4, pix = i / 4;                       // [py][px][ch']: the pixel's chunks permuted by its px
+            *reinterpret_cast<u32x4*>(pl + (size_t)pix * 32 + patch_chunk<CP>(pix % PW, ch) * 8) = v;
+        } else {
+            *reinterpret_cast<u32x4*>(pl + (size_t)i * 8) = v;      // [py][px][ch] is exactly chunk order i
+        }
     }
 }
 
@@ -154,8 +177,15 @@ __device__ __forceinline__ void img_patch_store(const PatchRegsImg& pr, bf16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------ fwd / bwd-data
-template <int CP, int NT, int SRC, bool IN_GELU, bool DGELU, bool DST_NCHW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__ src, const bf16_t* __restrict__ wr,
+// NW = waves per workgroup (4: a wave owns 4 pixel rows of the 16 x 16 tile; 8: 2 rows).  The 32-channel-input form keeps 64 KiB of
+// LDS (36 KiB of weights + 28 KiB of patch): two workgroups per CU whatever their size, so it runs 8-wave workgroups -- 4 waves per SIMD
+// instead of 2 (PMC, round 4: at 2 waves per SIMD its waves were parked 56 % of their cycles, matrix pipe 32 % busy).
+// GRP (NCHW output only): the packed outputs of GRP consecutive tiles of the sweep are held in registers and stored together, so that the
+// GRP x 32-byte pieces of one (channel, row) -- one 128-byte line at GRP = 4 -- leave the wave in consecutive instructions and meet in the L2's
+// write path.  (Stored tile by tile, the neighbouring pieces of a line arrive a tile time (~1 us) apart and the last layer's forward spent
+// 1.2 us per image on its 3.2 MB of output -- 2.7 TB/s; the NHWC form, whose two 32-byte halves of a pixel are consecutive stores: 5.8.)
+template <int CP, int NT, int SRC, bool IN_GELU, bool DGELU, bool DST_NCHW, int NW = 4, int GRP = 1>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3))) void conv_mfma_kernel(const void* __restrict__ src, const bf16_t* __restrict__ wr,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ dst,
                                                         const bf16_t* __restrict__ pre, int Cin, int Cout, int H, int W,
                                                         int pad_before, int tiles_x) {
@@ -163,6 +193,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
     constexpr int COP = NT * 16;                              // padded output channels
     __shared__ __attribute__((aligned(16))) bf16_t wl[COP * WROW];
     __shared__ __attribute__((aligned(16))) bf16_t pl[PW * PW * CP];
+    constexpr int NTH = 64 * NW, RW = TS / NW;                // threads per workgroup, pixel rows per wave
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.y;
@@ -170,36 +201,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
     // A workgroup sweeps one row of tiles: the weights (up to 36 KiB) are staged ONCE per 14 tiles -- per tile they cost
     // about as much LDS-fill time as the tile's MFMA work -- and the NCHW rows of neighbouring tiles are written by the
     // same workgroup back to back (32-byte pieces that the L2 merges into full lines).
-    for (int i = tid; i < COP * NTAP * CP / 8; i += 256) {    // weights: contiguous [co][tap][ci] -> padded rows
+    for (int i = tid; i < COP * NTAP * CP / 8; i += NTH) {    // weights: contiguous [co][tap][ci] -> padded rows
         const int co = i / (NTAP * CP / 8), rest = i % (NTAP * CP / 8);
         *reinterpret_cast<u32x4*>(wl + co * WROW + rest * 8) = *reinterpret_cast<const u32x4*>(wr + (size_t)i * 8);
     }
-    PatchRegs<CP> pr;
+    // bias of the lane's output channels: once per workgroup (NCHW output: channel 16 t + li; NHWC: channels 16 t + 4 g .. + 3)
+    float bvn[NT];
+    f32x4 bvh[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bvn[t] = (bias && 16 * t + li < Cout) ? bias[16 * t + li] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bvh[t][e] = (bias && 16 * t + 4 * g + e < Cout) ? bias[16 * t + 4 * g + e] : 0.f;
+    }
+    PatchRegs<CP, NTH> pr;
     PatchRegsImg pi;
-    constexpr bool IMG_OK = SRC == SRC_NCHW_F32 && CP == 8 && !IN_GELU;
+    constexpr bool IMG_OK = SRC == SRC_NCHW_F32 && CP == 8 && !IN_GELU && NW == 4;
     const bool img = IMG_OK && Cin <= 4;                      // workgroup-uniform
-    if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, 0, pad_before, tid);
+    if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU, NTH>(pr, src, b, H, W, y0, 0, pad_before, tid);
     else if (img) img_patch_load(pi, src, b, Cin, H, W, y0, 0, pad_before, tid);
-    for (int tx = 0; tx < tiles_x; ++tx) {
+    u32x2 hold[GRP][NT][TS / NW];                             // (DST_NCHW) packed outputs of the group's tiles
+    auto do_tile = [&](int tx, auto SUB_) {
+    constexpr int SUB = decltype(SUB_)::value;
     const int x0 = tx * TS;
     __syncthreads();                                          // the previous tile's patch reads are done
-    if (SRC == SRC_NHWC_BF16) patch_store<CP, IN_GELU>(pr, pl, tid);
+    if (SRC == SRC_NHWC_BF16) patch_store<CP, IN_GELU, NTH>(pr, pl, tid);
     else if (img) img_patch_store(pi, pl, tid);
-    else stage_patch<CP, SRC, IN_GELU>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
+    else stage_patch<CP, SRC, IN_GELU, NTH>(pl, src, b, Cin, H, W, y0, x0, pad_before, tid);
     __syncthreads();
     if (tx + 1 < tiles_x) {
-        if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU>(pr, src, b, H, W, y0, x0 + TS, pad_before, tid);
+        if (SRC == SRC_NHWC_BF16) patch_load<CP, IN_GELU, NTH>(pr, src, b, H, W, y0, x0 + TS, pad_before, tid);
         else if (img) img_patch_load(pi, src, b, Cin, H, W, y0, x0 + TS, pad_before, tid);
     }
 
-    f32x4 acc[4][NT];
+    // wave-uniform: the tile lies inside the image and every padded output channel exists
+    const bool full = (y0 + TS <= H) && (x0 + TS <= W) && (Cout == COP) && (!DST_NCHW || (W & 3) == 0);
+    u32x2 prq[RW][NT];         // GELU' inputs (DGELU): requested now, used after the MFMA loop
+    if constexpr (DGELU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int oy = min(y0 + RW * w + r, H - 1), oxc = min(x0 + li, W - 1), c0 = min(16 * t + 4 * g, Cout - 4);
+#ifdef I2T_CONV_DBG_NOPRE
+                prq[r][t] = u32x2{0x3f803f80u, 0x3f803f80u};
+#else
+                prq[r][t] = *reinterpret_cast<const u32x2*>(pre + (((size_t)b * H + oy) * W + oxc) * Cout + c0);
+#endif
+            }
+    }
+    f32x4 acc[RW][NT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int CH = CP / 8;
     constexpr int NSTEP = NTAP * CH / 4;                      // k-steps of 4 (tap, chunk) groups
+#ifdef I2T_CONV_DBG_NOMMA
+    if constexpr (false) {
+#else
     if constexpr (CP >= 16) {
+#endif
         // 16 / 32 input channels: one MFMA k-step covers 2 / 1 horizontal taps of ONE kernel row, so for a fixed
         // horizontal tap (pair) the 4 output rows x 6 vertical taps of a wave read only 9 distinct patch-row fragments:
         // keep them in registers and walk the vertical taps -- (9 + 6 NT) LDS reads per 24 NT MFMAs instead of 30 NT
@@ -209,10 +271,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
 #pragma unroll 1
         for (int m = 0; m < KS / TPM; ++m) {
             const int kx = m * TPM + kxo;
-            bf16x8 pf[TS / 4 + KS - 1];                       // rows 4 w .. 4 w + 8 of the halo patch
+            bf16x8 pf[RW + KS - 1];                           // rows RW w .. RW w + RW + 4 of the halo patch
+            const int chs = (SRC == SRC_NHWC_BF16) ? patch_chunk<CP>(li + kx, ch) : ch;      // (the planar staging keeps chunk order)
 #pragma unroll
-            for (int y = 0; y < 4 + KS - 1; ++y)
-                pf[y] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((4 * w + y) * PW + li + kx) * CP + ch * 8));
+            for (int y = 0; y < RW + KS - 1; ++y)
+                pf[y] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((RW * w + y) * PW + li + kx) * CP + chs * 8));
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int kg = (ky * KS + kx) * CH + ch;
@@ -221,60 +284,123 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const void* __restrict__
                 for (int t = 0; t < NT; ++t)
                     fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (16 * t + li) * WROW + kg * 8));
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < RW; ++r)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], pf[r + ky], acc[r][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t)
+                        // DST_NCHW: patch as the A operand -> acc = D^T[pixel 4 g + e][co 16 t + li]: a lane's 4 values are 4 consecutive x of
+                        // ONE channel = one 8-byte NCHW store (un-swapped, co in the registers, NCHW took four 2-byte stores per lane)
+                        acc[r][t] = DST_NCHW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[r + ky], fw[t], acc[r][t], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], pf[r + ky], acc[r][t], 0, 0, 0);
             }
         }
     } else
+#ifdef I2T_CONV_DBG_NOMMA
+    if (pl[tid] == 0x1234)
+#endif
 #pragma unroll 2
     for (int s = 0; s < NSTEP; ++s) {
         const int kg = 4 * s + g;
         const int tap = kg / CH, ch = kg % CH;
         const int ky = tap / KS, kx = tap % KS;
-        bf16x8 fw[NT], fp[4];
+        bf16x8 fw[NT], fp[RW];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wl + (16 * t + li) * WROW + kg * 8));
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            fp[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((4 * w + r + ky) * PW + li + kx) * CP + ch * 8));
+        for (int r = 0; r < RW; ++r)
+            fp[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + ((RW * w + r + ky) * PW + li + kx) * CP + ch * 8));
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], fp[r], acc[r][t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[r][t] = DST_NCHW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[r], fw[t], acc[r][t], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], fp[r], acc[r][t], 0, 0, 0);
     }
-    // D[co = 16 t + 4 g + e][pixel = li] of output row y0 + 4 w + r
+    // ---- epilogue.  Everything the stores depend on is in registers by now (bias: loaded once before the sweep; GELU' inputs: requested
+    // before the MFMA loop), and a tile that lies inside the image / channel range takes a branch-free copy: the stores of a tile then
+    // issue back to back.  (As first written -- a bias load and per-lane range branches between the stores -- hipcc put s_waitcnt vmcnt(0)
+    // in front of every store: each waited for the previous one's write acknowledgement, 1.2 us per image in the last layer's forward.)
+    if constexpr (DST_NCHW) {
+        // D^T[pixel x0 + 4 g + e][co = 16 t + li] of output row y0 + RW w + r: 8 bytes per lane, 32 contiguous bytes per (channel, row);
+        // packed here, stored by flush() once the group's tiles are done
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float bv = bvn[t];
+                hold[SUB][t][r] = u32x2{pack_bf16x2(acc[r][t][0] + bv, acc[r][t][1] + bv), pack_bf16x2(acc[r][t][2] + bv, acc[r][t][3] + bv)};
+            }
+        return;
+    }
+    // D[co = 16 t + 4 g + e][pixel = li] of output row y0 + RW w + r
     const int ox = x0 + li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oy = y0 + 4 * w + r;
-        if (oy >= H || ox >= W) continue;
+    for (int r = 0; r < RW; ++r) {
+        const int oy = y0 + RW * w + r;
+        if (!full && (oy >= H || ox >= W)) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int c0 = 16 * t + 4 * g;
-            if (c0 >= Cout) continue;
+            if (!full && c0 >= Cout) continue;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[r][t][e] + ((bias && c0 + e < Cout) ? bias[c0 + e] : 0.f);
-            if (DGELU) {       // pre-activation of the layer below, NHWC with Cout channels
-                const u32x2 pk = *reinterpret_cast<const u32x2*>(pre + (((size_t)b * H + oy) * W + ox) * Cout + c0);
+            for (int e = 0; e < 4; ++e) v[e] = acc[r][t][e] + bvh[t][e];
+            if (DGELU) {       // pre-activation of the layer below, NHWC with Cout channels (loaded before the MFMA loop)
+                const u32x2 pk = prq[r][t];
                 v[0] *= gelu_tanh_grad(bf16lo(pk[0]));
                 v[1] *= gelu_tanh_grad(bf16hi(pk[0]));
                 v[2] *= gelu_tanh_grad(bf16lo(pk[1]));
                 v[3] *= gelu_tanh_grad(bf16hi(pk[1]));
             }
-            if (DST_NCHW) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c0 + e < Cout) dst[(((size_t)b * Cout + c0 + e) * H + oy) * W + ox] = f32_to_bf16(v[e]);
-            } else {
-                const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(dst + (((size_t)b * H + oy) * W + ox) * Cout + c0) = pk;
-            }
+            const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+#ifdef I2T_CONV_DBG_NOSTORE
+            if (pk[0] == 0x12345678u)
+#endif
+            *reinterpret_cast<u32x2*>(dst + (((size_t)b * H + oy) * W + ox) * Cout + c0) = pk;
         }
     }
-    }   // tile sweep
+    };   // do_tile
+    // (DST_NCHW) the group's outputs: for every (channel, row) the tiles' 32-byte pieces in consecutive store instructions
+    auto flush = [&](int tx0, int count) {
+        if constexpr (DST_NCHW) {
+            const bool inside = (y0 + TS <= H) && ((tx0 + count) * TS <= W) && (Cout == COP) && ((W & 3) == 0);      // wave-uniform
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < TS / NW; ++r) {
+                    const int co = 16 * t + li, oy = y0 + (TS / NW) * w + r;
+                    bf16_t* o = dst + (((size_t)b * Cout + co) * H + oy) * W + tx0 * TS + 4 * g;
+                    if (inside) {
+#pragma unroll
+                        for (int sub = 0; sub < GRP; ++sub)
+                            if (sub < count) {
+#ifdef I2T_CONV_DBG_NOSTORE
+                                if (hold[sub][t][r][0] == 0x12345678u)
+#endif
+                                *reinterpret_cast<u32x2*>(o + sub * TS) = hold[sub][t][r];
+                            }
+                    } else if (co < Cout && oy < H) {
+#pragma unroll
+                        for (int sub = 0; sub < GRP; ++sub) {
+                            if (sub >= count) continue;
+                            const int oxq = (tx0 + sub) * TS + 4 * g;
+                            const unsigned lo = hold[sub][t][r][0], hi = hold[sub][t][r][1];
+                            const bf16_t v4[4] = {(bf16_t)(lo & 0xffffu), (bf16_t)(lo >> 16), (bf16_t)(hi & 0xffffu), (bf16_t)(hi >> 16)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (oxq + e < W) o[sub * TS + e] = v4[e];
+                        }
+                    }
+                }
+        }
+    };
+    for (int tx0 = 0; tx0 < tiles_x; tx0 += GRP) {
+        const int count = min(GRP, tiles_x - tx0);                // block-uniform
+        static_for_c<GRP>([&](auto S_) {
+            if (decltype(S_)::value < count) do_tile(tx0 + decltype(S_)::value, S_);
+        });
+        flush(tx0, count);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ bwd-weight
@@ -467,9 +593,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const bf16_t* __restr
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-#define LAUNCH_CONV(CP_, NT_, SRC_, G_, D_, N_)                                                                        \
-    hipLaunchKernelGGL((conv_mfma_kernel<CP_, NT_, SRC_, G_, D_, N_>), grid, dim3(256), 0, s, src, (const bf16_t*)wr,  \
-                       bias, (bf16_t*)dst, (const bf16_t*)pre, Cin, Cout, H, W, pad_before, tiles_x)
+#ifndef CONV_NCHW_GRP
+#define CONV_NCHW_GRP 4
+#endif
+#define LAUNCH_CONV(CP_, NT_, SRC_, G_, D_, N_)                                                                                             \
+    hipLaunchKernelGGL((conv_mfma_kernel<CP_, NT_, SRC_, G_, D_, N_, (CP_ == 32 || (N_ && CP_ == 16) ? 8 : 4), ((N_ && CP_ >= 16) ? CONV_NCHW_GRP : 1)>), grid,         \
+                       dim3((CP_ == 32 || (N_ && CP_ == 16)) ? 512 : 256), 0, s, src,                                                  \
+                       (const bf16_t*)wr, bias, (bf16_t*)dst, (const bf16_t*)pre, Cin, Cout, H, W, pad_before, tiles_x)
 
 static int conv_mfma_dispatch(hipStream_t s, const void* src, int src_layout, int in_gelu, const void* wr, const float* bias,
                               void* dst, int dst_nchw, const void* pre, int B, int Cin, int Cout, int H, int W,
