@@ -436,18 +436,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     const bool img = IMG_OK && Cin <= 4;
     PatchRegsImg pi;
     if (img) img_patch_load(pi, act, b, Cin, H, W, y0, 0, pad_before, tid);
+    // NHWC sources (the layers above the first): the next tile's dY tile and activation patch are in flight in registers while this
+    // tile is computed (a tile is < 1 us of MFMA work: staged synchronously, every tile paid its own global-load latency at a barrier)
+    // (16-channel activations: the 32 extra registers cost the kernel its fourth wave per SIMD and it ran 3 % slower -- 8-channel layers only)
+    constexpr bool PRE_DY = DY_SRC == SRC_NHWC_BF16 && CP == 8, PRE_ACT = ACT_SRC == SRC_NHWC_BF16 && CP == 8;
+    constexpr int DCH = COP / 8, NDY = TS * TS * DCH / 256;
+    u32x4 dyr[PRE_DY ? NDY : 1];
+    PatchRegs<CP> pr;
+    auto dy_load = [&](int x0) {
+        const bf16_t* s_ = reinterpret_cast<const bf16_t*>(dy) + (size_t)b * H * W * Cout;
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int i = tid + 256 * u;
+            const int ch = i % DCH, px = (i / DCH) % TS, py = i / (DCH * TS);
+            const int gy = y0 + py, gx = x0 + px;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (gy < H && gx < W && ch * 8 < Cout) v = *reinterpret_cast<const u32x4*>(s_ + ((size_t)gy * W + gx) * Cout + ch * 8);
+            dyr[u] = v;
+        }
+    };
+    if constexpr (PRE_DY) dy_load(0);
+    if constexpr (PRE_ACT) patch_load<CP, ACT_GELU>(pr, act, b, H, W, y0, 0, pad_before, tid);
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int x0 = tx * TS;
         __syncthreads();
         // dY tile as [pixel][COP] (pads zero); pad_before = 0: no halo
-        if (DY_SRC == SRC_NHWC_BF16) {
-            constexpr int CH = COP / 8;
-            const bf16_t* s = reinterpret_cast<const bf16_t*>(dy) + (size_t)b * H * W * Cout;
-            for (int i = tid; i < TS * TS * CH; i += 256) {
-                const int ch = i % CH, px = (i / CH) % TS, py = i / (CH * TS);
+        if constexpr (PRE_DY) {
+#pragma unroll
+            for (int u = 0; u < NDY; ++u) *reinterpret_cast<u32x4*>(dl + (size_t)(tid + 256 * u) * 8) = dyr[u];      // [py][px][ch] is chunk order
+        } else if constexpr (DY_SRC == SRC_NHWC_BF16) {
+            const bf16_t* s_ = reinterpret_cast<const bf16_t*>(dy) + (size_t)b * H * W * Cout;
+            for (int i = tid; i < TS * TS * DCH; i += 256) {
+                const int ch = i % DCH, px = (i / DCH) % TS, py = i / (DCH * TS);
                 const int gy = y0 + py, gx = x0 + px;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (gy < H && gx < W && ch * 8 < Cout) v = *reinterpret_cast<const u32x4*>(s + ((size_t)gy * W + gx) * Cout + ch * 8);
+                if (gy < H && gx < W && ch * 8 < Cout) v = *reinterpret_cast<const u32x4*>(s_ + ((size_t)gy * W + gx) * Cout + ch * 8);
                 *reinterpret_cast<u32x4*>(dl + (py * TS + px) * COP + ch * 8) = v;
             }
         } else {
@@ -461,9 +484,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             }
         }
         if (img) img_patch_store(pi, pl, tid);
+        else if constexpr (PRE_ACT) patch_store<CP, ACT_GELU>(pr, pl, tid);
         else stage_patch<CP, ACT_SRC, ACT_GELU>(pl, act, b, Cin, H, W, y0, x0, pad_before, tid);
         __syncthreads();
-        if (img && tx + 1 < tiles_x) img_patch_load(pi, act, b, Cin, H, W, y0, x0 + TS, pad_before, tid);
+        if (tx + 1 < tiles_x) {
+            if (img) img_patch_load(pi, act, b, Cin, H, W, y0, x0 + TS, pad_before, tid);
+            if constexpr (PRE_DY) dy_load(x0 + TS);
+            if constexpr (PRE_ACT) patch_load<CP, ACT_GELU>(pr, act, b, H, W, y0, x0 + TS, pad_before, tid);
+        }
         // 8 k-steps of 32 pixels = 2 tile rows x 16 x; k-slot (g, j) <-> pixel (row 2 s + (j >> 2), x = 4 g + (j & 3))
 #pragma unroll 1
         for (int s = 0; s < 8; ++s) {
