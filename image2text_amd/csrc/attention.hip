@@ -691,6 +691,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnPtr Q, AttnPtr K,
         }
         drow[qb] = (((unsigned)b * H + h) * Tq + min(q0 + li, Tq - 1)) * (unsigned)Tk;
     }
+    // ... and so do the fragments of the remaining 1-3 blocks every wave shares (requested after the main walk they cost each pair one
+    // exposed global-load latency: T = 260 ran 40 % over T = 256 for 1.5 % more work)
+    bf16x8 rq[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rq[r][0] = rq[r][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < rem) {
+            rq[r][0] = global_row_frag(qb_, Q.rs, (4 * per + r) * 16, Tq, 0, lane);
+            rq[r][1] = global_row_frag(qb_, Q.rs, (4 * per + r) * 16, Tq, 1, lane);
+        }
+    }
     v2_stage2(k_lds, v_lds, K.p + (size_t)b * K.bs + h * 64, K.rs, V.p + (size_t)b * V.bs + h * 64, V.rs, Tk, rows_pad, tid);
     __syncthreads();
     f32x4 o[V2_NQB][4];
@@ -719,17 +730,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnPtr Q, AttnPtr K,
     }
     if (rem == 0) return;                                               // workgroup-uniform
     // ---- the remaining 1-3 query blocks: every wave runs them against its quarter of the keys, partials combined through LDS
-    bf16x8 rq[3][2];
     unsigned rdrow[3];
     f32x4 ro[3][4];
     float rm[3], rl[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int q0 = (4 * per + r) * 16;
-        if (r < rem) {
-            rq[r][0] = global_row_frag(qb_, Q.rs, q0, Tq, 0, lane);
-            rq[r][1] = global_row_frag(qb_, Q.rs, q0, Tq, 1, lane);
-        }
         rdrow[r] = (((unsigned)b * H + h) * Tq + min(q0 + li, Tq - 1)) * (unsigned)Tk;
         rm[r] = -INFINITY; rl[r] = 0.f;
 #pragma unroll
@@ -1070,7 +1076,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd2_kernel(AttnPtr Q, AttnPtr K,
 // the 8 waves each take one 16 x 16 tile of dQ^T[64 dims][32 queries] and contract it over all keys -- K^T and dS^T both as
 // transposed LDS reads.  The dS buffer takes V's place in LDS (V is only needed as the owner's row fragments: loaded from global once);
 // its 128-byte rows hold two chunks side by side (double buffer: chunk i + 1 is written while stragglers still read chunk i).
-template <bool DROP, int CNT>
+template <bool DROP, int CNT, int NWV>
 __device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigned char* k_lds, const unsigned char* do_lds, unsigned char* ds_lds,
                                        const float* lse_l, const float* dl_l, const bf16_t* vb, int v_rs, int w, int Tq, int Tk,
                                        unsigned drow_base, unsigned drop_key, unsigned drop_thr, float dscale, bf16_t* dqb, int dq_rs,
@@ -1084,14 +1090,14 @@ __device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigne
     int key[NC];
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-        const int k0 = (w + 8 * c) * 16;
+        const int k0 = (w + NWV * c) * 16;
         key[c] = k0 + li;
         kf[c][0] = v2_row_frag(k_lds, k0, 0, lane); kf[c][1] = v2_row_frag(k_lds, k0, 1, lane);
         vf[c][0] = global_row_frag(vb, v_rs, k0, Tk, 0, lane); vf[c][1] = global_row_frag(vb, v_rs, k0, Tk, 1, lane);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) adk[c][dt] = adv[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int dt_w = w & 3, qt_w = w >> 2;                                    // this wave's tile of a chunk's dQ^T[4 x 16 dims][2 x 16 queries]
+    const int dt_w = w & 3, qt_w = (w >> 2) & 1;                              // this wave's tile of a chunk's dQ^T[4 x 16 dims][2 x 16 queries] (waves 0 .. 7)
     const int nks3 = ((kpad >> 5) + 2) / 3;                                   // 32-key steps in threes (rows up to 288 exist and are zero)
     // dQ^T[dims 16 dt_w ..][queries 16 (qb + qt_w) ..] = sum over keys K^T[dim][key] dS^T[key][query]: three independent accumulation
     // chains, the six transposed reads of a trip issued together
@@ -1120,6 +1126,15 @@ __device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigne
 #pragma unroll
             for (int qj = 0; qj < 2; ++qj) {
                 const int q0 = (qb + qj) * 16;
+                if (q0 >= Tq) {          // wave-uniform: the padded half of the last chunk (T = 260: queries 272 .. 287) -- zeros, no arithmetic
+#pragma unroll
+                    for (int c = 0; c < CNT; ++c) {
+                        pp[c][qj] = ds[c][qj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int chunk = half * 4 + 2 * qj + (g >> 1);
+                        *reinterpret_cast<u32x2*>(ds_lds + key[c] * V2_RB + ((chunk ^ (key[c] & 7)) << 4) + (g & 1) * 8) = u32x2{0u, 0u};
+                    }
+                    continue;
+                }
                 const bf16x8 q0f = v2_row_frag(q_lds, q0, 0, lane), q1f = v2_row_frag(q_lds, q0, 1, lane);
                 const bf16x8 d0f = v2_row_frag(do_lds, q0, 0, lane), d1f = v2_row_frag(do_lds, q0, 1, lane);
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_l + q0 + 4 * g);
@@ -1175,11 +1190,11 @@ __device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigne
         // upper four after their owner work on the NEXT chunk -- so that one wave's LDS-latency-bound contraction runs beside the other's
         // VALU-bound softmax (in lockstep both sat in the contraction together and the SIMD idled: 53 % of wave-cycles parked).  The
         // double buffer allows it: chunk i's half is next written after barrier i + 1.
-        if (w >= 4 && qb > 0) dq_tile(qb - 2);
+        if (w >= 4 && w < 8 && qb > 0) dq_tile(qb - 2);
         __syncthreads();                                                     // the chunk's dS is complete (every key row, all owners)
         if (w < 4) dq_tile(qb);
     }
-    if (w >= 4) dq_tile(((qpad >> 4) - 1) & ~1);
+    if (w >= 4 && w < 8) dq_tile(((qpad >> 4) - 1) & ~1);
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
         if (key[c] < Tk) {
@@ -1198,8 +1213,12 @@ __device__ __forceinline__ void b3_run(const unsigned char* q_lds, const unsigne
     }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse,
+// NWV = 8 or 9 waves.  Key blocks are dealt w, w + NWV, ...: at T = 260 (17 blocks, the last one 4 keys wide) eight waves leave wave 0
+// with THREE blocks and the other seven waiting for it at every chunk barrier; a ninth wave takes the odd block (it owns no dQ tile: the
+// eight tiles of a chunk stay with waves 0 .. 7), every wave has at most two and the registers of the 3-block instantiation are never
+// needed (9 waves = 3 on one SIMD: 168 registers).
+template <bool DROP, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, bf16_t* __restrict__ dK, long dk_bs,
                                                            int dk_rs, bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq, int Tk,
                                                            unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned od_key,
@@ -1218,6 +1237,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K,
     const bf16_t* ob = O.p + (size_t)b * O.bs + h * 64;
     const bf16_t* kb_ = K.p + (size_t)b * K.bs + h * 64;
     const int qpad = (Tq + 31) & ~31, kpad = (Tk + 31) & ~31;
+    if (tid < 512) {                                                         // (the staging loops are written for 512 threads)
     b2_stage2(q_lds, do_lds, qb_, Q.rs, dob, dO.rs, Tq, qpad, tid);
     for (int c = tid; c < V2_MAXROWS * 8; c += 512) {                        // K alone (zero rows past Tk), and a dS buffer of zeros: its
         const int r = c >> 3, kc = c & 7;                                    // rows past the last owned key block are never written
@@ -1244,6 +1264,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K,
             lse_l[r] = r < Tq ? lse[stat_base + r] * LOG2E : INFINITY;
         }
     }
+    }
     __syncthreads();
     const float dscale = DROP ? drop_scale : 1.f;
     const unsigned drow_base = ((unsigned)b * H + h) * (unsigned)Tq * (unsigned)Tk, grow_q = (unsigned)b * Tq, grow_k = (unsigned)b * Tk;
@@ -1252,13 +1273,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd3_kernel(AttnPtr Q, AttnPtr K,
     bf16_t* dvb = dV + (size_t)b * dv_bs + h * 64;
     const bf16_t* vb = V.p + (size_t)b * V.bs + h * 64;
     const int nkb = (Tk + 15) >> 4;
-    const int cnt = max(0, (nkb - w + 7) >> 3);                              // key blocks w, w + 8, ... < nkb
+    const int cnt = max(0, (nkb - w + NWV - 1) / NWV);                       // key blocks w, w + NWV, ... < nkb
 #define B3_ARGS q_lds, k_lds, do_lds, ds_lds, lse_l, dl_l, vb, V.rs, w, Tq, Tk, drow_base, drop_key, drop_thr, dscale, dqb, dq_rs, dkb, dk_rs, dvb, dv_rs, \
                 od_key, od_thr, od_scale, grow_q, grow_k, lane
-    if (cnt == 0) b3_run<DROP, 0>(B3_ARGS);                                  // (every wave meets every barrier: same trip count in all four)
-    else if (cnt == 1) b3_run<DROP, 1>(B3_ARGS);
-    else if (cnt == 2) b3_run<DROP, 2>(B3_ARGS);
-    else b3_run<DROP, 3>(B3_ARGS);
+    if (cnt == 0) b3_run<DROP, 0, NWV>(B3_ARGS);                             // (every wave meets every barrier: same trip count in all four)
+    else if (cnt == 1) b3_run<DROP, 1, NWV>(B3_ARGS);
+    else if (cnt == 2 || NWV == 9) b3_run<DROP, 2, NWV>(B3_ARGS);            // (9 waves x 2 blocks = V2_MAXROWS / 16: never a third)
+    else b3_run<DROP, 3, NWV>(B3_ARGS);
 #undef B3_ARGS
 }
 
@@ -1342,12 +1363,18 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     const char* be = getenv("I2T_ATTN_BWD");
     const int bmode = (getenv("I2T_ATTN_BWD2") && getenv("I2T_ATTN_BWD2")[0] == '0') ? 0 : (be ? atoi(be) : 3);
     if (bmode == 3 && v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS) {
-        if (!drop_thr) hipLaunchKernelGGL((attn_bwd3_kernel<false>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
-                                          (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
-                                          out_drop_key, out_drop_thr, out_drop_scale);
-        else hipLaunchKernelGGL((attn_bwd3_kernel<true>), dim3(H * B), dim3(512), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
-                                (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,
-                                out_drop_key, out_drop_thr, out_drop_scale);
+        // 9 waves whenever 8 would leave a wave with a third key block (I2T_ATTN_BWD3_WAVES = 8 | 9 forces one: A/B runs)
+        static const char* we = getenv("I2T_ATTN_BWD3_WAVES");
+        const int nkb = (Tk + 15) >> 4;
+        const bool nine = we && atoi(we) == 9;      // measured (B = 1024, T = 260, dropout): 1295 us against 1228 for 8 waves -- the third register-limited
+        // wave of a SIMD and its spills cost more than wave 0's third block: off unless asked for
+        (void)nkb;
+#define B3_LAUNCH(D_, W_) hipLaunchKernelGGL((attn_bwd3_kernel<D_, W_>), dim3(H * B), dim3(64 * W_), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs, \
+                                             (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,          \
+                                             out_drop_key, out_drop_thr, out_drop_scale)
+        if (!drop_thr) { if (nine) B3_LAUNCH(false, 9); else B3_LAUNCH(false, 8); }
+        else { if (nine) B3_LAUNCH(true, 9); else B3_LAUNCH(true, 8); }
+#undef B3_LAUNCH
         I2T_CHECK_LAUNCH("i2t_attention_bwd(v3)");
         return I2T_OK;
     }

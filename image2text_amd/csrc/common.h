@@ -75,6 +75,14 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {               // s + 
     return s + (x * s) * (1.0f - s) * (d0 + d1 * x2);
 }
 
+// GELU and its derivative from ONE sigmoid (forward epilogues that keep the derivative for the backward pass: I2T_ACT_GELU_DOUT)
+__device__ __forceinline__ void gelu_tanh_both(float x, float& h, float& dh) {
+    const float d0 = 2.0f * 0.7978845608028654f, d1 = d0 * 3.0f * 0.044715f;
+    const float x2 = x * x, s = gelu_sigmoid_(x, x2);
+    h = x * s;
+    dh = s + h * (1.0f - s) * (d0 + d1 * x2);
+}
+
 // ---- exact GELU (torch nn.GELU() default, torchvision's ViT MLP): x Phi(x), Phi(x) = (1 + erf(x / sqrt 2)) / 2; derivative
 // Phi(x) + x phi(x).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, branch-free: one v_rcp_f32 + one v_exp_f32 -- libm's
 // erff inlined sixteen times per thread spilled 341 registers in the generic epilogue); exp(-x^2/2) serves erf and phi alike.

@@ -230,7 +230,18 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, const f32x4 a
                 if (r < nv) v[r] += p.bias[n4 + r];
         }
     }
-    if (p.aux_out) {
+    if (p.act == I2T_ACT_GELU_DOUT) {      // activated output + the derivative (not the pre-activation) for the backward pass
+        float dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x_ = v[r];
+            gelu_tanh_both(x_, v[r], dv[r]);
+        }
+        if (p.aux_out) {
+            bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
+            for (int r = 0; r < nv; ++r) ao[r] = f32_to_bf16(dv[r]);
+        }
+    } else if (p.aux_out) {
         bf16_t* ao = p.aux_out + (size_t)m * p.ld_aux_out + n4;
         if (nv == 4 && (p.ld_aux_out & 3) == 0) {
             u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -239,7 +250,12 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, const f32x4 a
             for (int r = 0; r < nv; ++r) ao[r] = f32_to_bf16(v[r]);
         }
     }
-    if (p.act == I2T_ACT_GELU) {
+    if (p.act == I2T_ACT_MUL_AUX) {
+        const bf16_t* ai = p.aux_in + (size_t)m * p.ld_aux_in + n4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] *= bf16_to_f32(ai[r]);
+    } else if (p.act == I2T_ACT_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
     } else if (p.act == I2T_ACT_GELU_ERF) {
@@ -345,12 +361,14 @@ struct EpiPre {
 template <int EPI>
 struct EpiFlags {
     static constexpr bool GEN = EPI == 0;
-    bool f_bias, f_gelu, f_dgelu, f_auxout, f_drop1, f_drop2, f_res, f_acc, f_f32;
+    bool f_bias, f_gelu, f_dgelu, f_auxout, f_drop1, f_drop2, f_res, f_acc, f_f32, f_gout, f_mul;
     __device__ __forceinline__ explicit EpiFlags(const GemmParams& p) {
-        f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7 || EPI == 9) ? (p.bias != nullptr) : false;
+        f_bias = (GEN || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 7 || EPI == 9 || EPI == 10) ? (p.bias != nullptr) : false;
+        f_gout = GEN ? (p.act == I2T_ACT_GELU_DOUT) : (EPI == 10);        // class 10: GELU + its derivative as the second output
+        f_mul = GEN ? (p.act == I2T_ACT_MUL_AUX) : (EPI == 11);           // class 11: product with aux_in (the stored derivative)
         f_gelu = GEN ? (p.act == I2T_ACT_GELU || p.act == I2T_ACT_GELU_ERF) : (EPI == 2);        // (the erf flavours: generic class only)
         f_dgelu = GEN ? (p.act == I2T_ACT_DGELU || p.act == I2T_ACT_DGELU_ERF) : (EPI == 4);
-        f_auxout = (GEN || EPI == 2) ? (p.aux_out != nullptr) : false;
+        f_auxout = (GEN || EPI == 2 || EPI == 10) ? (p.aux_out != nullptr) : false;
         f_drop1 = (GEN || EPI == 3) ? (p.drop_mode == 1) : false;
         f_drop2 = (GEN || EPI == 1 || EPI == 7) ? (p.drop_mode == 2) : false;
         f_res = (GEN || EPI == 3 || EPI == 9) ? (p.residual != nullptr) : false;
@@ -375,7 +393,27 @@ __device__ __forceinline__ void epilogue_loads4(const GemmParams& p, const int (
 #pragma unroll
         for (int q = 0; q < 4; ++q) L.bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nc[q]);
     }
+#ifdef I2T_G2_DBG_NOLOADS      // timing experiment (tools/build_variant.sh): the per-element epilogue loads left out -- WRONG results
+    if (F.f_dgelu) { for (int q = 0; q < 4; ++q) L.ax[q] = u32x2{0x3f803f80u, 0x3f803f80u}; }
+    if (F.f_res || F.f_acc) { for (int q = 0; q < 4; ++q) L.add[q] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+    return;
+#endif
+#ifdef I2T_G2_DBG_SMALLLOADS   // timing experiment: the same load instructions, from the first 256 rows only (cache-resident) -- WRONG results
     if (F.f_dgelu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)(mc[q] & 255) * p.ld_aux_in + nc[q]);
+    }
+    if (F.f_res) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.add[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(mc[q] & 255) * p.ldr + nc[q]);
+    }
+    if (F.f_acc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.add[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)(mc[q] & 255) * p.ldc + nc[q]);
+    }
+    return;
+#endif
+    if (F.f_dgelu || F.f_mul) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) L.ax[q] = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)mc[q] * p.ld_aux_in + nc[q]);
     }
@@ -425,7 +463,22 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
             }
         }
     }
-    if (F.f_auxout) {
+    if (F.f_gout) {                      // one sigmoid per element serves the activation and its derivative
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 dv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h_, d_;
+                gelu_tanh_both(v[q][r], h_, d_);
+                v[q][r] = h_; dv[r] = d_;
+            }
+            if (F.f_auxout && ok[q]) {
+                const u32x2 pk = {pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3])};
+                G2_STORE(reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]), pk);
+            }
+        }
+    } else if (F.f_auxout) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (ok[q]) {
@@ -433,7 +486,14 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
                 G2_STORE(reinterpret_cast<u32x2*>(p.aux_out + (size_t)m[q] * p.ld_aux_out + n4[q]), pk);
             }
     }
-    if (F.GEN && (p.act == I2T_ACT_GELU_ERF || p.act == I2T_ACT_DGELU_ERF)) {      // torchvision's ViT MLP: exact (erf) GELU
+    if (F.f_mul) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q][0] *= bf16lo(L.ax[q][0]); v[q][1] *= bf16hi(L.ax[q][0]);
+            v[q][2] *= bf16lo(L.ax[q][1]); v[q][3] *= bf16hi(L.ax[q][1]);
+        }
+    } else if (F.f_gout) {
+    } else if (F.GEN && (p.act == I2T_ACT_GELU_ERF || p.act == I2T_ACT_DGELU_ERF)) {      // torchvision's ViT MLP: exact (erf) GELU
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (p.act == I2T_ACT_GELU_ERF) {
@@ -553,7 +613,7 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
     const bool fast = EPI != 0 || epilogue_fast_ok(p);        // the launcher picks a specialised class only when fast_ok holds
     // classes that LOAD per element (residual, accumulate, GELU' input) run the loads G2_EPI_DEPTH row groups ahead
-    constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5 || EPI == 9;
+    constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5 || EPI == 9 || EPI == 11;
     constexpr int DEPTH = PIPE ? G2_EPI_DEPTH : 0, NB = DEPTH + 1;
     EpiPre L[NB];
     const int n4c = nbase + 4 * li;                           // after the transpose a lane's 4 quads share their columns
@@ -1255,6 +1315,14 @@ struct G2 {
     }
 };
 
+// The kernel's own argument block (GemmParams is the only argument: offset 0 of the kernarg segment), through a pointer the
+// compiler cannot connect to the argument `p`: loads through it are scalar loads issued where they are used.
+__device__ __forceinline__ const GemmParams* epilogue_params() {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return (const GemmParams*)k;
+}
+
 // Persistent: gridDim.x = min(#CUs, tiles) workgroups, each walks tiles idx, idx + grid, ... ; the DMA stream runs 6
 // units ahead of the MFMAs and simply continues into the next tile, so the next tile's first K-tiles land while this
 // tile's epilogue runs.  XCD x (workgroups = x mod 8) takes a contiguous chunk of every round of tiles.
@@ -1295,9 +1363,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             g.nxt = g.tile_desc(p, idx + 2 * G, ntiles);
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
-            const int inside = __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= p.M && n0 + g.wc * 64 + 64 <= p.N) ? 1 : 0);
-            if (inside) epilogue_tile_tr<8, 9, true>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
-            else epilogue_tile_tr<8, 9, false>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            const GemmParams& pe = *epilogue_params();       // (see the bf16 classes below: epilogue scalars are not kept live across the K loop)
+            const int inside = __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= pe.M && n0 + g.wc * 64 + 64 <= pe.N) ? 1 : 0);
+            if (inside) epilogue_tile_tr<8, 9, true>(pe, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            else epilogue_tile_tr<8, 9, false>(pe, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
             g.init_lane(p, tid);
             g.next_tile_reads_fp8(fa, fb0);
         }
@@ -1327,7 +1396,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         if constexpr (EPI == 8) {        // fused cross-attention: the wave's (image, head) attends out of the accumulators
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
-            xattn_epilogue(p, acc, m0 >> 8, n0, g.wr, g.wc, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+            xattn_epilogue(*epilogue_params(), acc, m0 >> 8, n0, g.wr, g.wc, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
         } else if constexpr (EPI == 6) {        // split-K partial: fp32 atomics, one wave-instruction = 4 rows x 64 contiguous bytes
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
@@ -1345,15 +1414,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         } else {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
+            // The epilogue reads its scalars (C, leading dimensions, bias / aux / residual pointers, dropout constants ...) from a
+            // LAUNDERED pointer to the kernel-argument segment: taken from `p` they are loaded at kernel entry and stay live across the
+            // K loop -- 18-30 SGPRs more than the file holds, and with all 256 VGPRs taken the spills went to SCRATCH, whose reloads
+            // (scratch_load + s_waitcnt vmcnt(0), one per 16-row group) drained every store of the tile and the next tile's DMA stream.
+            const GemmParams& pe = *epilogue_params();
             // most tiles lie inside C: that copy of the epilogue carries no clamps and no store predicates (wave-uniform choice)
-            const int inside = (EPI != 0 && p.g2_dbg == 0) ?
-                __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= p.M && n0 + g.wc * 64 + 64 <= p.N) ? 1 : 0) : 0;
-            if (p.g2_dbg & 2) {
-                if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[7][3][3];      // keep the accumulators alive
+            const int inside = (EPI != 0 && pe.g2_dbg == 0) ?
+                __builtin_amdgcn_readfirstlane((m0 + g.wr * 128 + 128 <= pe.M && n0 + g.wc * 64 + 64 <= pe.N) ? 1 : 0) : 0;
+            if (pe.g2_dbg & 2) {
+                if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(pe.C)[0] = acc[7][3][3];      // keep the accumulators alive
             } else if (inside) {
-                epilogue_tile_tr<8, EPI, true>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+                epilogue_tile_tr<8, EPI, true>(pe, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
             } else {
-                epilogue_tile_tr<8, EPI, false>(p, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+                epilogue_tile_tr<8, EPI, false>(pe, acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
             }
         }
         g.init_lane(p, tid);
@@ -1685,6 +1759,8 @@ int g256_epilogue_class(const GemmParams& p) {
     if (!fast4 || (p.N & 3) != 0) return 0;
     if (!p.c_is_f32 && none && !p.residual && !p.accumulate && p.drop_mode != 1) return 1;
     if (!p.c_is_f32 && p.act == I2T_ACT_GELU && !p.drop_mode && !p.residual && !p.accumulate) return 2;
+    if (!p.c_is_f32 && p.act == I2T_ACT_GELU_DOUT && !p.drop_mode && !p.residual && !p.accumulate) return 10;
+    if (!p.c_is_f32 && p.act == I2T_ACT_MUL_AUX && !p.bias && !p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 11;
     if (p.c_is_f32 && none && !p.accumulate && p.drop_mode != 2 && (p.residual || p.bias || p.drop_mode)) return 3;
     if (!p.c_is_f32 && p.act == I2T_ACT_DGELU && !p.bias && !p.aux_out && !p.drop_mode && !p.residual && !p.accumulate) return 4;
     if (p.c_is_f32 && none && !p.bias && !p.residual && !p.drop_mode) return 5;
@@ -1736,13 +1812,15 @@ void launch_g256(hipStream_t s, GemmParams p) {
     // forward GEMMs (B^T form) meet classes 1, 2, 3, 5, 7, the dX GEMMs (B form) classes 1, 4, 5; a class that is not built for
     // the layout runs the generic kernel (NO fall-through between cases: a wrong class dereferences a null epilogue operand)
     int cls = g256_epilogue_class(p);
-    if (B_KMAJOR ? (cls == 2 || cls == 3 || cls == 7) : (cls == 4)) cls = 0;
+    if (B_KMAJOR ? (cls == 2 || cls == 3 || cls == 7 || cls == 10) : (cls == 4 || cls == 11)) cls = 0;
     if (cls == 1) hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 1>), grid, block, 0, s, p);
     else if (cls == 5) hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 5>), grid, block, 0, s, p);
     else if (cls == 2) hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, s, p);
     else if (cls == 3) hipLaunchKernelGGL((gemm256_kernel<false, false, 3>), grid, block, 0, s, p);
     else if (cls == 7) hipLaunchKernelGGL((gemm256_kernel<false, false, 7>), grid, block, 0, s, p);
     else if (cls == 4) hipLaunchKernelGGL((gemm256_kernel<false, true, 4>), grid, block, 0, s, p);
+    else if (cls == 10) hipLaunchKernelGGL((gemm256_kernel<false, false, 10>), grid, block, 0, s, p);
+    else if (cls == 11) hipLaunchKernelGGL((gemm256_kernel<false, true, 11>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<false, B_KMAJOR, 0>), grid, block, 0, s, p);
 }
 
@@ -1965,8 +2043,8 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     I2T_REQUIRE(ldb >= (b_kmajor ? ((N + 7) & ~7) : ((K + 7) & ~7)), "i2t_gemm_bf16: ldb=%d too small", ldb);
     I2T_REQUIRE(ldc >= N, "i2t_gemm_bf16: ldc=%d < N=%d", ldc, N);
     I2T_REQUIRE(!accumulate || c_is_f32, "i2t_gemm_bf16: accumulate needs an f32 C");
-    I2T_REQUIRE((act != I2T_ACT_DGELU && act != I2T_ACT_DGELU_ERF) || aux_in, "i2t_gemm_bf16: DGELU needs aux_in");
-    I2T_REQUIRE(act >= I2T_ACT_NONE && act <= I2T_ACT_DGELU_ERF, "i2t_gemm_bf16: unknown act %d", act);
+    I2T_REQUIRE((act != I2T_ACT_DGELU && act != I2T_ACT_DGELU_ERF && act != I2T_ACT_MUL_AUX) || aux_in, "i2t_gemm_bf16: DGELU / MUL_AUX need aux_in");
+    I2T_REQUIRE(act >= I2T_ACT_NONE && act <= I2T_ACT_MUL_AUX, "i2t_gemm_bf16: unknown act %d", act);
     I2T_REQUIRE(((uintptr_t)C & (c_is_f32 ? 15 : 7)) == 0, "i2t_gemm_bf16: C misaligned");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;

@@ -45,6 +45,8 @@ from .engine_vit import ViTEncoder
 from .lib import I2TError
 
 BF16, F32 = torch.bfloat16, torch.float32
+# I2T_GELU_DOUT=0: the MLP's first GEMM keeps the pre-activation and the backward re-evaluates GELU' (A/B runs, bit-compatible with round 3)
+GELU_KEEPS_DERIVATIVE = os.environ.get('I2T_GELU_DOUT', '1') != '0'
 
 
 def _round_up(x: int, m: int) -> int:
@@ -515,7 +517,12 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             sv.lo['mlp_c_fc'] = self._lora_gemm(lo['mlp_c_fc'], ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ldrop('mlp_c_fc'), save,
                                                 bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
         else:
-            ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+            # the second output of a step that will be differentiated is GELU'(pre), not pre: the backward GEMM's epilogue is then one
+            # multiply per element (ops.ACT_MUL_AUX) instead of re-evaluating exp + rcp; the LoRA forms keep the pre-activation
+            dout = save and GELU_KEEPS_DERIVATIVE and lo.get('mlp_c_proj') is None
+            ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, M, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'),
+                     act=ops.ACT_GELU_DOUT if dout else 1, aux_out=pre)
+            sv.pre_is_grad = dout
         x3 = self._empty(M, d)
         if lo.get('mlp_c_proj') is not None:
             sv.lo['mlp_c_proj'] = self._lora_gemm(lo['mlp_c_proj'], h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, M, ldrop('mlp_c_proj'), save,
@@ -563,7 +570,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             ops.dgelu_mul(dh32, sv.pre, dpre)
         else:
             self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
-                             dx_out=dpre, act=2, aux_in=sv.pre)
+                             dx_out=dpre, act=ops.ACT_MUL_AUX if getattr(sv, 'pre_is_grad', False) else 2, aux_in=sv.pre)
         dln = self._empty(M, d, dtype=BF16)
         dln2 = dln
         if svlo.get('mlp_c_fc') is not None:
@@ -649,10 +656,11 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         ops.layernorm_fwd(x1, a.P(f'{pfx}.ln_2.weight'), a.P(f'{pfx}.ln_2.bias'), ln2, m2, r2, Mc, d)
         h = self._empty(Mc, ff, dtype=BF16)
         pre = self._empty(Mc, ff, dtype=BF16) if save else None
-        ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, Mc, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=1, aux_out=pre)
+        dout = save and GELU_KEEPS_DERIVATIVE
+        ops.gemm(ln2, a.W(f'{pfx}.mlp.c_fc.weight'), h, Mc, ff, d, bias=a.P(f'{pfx}.mlp.c_fc.bias'), act=ops.ACT_GELU_DOUT if dout else 1, aux_out=pre)
         x3 = self._empty(Mc, d)
         ops.gemm(h, a.W(f'{pfx}.mlp.c_proj.weight'), x3, Mc, d, ff, bias=a.P(f'{pfx}.mlp.c_proj.bias'), residual=x1, drop=dr['mlp'])
-        sv = SimpleNamespace(x=x, dr=dr, ln1=ln1, m1=m1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, ln2=ln2, m2=m2, r2=r2, h=h, pre=pre)
+        sv = SimpleNamespace(x=x, dr=dr, ln1=ln1, m1=m1, r1=r1, qkv=qkv, ao=ao, lse=lse, x1=x1, ln2=ln2, m2=m2, r2=r2, h=h, pre=pre, pre_is_grad=dout)
         return x3, (sv if save else None)
 
     def block_bwd_cls(self, pfx: str, sv, dcls, dx_full, B, T, d, H, ff, ncls):
@@ -666,8 +674,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         # (the patch rows' gradient is zero: same norm as over the full block output); ws[1] collects sum(dx_full^2) below
         ops.grad_normalize(dcls, self._ws[0:1], dxb, bf16_drop=dr['mlp'], clear_after=self._ws[1:2])
         dpre = self._empty(Mc, ff, dtype=BF16)
-        self._linear_bwd(dxb, Mc, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', bias(f'{pfx}.mlp.c_proj.bias'), dx_out=dpre, act=2,
-                         aux_in=sv.pre)
+        self._linear_bwd(dxb, Mc, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', bias(f'{pfx}.mlp.c_proj.bias'), dx_out=dpre,
+                         act=ops.ACT_MUL_AUX if sv.pre_is_grad else 2, aux_in=sv.pre)
         dln = self._empty(Mc, d, dtype=BF16)
         self._linear_bwd(dpre, Mc, ff, d, sv.ln2, f'{pfx}.mlp.c_fc.weight', bias(f'{pfx}.mlp.c_fc.bias'), dx_out=dln)
         ops.layernorm_bwd(dln, sv.x1, a.P(f'{pfx}.ln_2.weight'), sv.m2, sv.r2, dcls, a.G(f'{pfx}.ln_2.weight'),

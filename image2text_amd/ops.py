@@ -580,7 +580,7 @@ class Graph:
 
 
 # ---- PretrainedViT pieces (csrc/vit.hip)
-ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_ERF, ACT_DGELU_ERF = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_ERF, ACT_DGELU_ERF, ACT_GELU_DOUT, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
 def patchify(images, out, B, C, H, W, p):

@@ -54,6 +54,9 @@ int i2t_last_error(char* buf, size_t n);
 #define I2T_ACT_DGELU 2
 #define I2T_ACT_GELU_ERF 3  /* exact GELU x Phi(x) (torchvision ViT MLP); generic epilogue class only */
 #define I2T_ACT_DGELU_ERF 4 /* v *= gelu_erf'(aux_in[m][n]) */
+#define I2T_ACT_GELU_DOUT 5 /* C = gelu_tanh(v) and aux_out = gelu_tanh'(v) (bf16) instead of the pre-activation: the layer's backward is then */
+#define I2T_ACT_MUL_AUX 6   /* v *= aux_in[m][n] -- one multiply per element where I2T_ACT_DGELU re-evaluates exp + rcp (the GELU' epilogue */
+                            /* of a K = 512 GEMM cost ~8 us of VALU per 256 x 256 tile against 11.6 us of MFMA work) */
 int i2t_gemm_bf16(void* stream,
                   const void* A, int lda, int a_kmajor,
                   const void* B, int ldb, int b_kmajor,

@@ -282,6 +282,37 @@ def test_gemm_large_tile_epilogues(ops):
     check('qkv multipliers', outq, (base + bias) * mult.repeat_interleave(N // 3, dim=1), 2e-2, 1 / 128)
 
 
+@pytest.mark.parametrize('M,N,K', [(260, 512, 256), (2900, 2304, 512), (2560, 2048, 768)])
+def test_gemm_gelu_derivative_output_and_multiply_epilogues(ops, M, N, K):
+    """I2T_ACT_GELU_DOUT (forward: C = gelu(v), aux_out = gelu'(v)) and I2T_ACT_MUL_AUX (backward: v *= aux_in): the pair the dense MLP
+    uses instead of (GELU + pre-activation, GELU' re-evaluated) -- small shape = the 128^2 kernel's generic epilogue, large = the
+    persistent kernel's classes 10 / 11 (and the generic class for the layouts those are not built for)."""
+    a, b = rnd(M, K, dtype=BF16, seed=23), rnd(N, K, dtype=BF16, seed=24, scale=0.1)
+    bias = rnd(N, seed=25)
+    base = a.float() @ b.float().t()
+    out, dout = torch.empty(M, N, dtype=BF16, device=dev()), torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, b, out, M, N, K, bias=bias, act=ops.ACT_GELU_DOUT, aux_out=dout)
+    check('gelu(bias + ab)', out, F.gelu(base + bias, approximate='tanh'), 1e-2, 1 / 128)
+    check("gelu'(bias + ab)", dout, gelu_grad(base + bias), 1e-2, 1 / 128)
+    ref_out = torch.empty_like(out)
+    ops.gemm(a, b, ref_out, M, N, K, bias=bias, act=1)
+    assert torch.equal(out, ref_out), 'the activated output must not depend on what the second output holds'
+    ops.gemm(a, b, out, M, N, K, act=ops.ACT_GELU_DOUT, aux_out=dout)           # no bias
+    check("gelu'(ab)", dout, gelu_grad(base), 1e-2, 1 / 128)
+    aux = rnd(M, N, dtype=BF16, seed=27)
+    bt = b.t().contiguous()
+    for kw, what in ((dict(), 'B^T form'), (dict(b_kmajor=True), 'k-major B (the dX form)')):
+        od = torch.empty(M, N, dtype=BF16, device=dev())
+        ops.gemm(a, bt if kw else b, od, M, N, K, act=ops.ACT_MUL_AUX, aux_in=aux, **kw)
+        check(f'multiply by aux, {what}', od, base * aux.float(), 2e-2, 1 / 128)
+    # the pair is the old pair: (ab^T) * gelu'(pre) either way
+    pre = rnd(M, N, dtype=BF16, seed=28)
+    old_, new_ = torch.empty(M, N, dtype=BF16, device=dev()), torch.empty(M, N, dtype=BF16, device=dev())
+    ops.gemm(a, bt, old_, M, N, K, b_kmajor=True, act=2, aux_in=pre)
+    ops.gemm(a, bt, new_, M, N, K, b_kmajor=True, act=ops.ACT_MUL_AUX, aux_in=gelu_grad(pre.float()).to(BF16))
+    check('dgelu == multiply by the stored derivative', new_, old_.float(), 1e-2, 1 / 64)
+
+
 def test_colsum(ops):
     x = rnd(5000, 200, dtype=BF16, seed=11)
     out = torch.zeros(200, device=dev())
