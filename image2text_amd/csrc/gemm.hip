@@ -41,6 +41,7 @@ struct GemmParams {
     int M, N, K;
     int lda, ldb, ldc;
     float alpha;
+    const float* alpha_sumsq;   // device scalar S (or null): alpha is multiplied by 1 / (sqrt(S) + 1e-6) -- a gradient normaliser folded into the GEMM
     const float* bias;
     int act;
     const bf16_t* aux_in;
@@ -89,6 +90,12 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int swz, int& t
     }
     tile_m = rem / width;
     tile_n = grp * gn + rem % width;
+}
+
+// alpha as the epilogues apply it: the host's factor, times the gradient normaliser 1 / (||g|| + 1e-6) when the caller hands over
+// sum(g^2) of the tensor the A operand was cut from (models/functions.py:19-24: the operand then stays un-normalised in memory)
+__device__ __forceinline__ float eff_alpha(const GemmParams& p) {
+    return p.alpha_sumsq ? p.alpha / (sqrtf(*p.alpha_sumsq) + 1e-6f) : p.alpha;
 }
 
 // One operand's staging registers: 4 x 16-byte chunks per thread per K-step.
@@ -198,6 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     if (SPLITK) {
         // un-swapped accumulators: lane holds C[m0 + wm*64 + 16 i + 4 g + r][n0 + wn*64 + 16 j + li], r = 0..3
         float* C = reinterpret_cast<float*>(p.C);
+        const float alpha = eff_alpha(p);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -206,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
-                    if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                    if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * alpha);
                 }
             }
         return;
@@ -217,8 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // The fused epilogue for ONE lane's 4 consecutive columns C[m][n4 .. n4+3] (a4 = raw accumulators); m < M and n4 < N.
 __device__ __forceinline__ void epilogue_quad(const GemmParams& p, const f32x4 a4, int m, int n4, bool vec_ok) {
     float v[4];
+    const float alpha = eff_alpha(p);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = a4[r] * p.alpha;
+    for (int r = 0; r < 4; ++r) v[r] = a4[r] * alpha;
     const int nv = (p.N - n4) < 4 ? (p.N - n4) : 4;
     if (p.bias) {
         if (nv == 4) {      // one 16-byte load (n4 % 4 == 0) instead of four scalar ones
@@ -357,6 +366,7 @@ struct EpiPre {
     u32x2 ax[4];
     f32x4 sb;            // class 9: the lane's 4 column scales (one vector per tile) and its 4 rows' scales
     float sa[4];
+    float alpha;         // eff_alpha(p), evaluated once per tile
 };
 template <int EPI>
 struct EpiFlags {
@@ -450,7 +460,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
     const bool has_add = F.f_res || F.f_acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        v[q] = a[q] * p.alpha;
+        v[q] = a[q] * L.alpha;
         if constexpr (EPI == 9) v[q] = v[q] * L.sa[q] * L.sb;          // fp8 operands: row scale of A x column scale of B
         if (F.f_bias) v[q] += L.bv[q];
         if constexpr (EPI == 9) {                                      // (forward-only users: a frozen backbone's MLP -- no pre-activation output)
@@ -565,6 +575,7 @@ __device__ __forceinline__ void epilogue_finish4(const GemmParams& p, const f32x
 template <int EPI>
 __device__ __forceinline__ void epilogue_batch4(const GemmParams& p, const f32x4 (&a)[4], const int (&m)[4], const int (&n4)[4]) {
     EpiPre L;
+    L.alpha = eff_alpha(p);
     epilogue_loads4<EPI>(p, m, n4, L);
     epilogue_finish4<EPI>(p, a, m, n4, L);
 }
@@ -616,6 +627,11 @@ __device__ __forceinline__ void epilogue_tile_tr(const GemmParams& p, f32x4 (&ac
     constexpr bool PIPE = EPI == 3 || EPI == 4 || EPI == 5 || EPI == 9 || EPI == 11;
     constexpr int DEPTH = PIPE ? G2_EPI_DEPTH : 0, NB = DEPTH + 1;
     EpiPre L[NB];
+    {
+        const float alpha = eff_alpha(p);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) L[s].alpha = alpha;
+    }
     const int n4c = nbase + 4 * li;                           // after the transpose a lane's 4 quads share their columns
     auto rows_of = [&](int i, int (&m)[4], int (&n4)[4]) {
 #pragma unroll
@@ -1401,6 +1417,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
             float* C = reinterpret_cast<float*>(p.C);
+            const float alpha = eff_alpha(p);
             const int mb = m0 + g.wr * 128 + 4 * (lane_e >> 4), n_ = n0 + g.wc * 64 + (lane_e & 15);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -1409,7 +1426,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = mb + i * 16 + r, n = n_ + j * 16;
-                        if (m < p.M && n < p.N && !(p.g2_dbg & 2)) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                        if (m < p.M && n < p.N && !(p.g2_dbg & 2)) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * alpha);
                     }
         } else {
             int lane_e = tid & 63;
@@ -1882,7 +1899,7 @@ bool launch_g256_dw(hipStream_t s, GemmParams p) {
 // out[n] (+)= sum_m X[m][n]: 16-byte loads (8 columns per lane, 512 columns per wave-row), the 4 waves of a
 // workgroup stride the rows of its slice, LDS combine, one float atomic per column per workgroup.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const float* __restrict__ alpha_sumsq) {
     __shared__ float part[4][512];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 512 + lane * 8;
@@ -1922,7 +1939,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int n = blockIdx.x * 512 + c;
-        if (n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+        if (n < N) atomicAdd(out + n, (part[0][c] + part[1][c] + part[2][c] + part[3][c]) * (alpha_sumsq ? 1.0f / (sqrtf(*alpha_sumsq) + 1e-6f) : 1.0f));
     }
 }
 
@@ -1978,7 +1995,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
         for (int r = 0; r < 4; ++r) {
             const int n = n4 + r;
             if (n >= p.N) continue;
-            float val = v[r] * p.alpha;
+            float val = v[r] * eff_alpha(p);
             if (gridDim.y > 1) {            // split-K: C already holds the residual; slice 0 contributes the bias
                 if (p.bias && blockIdx.y == 0) val += p.bias[n];
                 atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, val);
@@ -2033,6 +2050,15 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
                              const float* bias, int act, const void* aux_in, int ld_aux_in, void* aux_out,
                              int ld_aux_out, const float* residual, int ldr, int accumulate, int drop_mode,
                              unsigned drop_key, unsigned drop_thr, float drop_scale) {
+    return i2t_gemm_bf16_ex(stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, c_is_f32, M, N, K, alpha, bias, act, aux_in, ld_aux_in, aux_out,
+                            ld_aux_out, residual, ldr, accumulate, drop_mode, drop_key, drop_thr, drop_scale, nullptr);
+}
+
+extern "C" int i2t_gemm_bf16_ex(void* stream, const void* A, int lda, int a_kmajor, const void* B, int ldb,
+                                int b_kmajor, void* C, int ldc, int c_is_f32, int M, int N, int K, float alpha,
+                                const float* bias, int act, const void* aux_in, int ld_aux_in, void* aux_out,
+                                int ld_aux_out, const float* residual, int ldr, int accumulate, int drop_mode,
+                                unsigned drop_key, unsigned drop_thr, float drop_scale, const float* alpha_sumsq) {
     I2T_REQUIRE(A && B && C, "i2t_gemm_bf16: null operand");
     I2T_REQUIRE(M > 0 && N > 0 && K > 0, "i2t_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     // K need not be a multiple of 8, but an operand whose reduction index is contiguous is then read up to the
@@ -2049,7 +2075,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.alpha = alpha; p.bias = bias; p.act = act;
+    p.alpha = alpha; p.alpha_sumsq = alpha_sumsq; p.bias = bias; p.act = act;
     p.aux_in = (const bf16_t*)aux_in; p.ld_aux_in = ld_aux_in;
     p.aux_out = (bf16_t*)aux_out; p.ld_aux_out = ld_aux_out;
     p.residual = residual; p.ldr = ldr; p.c_is_f32 = c_is_f32; p.accumulate = accumulate;
@@ -2147,7 +2173,7 @@ extern "C" int i2t_gemm_bf16(void* stream, const void* A, int lda, int a_kmajor,
         // rule is OFF; gemm3 stays reachable through I2T_GEMM3 for the record of the overlap experiment.
         const int g3 = e3 ? atoi(e3) : 0;
         const int cls3 = g256_epilogue_class(p);
-        if (g3 && splits == 1 && !a_kmajor && !b_kmajor && K % 64 == 0 && alpha == 1.0f && (N & 7) == 0 && (ldc & 7) == 0 && ALIGNED16(C) &&
+        if (g3 && splits == 1 && !a_kmajor && !b_kmajor && K % 64 == 0 && alpha == 1.0f && !alpha_sumsq && (N & 7) == 0 && (ldc & 7) == 0 && ALIGNED16(C) &&
             ((cls3 == 1 && K >= 5 * 64) || (cls3 == 2 && K >= 8 * 64 && (!aux_out || ((ld_aux_out & 7) == 0 && ALIGNED16(aux_out))))) &&
             (long)((M + 255) / 256) * ((N + 127) / 128) >= 2 * min_tiles) {
             launch_g3(s, p, g3 == 2);
@@ -2259,6 +2285,10 @@ extern "C" int i2t_gemm_reserve_cus(int n_reserved) {
 extern "C" int i2t_gemm_reserved_cus(void) { return __atomic_load_n(&g_cu_reserve, __ATOMIC_RELAXED); }
 
 extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate) {
+    return i2t_colsum_bf16_ex(stream, X, ld, M, N, out, accumulate, nullptr);
+}
+
+extern "C" int i2t_colsum_bf16_ex(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate, const float* alpha_sumsq) {
     I2T_REQUIRE(X && out && M > 0 && N > 0, "i2t_colsum_bf16: bad args");
     I2T_REQUIRE((ld & 7) == 0 && ALIGNED16(X), "i2t_colsum_bf16: X must be 16-byte aligned with ld %% 8 == 0");
     hipStream_t s = (hipStream_t)stream;
@@ -2271,7 +2301,7 @@ extern "C" int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N
     const int want = 512 / col_blocks;                // ~2 workgroups per CU overall
     if (splits > want) splits = want;
     if (splits < 1 || i2t_det()) splits = 1;           // (deterministic mode: one workgroup per column block = one add per column)
-    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, splits), dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, splits), dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out, alpha_sumsq);
     I2T_CHECK_LAUNCH("i2t_colsum_bf16");
     return I2T_OK;
 }

@@ -47,6 +47,8 @@ from .lib import I2TError
 BF16, F32 = torch.bfloat16, torch.float32
 # I2T_GELU_DOUT=0: the MLP's first GEMM keeps the pre-activation and the backward re-evaluates GELU' (A/B runs, bit-compatible with round 3)
 GELU_KEEPS_DERIVATIVE = os.environ.get('I2T_GELU_DOUT', '1') != '0'
+# I2T_FOLD_NORMALISER=0: every block runs its own grad_normalize pass over the incoming gradient (A/B runs)
+NORMALISER_FOLDED = os.environ.get('I2T_FOLD_NORMALISER', '1') != '0'
 
 
 def _round_up(x: int, m: int) -> int:
@@ -534,20 +536,22 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         sv.layer = layer
         return x3, (sv if save else None)
 
-    def _linear_bwd(self, dyb, M, N, K, x_bf, wname: str, bname: Optional[str], dx_out=None, **dx_kw):
-        """y = x W^T + b with y [M,N], x [M,K], W [N,K]: accumulates dW, db; returns/fills dX when requested."""
+    def _linear_bwd(self, dyb, M, N, K, x_bf, wname: str, bname: Optional[str], dx_out=None, dy_sumsq=None, **dx_kw):
+        """y = x W^T + b with y [M,N], x [M,K], W [N,K]: accumulates dW, db; returns/fills dX when requested.
+        dy_sumsq (1-float device tensor): dyb is an UN-normalised gradient whose normaliser 1 / (sqrt(dy_sumsq) + 1e-6) the three
+        consumers apply themselves (ops.gemm alpha_sumsq): no pass over dyb exists just to rescale it."""
         a = self.arena
         gb = a.Gt(bname) if bname else None
         if gb is not None:
-            ops.colsum(dyb, gb, M, N, accumulate=True)
+            ops.colsum(dyb, gb, M, N, accumulate=True, alpha_sumsq=dy_sumsq)
         if a.trainable(wname):
-            ops.gemm(dyb, x_bf, a.G(wname), N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True)
+            ops.gemm(dyb, x_bf, a.G(wname), N, K, M, a_kmajor=True, b_kmajor=True, accumulate=True, alpha_sumsq=dy_sumsq)
         if dx_out is not None:
-            ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, **dx_kw)
+            ops.gemm(dyb, a.W(wname), dx_out, M, K, N, b_kmajor=True, alpha_sumsq=dy_sumsq, **dx_kw)
         return dx_out
 
     def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None, sumsq_out=None,
-                  dx_pre=None):
+                  dx_pre=None, dxb_sumsq=None, last_bf16_drop=None):
         """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output; dxb already normalised, dx too unless dx_pre (1 float:
         sum(dx^2)) is given -- then the first LayerNorm backward that accumulates onto dx applies 1 / (||dx|| + 1e-6) on the fly
         (the normaliser's fp32 rescale pass is not run).  On return dx (and dxb when emit_last_bf16) hold the gradient w.r.t. the
@@ -569,8 +573,10 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                                   a.Gt(f'{pfx}.mlp.c_proj.weight'), a.Gt(f'{pfx}.mlp.c_proj.bias'), M, ldrop('mlp_c_proj'))
             ops.dgelu_mul(dh32, sv.pre, dpre)
         else:
+            # dxb_sumsq: dxb is the block-output gradient as the layer above left it -- masked, NOT normalised; mlp.c_proj's three
+            # backward launches apply 1 / (||dx|| + 1e-6) in their epilogues (no grad_normalize pass ran for this block)
             self._linear_bwd(dxb, M, d, ff, sv.h, f'{pfx}.mlp.c_proj.weight', f'{pfx}.mlp.c_proj.bias' if a.G(f'{pfx}.mlp.c_proj.bias') is not None else None,
-                             dx_out=dpre, act=ops.ACT_MUL_AUX if getattr(sv, 'pre_is_grad', False) else 2, aux_in=sv.pre)
+                             dx_out=dpre, act=ops.ACT_MUL_AUX if getattr(sv, 'pre_is_grad', False) else 2, aux_in=sv.pre, dy_sumsq=dxb_sumsq)
         dln = self._empty(M, d, dtype=BF16)
         dln2 = dln
         if svlo.get('mlp_c_fc') is not None:
@@ -629,9 +635,10 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             self._linear_bwd(dqkv, M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight',
                              f'{pfx}.attn.c_attn.bias' if a.G(f'{pfx}.attn.c_attn.bias') is not None else None, dx_out=dln)
         # last writer of dx in this block: it also leaves sum(dx^2) for the next block's gradient normaliser
+        # (emit_last_bf16 with last_bf16_drop: the bf16 copy is the NEXT block's incoming gradient, already masked for ITS mlp.c_proj)
         ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.Gt(f'{pfx}.ln_1.weight'),
                           a.Gt(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None,
-                          sumsq_out=sumsq_out)
+                          bf16_drop=last_bf16_drop if emit_last_bf16 else None, sumsq_out=sumsq_out)
 
     # ---- the encoder's LAST block, CLS rows only.  The encoder output is ln_f of the first ncls rows (encoder.py:172-173); the
     # patch rows of the last block feed nothing, forward or backward.  K and V still come from every row; the queries, the
@@ -713,14 +720,23 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                 self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
                                vl=vl, dx_pre=self._unit_sq)
             return
+        fold = NORMALISER_FOLDED and not any(getattr(sv, 'lo', None) for sv in saves)      # (LoRA's mlp.c_proj backward reads a normalised dxb)
+        folded = False          # dxb already holds this block's incoming gradient (raw, masked): written by the block above
         for l in reversed(range(len(saves))):
             cur, nxt = self._ws[slot:slot + 1], self._ws[1 - slot:2 - slot]
-            # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
-            # (fp32 dx stays un-normalised here: the block's first LayerNorm backward rescales it while accumulating)
-            ops.grad_normalize(dx, cur, dxb, bf16_drop=saves[l].dr['mlp'], presummed=presummed, clear_after=nxt, keep_f32=True)
-            self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
-                           vl=vl, sumsq_out=nxt, dx_pre=cur)
-            slot, presummed = 1 - slot, True
+            if folded:
+                nxt.zero_()                                    # the accumulator this block's last LayerNorm backward adds into
+            else:
+                # normalize_gradients at the block output; the bf16 copy feeds mlp.c_proj's backward -> carries the MLP mask
+                # (fp32 dx stays un-normalised here: the block's first LayerNorm backward rescales it while accumulating)
+                ops.grad_normalize(dx, cur, dxb, bf16_drop=saves[l].dr['mlp'], presummed=presummed, clear_after=nxt, keep_f32=True)
+            # every block but the lowest hands the one below its gradient as an UN-normalised bf16 copy (written by its last LayerNorm
+            # backward, which also leaves sum(dx^2)): that block's mlp.c_proj backward applies the normaliser in its GEMM epilogues
+            hand_down = fold and l > 0
+            self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=hand_down,
+                           vl=vl, sumsq_out=nxt, dx_pre=cur, dxb_sumsq=cur if folded else None,
+                           last_bf16_drop=saves[l - 1].dr['mlp'] if hand_down else None)
+            slot, presummed, folded = 1 - slot, True, hand_down
 
     # ------------------------------------------------------------------------------------------------ encoder
     def encode(self, images: torch.Tensor, save: bool):

@@ -14,10 +14,12 @@ SIGNATURES = {
     'i2t_abi_version': [],
     'i2t_last_error': [C.c_char_p, C.c_size_t],
     'i2t_gemm_bf16': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I, I, U, U, F],
+    'i2t_gemm_bf16_ex': [P, P, I, I, P, I, I, P, I, I, I, I, I, F, P, I, P, I, P, I, P, I, I, I, U, U, F, P],
     'i2t_gemm_reserve_cus': [I],
     'i2t_gemm_reserved_cus': [],
     'i2t_xattn_kv_fused': [P, P, I, P, I, P, P, L, I, P, I, P, I, P, L, I, P, I, I, I, I, U, U, F],
     'i2t_colsum_bf16': [P, P, I, I, I, P, I],
+    'i2t_colsum_bf16_ex': [P, P, I, I, I, P, I, P],
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_fwd_eps': [P, P, P, P, P, I, P, P, I, I, F],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],

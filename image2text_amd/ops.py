@@ -38,9 +38,10 @@ def _drop(drop):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
          lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         ldr=None, accumulate=False, drop=None, workspace=None):
+         ldr=None, accumulate=False, drop=None, workspace=None, alpha_sumsq=None):
     """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16.  workspace (fp32, decode steps): the
-    deterministic split-K form i2t_gemm_bf16_ws when the problem has few tiles and a long K."""
+    deterministic split-K form i2t_gemm_bf16_ws when the problem has few tiles and a long K.  alpha_sumsq (1-float device tensor):
+    alpha is further divided by sqrt(alpha_sumsq) + 1e-6 on the device (i2t_gemm_bf16_ex: a folded gradient normaliser)."""
     _need_cuda(a, b, out)
     assert a.dtype == BF16 and b.dtype == BF16 and out.dtype in (BF16, F32)
     lda = a.stride(0) if lda is None else lda
@@ -55,6 +56,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     ld_ai = aux_in.stride(0) if aux_in is not None else 0
     ld_ao = aux_out.stride(0) if aux_out is not None else 0
     ldr = (residual.stride(0) if residual is not None else 0) if ldr is None else ldr
+    if alpha_sumsq is not None:
+        _l.check(_lib().i2t_gemm_bf16_ex(_stream(), _p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc,
+                                         int(out.dtype == F32), M, N, K, float(alpha), _p(bias), int(act), _p(aux_in), ld_ai,
+                                         _p(aux_out), ld_ao, _p(residual), ldr, int(accumulate), *_drop(drop), _p(alpha_sumsq)), 'i2t_gemm_bf16_ex')
+        return out
     _l.check(_lib().i2t_gemm_bf16(_stream(), _p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc,
                                   int(out.dtype == F32), M, N, K, float(alpha), _p(bias), int(act), _p(aux_in), ld_ai,
                                   _p(aux_out), ld_ao, _p(residual), ldr, int(accumulate), *_drop(drop)), 'i2t_gemm_bf16')
@@ -79,10 +85,10 @@ def gemm_reserved_cus() -> int:
     return int(_lib().i2t_gemm_reserved_cus())
 
 
-def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumulate=False):
+def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumulate=False, alpha_sumsq=None):
     _need_cuda(x, out)
-    _l.check(_lib().i2t_colsum_bf16(_stream(), _p(x), x.stride(0) if ld is None else ld, M, N, _p(out), int(accumulate)),
-             'i2t_colsum_bf16')
+    _l.check(_lib().i2t_colsum_bf16_ex(_stream(), _p(x), x.stride(0) if ld is None else ld, M, N, _p(out), int(accumulate), _p(alpha_sumsq)),
+             'i2t_colsum_bf16_ex')
     return out
 
 

@@ -68,6 +68,22 @@ int i2t_gemm_bf16(void* stream,
                   const float* residual, int ldr,
                   int accumulate,
                   int drop_mode, unsigned drop_key, unsigned drop_thr, float drop_scale);
+/* The same call with a gradient normaliser folded in: alpha_sumsq (device scalar, or NULL) = sum(g^2) of the tensor the A operand was
+ * cut from; alpha is then multiplied by 1 / (sqrt(*alpha_sumsq) + 1e-6) on the device (reference models/functions.py:19-24 divides the
+ * block-output gradient by its norm + 1e-6: the backward GEMMs of the block's last linear read the UN-normalised bf16 gradient and
+ * apply the factor in their epilogues, so no pass over the gradient exists just to rescale it). */
+int i2t_gemm_bf16_ex(void* stream,
+                  const void* A, int lda, int a_kmajor,
+                  const void* B, int ldb, int b_kmajor,
+                  void* C, int ldc, int c_is_f32,
+                  int M, int N, int K, float alpha,
+                  const float* bias, int act,
+                  const void* aux_in, int ld_aux_in,
+                  void* aux_out, int ld_aux_out,
+                  const float* residual, int ldr,
+                  int accumulate,
+                  int drop_mode, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                     const float* alpha_sumsq);
 
 /* Fused cross-attention forward (reference models/layers.py:537-542,600-605: nn.MultiheadAttention over the encoder output):
  *   kv[b][key][0:d | d:2d] = mem[b][key][:] . [W_k ; W_v]^T + bias_kv          (bf16, written once: the backward pass reads it)
@@ -104,6 +120,9 @@ int i2t_gemm_reserve_cus(int n_reserved);
 int i2t_gemm_reserved_cus(void);
 
 int i2t_colsum_bf16(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate);
+/* out[n] (+)= (sum_m X[m][n]) / (sqrt(*alpha_sumsq) + 1e-6)  (alpha_sumsq NULL: plain sums): the bias gradient of a linear layer whose
+ * output gradient X is kept un-normalised (see i2t_gemm_bf16_ex) */
+int i2t_colsum_bf16_ex(void* stream, const void* X, int ld, int M, int N, float* out, int accumulate, const float* alpha_sumsq);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (layers.py:349-358, F.layer_norm eps 1e-5, optional bias)
