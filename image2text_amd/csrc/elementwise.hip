@@ -123,6 +123,21 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f32_to_bf16(src[n8 * 8 + threadIdx.x]);
 }
 
+// I2T_PRECISE=1 (the opt-in inference parity mode, ops.py): an fp32 buffer as the sum of two bf16 terms, hi = bf16(f(x)) and
+// lo = bf16(f(x) - hi), f = identity / GELU(tanh) / exact GELU.  A GEMM fed hi and lo of both operands (three products through the
+// accumulate class) sees them to 2^-17 instead of 2^-9.
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n,
+                                                    int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = src[i];
+        if (act == I2T_ACT_GELU) v = gelu_tanh(v);
+        else if (act == I2T_ACT_GELU_ERF) v = gelu_erf(v);
+        const bf16_t h = f32_to_bf16(v);
+        hi[i] = h;
+        if (lo) lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- cross entropy
 // one workgroup per row; V bf16 logits are read once with an online (max, sum) per thread, combined across the block
 constexpr int CE_THREADS = 512;
@@ -662,6 +677,14 @@ extern "C" int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long
     I2T_REQUIRE(src && dst && n > 0 && ALIGNED16(src) && ALIGNED16(dst), "i2t_cast_f32_bf16: bad args");
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     I2T_CHECK_LAUNCH("i2t_cast_f32_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_split_f32_bf16(void* stream, const float* src, void* hi, void* lo, long n, int act) {
+    I2T_REQUIRE(src && hi && n > 0, "i2t_split_f32_bf16: bad args");
+    I2T_REQUIRE(act == I2T_ACT_NONE || act == I2T_ACT_GELU || act == I2T_ACT_GELU_ERF, "i2t_split_f32_bf16: act=%d (none, GELU(tanh) or exact GELU)", act);
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)hi, (bf16_t*)lo, n, act);
+    I2T_CHECK_LAUNCH("i2t_split_f32_bf16");
     return I2T_OK;
 }
 

@@ -215,6 +215,8 @@ class ParamArena:
         v = tuple(p._version for p in self.params.values())
         if v != self._versions:
             ops.cast_f32_bf16(self.p32, self.pbf, self.total)
+            if ops.precise():          # I2T_PRECISE=1: the cast also wrote the parameters' low-order bf16 terms (ops.py)
+                ops.register_shadow(self.pbf)
             self._versions = v
             self.generation += 1
 
@@ -413,6 +415,11 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             self._moe_cache.clear()
             self._sub_cache.clear()
             self._lora_merge_list = []
+        if ops.precise():
+            if training:
+                raise I2TError('I2T_PRECISE=1 is the parity mode of the inference forward: unset it to train')
+            if getattr(self.arena.pbf, '_i2t_lo', None) is None:       # shadow cast before the mode was switched on: cast again, both terms
+                self.arena._versions = None
         self.arena.refresh_shadow()
         self._refresh_sparse_sets()
         self.enc_drop = self.dec_drop = self.dec_drop_prompt = None
@@ -498,7 +505,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                                                         save, bias=bin_[d:])
                 ops.attention_fwd(v3(q, d), kv[..., :d], kv[..., d:], v3(co, d), lse_c, B, H, T, S, False, drop=dr['xattn'],
                                   cu_q=cu, total_q=M)
-            elif self.xattn_fused and S == 64 and H % 2 == 0 and d == 64 * H:
+            elif self.xattn_fused and S == 64 and H % 2 == 0 and d == 64 * H and not ops.precise():
                 # ONE launch: K/V projection GEMM whose waves run the attention of their (image, head) out of the accumulators
                 # (K and V are written once for the backward pass and never read back here)
                 ops.xattn_kv_fused(mem_bf, win[d:], bin_[d:], v3(q, d), kv, v3(co, d), lse_c, B, S, H, T, drop=dr['xattn'],

@@ -46,6 +46,7 @@ SIGNATURES = {
     'i2t_conv6_bwd_weight': [P, P, I, P, I, I, P, P, P, I, I, I, I, I],
     'i2t_nchw_to_nhwc_bf16': [P, P, P, I, I, I, I],
     'i2t_cast_f32_bf16': [P, P, P, L],
+    'i2t_split_f32_bf16': [P, P, P, P, L, I],
     'i2t_dropout_apply': [P, P, I, L, I, I, U, U, F],
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_snradam_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],

@@ -3,6 +3,8 @@
 PyTorch supplies device memory and the current HIP stream; every op below launches hand-written gfx950 kernels
 through ``libi2t_hip.so`` and raises ``I2TError`` on any failure (no fallback).
 """
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -36,12 +38,101 @@ def _drop(drop):
     return (0, 0, 0, 1.0) if drop is None else (int(drop[0]), int(drop[1]), int(drop[2]), float(drop[3]))
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# I2T_PRECISE=1 -- the opt-in PARITY mode of the teacher-forced forward (never part of a measured step).  Every
+# bf16 GEMM operand this module produces from fp32 data (LayerNorm rows, fp32 -> bf16 casts, the parameter shadow, activated GEMM
+# outputs) is written as TWO bf16 terms, hi = bf16(x) and lo = bf16(x - hi); ``lo`` rides on the hi tensor object (``_i2t_lo``), so a
+# tensor that lost it (a view, an attention output, the conv stack's bf16 patches) simply counts as exact: never wrong, only one
+# term short.  gemm() then runs hi.hi + lo.hi + hi.lo through the SAME MFMA kernels (the second and third product through the
+# accumulate class) into fp32, and applies bias / GELU / the bf16 rounding of its output afterwards.  Attention keeps bf16 q, k, v, P
+# and the conv stack its bf16 operands: the oracle with exactly those two roundings left deviates by 5e-3 on the nano-224 logits
+# (tools/diag_precision.py), the shipped one-term pipeline by 1.7e-2.
+# ------------------------------------------------------------------------------------------------------------------------------
+PRECISE_CALLS = {'gemm': 0, 'products': 0, 'splits': 0}
+_SHADOWS = []            # weak references to bf16 parameter shadows that carry a low-order term (engine.ParamArena.refresh_shadow)
+
+
+def precise() -> bool:
+    return os.environ.get('I2T_PRECISE', '0') not in ('', '0')
+
+
+def split_f32(src: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], n: Optional[int] = None, act: int = 0):
+    """hi = bf16(f(src)), lo = bf16(f(src) - hi) over the first n elements (include/i2t.h::i2t_split_f32_bf16)"""
+    _need_cuda(src, hi, lo)
+    assert src.dtype == F32 and hi.dtype == BF16 and (lo is None or lo.dtype == BF16)
+    _l.check(_lib().i2t_split_f32_bf16(_stream(), _p(src), _p(hi), _p(lo), src.numel() if n is None else n, int(act)), 'i2t_split_f32_bf16')
+    PRECISE_CALLS['splits'] += 1
+    return hi
+
+
+def register_shadow(shadow: torch.Tensor):
+    """the bf16 parameter shadow (whose ``_i2t_lo`` a precise cast just wrote): weight VIEWS of it find their low-order term by address"""
+    _SHADOWS[:] = [r for r in _SHADOWS if r() is not None and r() is not shadow]
+    _SHADOWS.append(weakref.ref(shadow))
+
+
+def _lo_of(t: torch.Tensor):
+    lo = getattr(t, '_i2t_lo', None)
+    if lo is not None:
+        return lo
+    for r in _SHADOWS:
+        sh = r()
+        if sh is None or getattr(sh, '_i2t_lo', None) is None:
+            continue
+        off = t.data_ptr() - sh.data_ptr()
+        if 0 <= off < 2 * sh.numel():
+            return torch.as_strided(sh._i2t_lo, t.size(), t.stride(), off // 2)
+    return None
+
+
+def _gemm_precise(a, b, out, M, N, K, *, a_kmajor, b_kmajor, lda, ldb, ldc, alpha, bias, act, aux_in, aux_out, residual, ldr, accumulate,
+                  drop, alpha_sumsq):
+    if drop is not None or aux_in is not None or aux_out is not None or alpha_sumsq is not None or act not in (0, ACT_GELU, ACT_GELU_ERF):
+        raise _l.I2TError('I2T_PRECISE=1 covers inference forwards only (no dropout, no saved pre-activations, no backward epilogues)')
+    direct = out.dtype == F32 and act == 0
+    if not direct and (residual is not None or accumulate or not out.is_contiguous() or (ldc is not None and ldc != out.stride(0))):
+        raise _l.I2TError('I2T_PRECISE=1: a bf16 / activated GEMM output must be a plain contiguous buffer')
+    acc = out if direct else torch.zeros(M, out.shape[-1], dtype=F32, device=out.device)          # (pad columns stay zero)
+    kw = dict(a_kmajor=a_kmajor, b_kmajor=b_kmajor, alpha=alpha)
+    ldacc = ldc if direct else None
+    _gemm(a, b, acc, M, N, K, lda=lda, ldb=ldb, ldc=ldacc, bias=bias, residual=residual, ldr=ldr, accumulate=accumulate, **kw)
+    n = 1
+    a_lo, b_lo = _lo_of(a), _lo_of(b)
+    if a_lo is not None:
+        _gemm(a_lo, b, acc, M, N, K, lda=lda, ldb=ldb, ldc=ldacc, accumulate=True, **kw)
+        n += 1
+    if b_lo is not None:
+        _gemm(a, b_lo, acc, M, N, K, lda=lda, ldb=ldb, ldc=ldacc, accumulate=True, **kw)
+        n += 1
+    PRECISE_CALLS['gemm'] += 1
+    PRECISE_CALLS['products'] += n
+    if not direct:
+        if out.dtype == F32:
+            raise _l.I2TError('I2T_PRECISE=1: an activated GEMM writes bf16 operands')
+        lo = torch.empty_like(out)
+        split_f32(acc, out, lo, act=act)
+        out._i2t_lo = lo
+    return out
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, a_kmajor=False, b_kmajor=False,
          lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          ldr=None, accumulate=False, drop=None, workspace=None, alpha_sumsq=None):
     """out[M,N] = epilogue(alpha * op(a) . op(b)); see include/i2t.h::i2t_gemm_bf16.  workspace (fp32, decode steps): the
     deterministic split-K form i2t_gemm_bf16_ws when the problem has few tiles and a long K.  alpha_sumsq (1-float device tensor):
-    alpha is further divided by sqrt(alpha_sumsq) + 1e-6 on the device (i2t_gemm_bf16_ex: a folded gradient normaliser)."""
+    alpha is further divided by sqrt(alpha_sumsq) + 1e-6 on the device (i2t_gemm_bf16_ex: a folded gradient normaliser).
+    Under I2T_PRECISE=1: the three-product form of the parity mode (above)."""
+    if precise():
+        return _gemm_precise(a, b, out, M, N, K, a_kmajor=a_kmajor, b_kmajor=b_kmajor, lda=lda, ldb=ldb, ldc=ldc, alpha=alpha, bias=bias,
+                             act=act, aux_in=aux_in, aux_out=aux_out, residual=residual, ldr=ldr, accumulate=accumulate, drop=drop,
+                             alpha_sumsq=alpha_sumsq)
+    return _gemm(a, b, out, M, N, K, a_kmajor=a_kmajor, b_kmajor=b_kmajor, lda=lda, ldb=ldb, ldc=ldc, alpha=alpha, bias=bias, act=act,
+                 aux_in=aux_in, aux_out=aux_out, residual=residual, ldr=ldr, accumulate=accumulate, drop=drop, workspace=workspace,
+                 alpha_sumsq=alpha_sumsq)
+
+
+def _gemm(a, b, out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, alpha=1.0, bias=None, act=0, aux_in=None,
+          aux_out=None, residual=None, ldr=None, accumulate=False, drop=None, workspace=None, alpha_sumsq=None):
     _need_cuda(a, b, out)
     assert a.dtype == BF16 and b.dtype == BF16 and out.dtype in (BF16, F32)
     lda = a.stride(0) if lda is None else lda
@@ -95,6 +186,11 @@ def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld=None, accumula
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=None):
     """eps None: the reference's LayerNorm (1e-5); torchvision's ViT blocks pass 1e-6."""
     _need_cuda(x, y)
+    if y.dtype == BF16 and precise():          # parity mode: the row in fp32, then its two bf16 terms
+        y32 = torch.empty(y.shape, dtype=F32, device=y.device)
+        layernorm_fwd(x, gamma, beta, y32, mean, rstd, M, d, eps)
+        y._i2t_lo = torch.empty_like(y)
+        return split_f32(y32, y, y._i2t_lo)
     if eps is not None:
         _l.check(_lib().i2t_layernorm_fwd_eps(_stream(), _p(x), _p(gamma), _p(beta), _p(y), int(y.dtype == F32), _p(mean), _p(rstd),
                                               M, d, float(eps)), 'i2t_layernorm_fwd_eps')
@@ -487,6 +583,9 @@ def nchw_to_nhwc(src, dst, B, C, H, W):
 
 def cast_f32_bf16(src, dst, n=None):
     _need_cuda(src, dst)
+    if precise():
+        dst._i2t_lo = torch.zeros_like(dst)
+        return split_f32(src, dst, dst._i2t_lo, n)
     _l.check(_lib().i2t_cast_f32_bf16(_stream(), _p(src), _p(dst), src.numel() if n is None else n), 'i2t_cast_f32_bf16')
     return dst
 

@@ -293,6 +293,11 @@ int i2t_nchw_to_nhwc_bf16(void* stream, const void* src, void* dst, int B, int C
  *   add_rows / cls concat helpers for the encoder token buffer.
  * --------------------------------------------------------------------------------------------------------- */
 int i2t_cast_f32_bf16(void* stream, const float* src, void* dst, long n);
+/* hi[i] = bf16(f(src[i])), lo[i] = bf16(f(src[i]) - hi[i]) (lo may be null); f by act: I2T_ACT_NONE, I2T_ACT_GELU, I2T_ACT_GELU_ERF.
+ * The operand producer of the opt-in parity mode I2T_PRECISE=1 (image2text_amd/ops.py: every GEMM as hi.hi + lo.hi + hi.lo through the
+ * accumulate class; inference only, never part of a measured step).  The reference computes these operands in fp32
+ * (models/layers.py: nn.Linear on fp32 activations under precision '32'). */
+int i2t_split_f32_bf16(void* stream, const float* src, void* hi, void* lo, long n, int act);
 /* in-place dropout of x[rows][cols] (f32 or bf16) with the same counter-based keep rule as the fused epilogues:
  * mode 1: element (r, c) kept iff u8(key, r*cols + c) >= thr; mode 2: all of (r, third t of cols) kept iff
  * u8(key + t, r) >= thr (u8 and thr as for i2t_gemm_bf16).  Used for the embedding dropouts and to re-apply a forward mask to a gradient. */

@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 import torch
 
+from image2text_amd.lib import I2TError
 from image2text_amd.synth import det_init_, fake_tokenizer, nano224_config, synthetic_batch, tiny_config
 
 pytestmark = pytest.mark.gpu
@@ -303,6 +304,43 @@ def test_nano224_reference_init_logits_bf16_floor():
         assert err.max() <= ref_max and rms <= ref_rms and (err <= 1e-2).mean() >= ref_frac, 'worse than the reference under bf16 autocast'
     maxerr('nano224_refinit.logits_lse', torch.logsumexp(out.logits.float(), -1), g['logits_lse'], 1e-2)
     assert abs(float(vloss) - float(g['val_loss'])) <= 1e-3 * float(g['val_loss'])
+
+
+def test_nano224_reference_init_logits_within_1e2_in_precise_mode(monkeypatch):
+    """The literal north-star tolerance, met once: under I2T_PRECISE=1 (image2text_amd/ops.py: every GEMM operand produced from fp32
+    data carries a second bf16 term, every GEMM runs hi.hi + lo.hi + hi.lo through the same MFMA kernels and its accumulate class;
+    attention and the conv stack keep their bf16 operands) the nano-224 logits at the reference's initial distributions satisfy
+    allclose(atol=1e-2, rtol=1e-2) against the fp32 reference fixture -- all of them.  So the 1.5-1.7e-2 of the shipped one-term
+    pipeline (test above) is operand rounding and nothing else.  The mode is inference-only and never runs in bench.py."""
+    from conftest import load_golden
+    from image2text_amd import ops
+    g = load_golden('nano224_refinit.npz')
+    monkeypatch.setenv('I2T_PRECISE', '1')
+    cfg = nano224_config()
+    w = _wrapper(cfg)
+    det_init_(w.model, seed=0, style='reference')
+    w.eval()
+    tok = fake_tokenizer(cfg.decoder_config.vocab_size)
+    images, labels = synthetic_batch(2, 224, 64, cfg.decoder_config.vocab_size, seed=1)
+    ids = torch.where(labels != -100, labels, torch.full_like(labels, tok.eos_token_id))
+    ids = torch.cat((torch.full((2, 1), tok.bos_token_id), ids), dim=1)[:, :64]
+    before = dict(ops.PRECISE_CALLS)
+    with torch.no_grad():
+        out = w.model(images=images.to(dev()), ids=ids.to(dev()))
+    calls = {k: ops.PRECISE_CALLS[k] - before[k] for k in before}
+    REPORT['nano224_refinit.precise.calls'] = calls
+    L_e, L_d = cfg.vision_encoder_config.n_layer, cfg.decoder_config.n_layer
+    assert calls['gemm'] >= 4 * L_e + 6 * L_d + 3 and calls['products'] >= 3 * calls['gemm'] - 2 * (L_e + 2 * L_d) - 1, calls
+    maxerr('nano224_refinit.precise.encoder_output', out.encoder_output, g['encoder_output'], 1e-2)
+    for key, sl in (('logits_head', slice(0, 256)), ('logits_tail', slice(-64, None))):
+        got = out.logits[:, :, sl].float().cpu().numpy()
+        err = np.abs(got - g[key])
+        REPORT[f'nano224_refinit.precise.{key}'] = {'max_abs_err': float(err.max()), 'rms_err': float(np.sqrt((err ** 2).mean())),
+                                                     'frac_violating_allclose_1e-2_1e-2': float((err > 1e-2 + 1e-2 * np.abs(g[key])).mean())}
+        assert np.allclose(got, g[key], atol=1e-2, rtol=1e-2), f'{key}: max abs err {err.max():.4g}'
+    with pytest.raises(I2TError, match='I2T_PRECISE'):          # inference only
+        w.train()
+        w.train_step(images.to(dev()), labels.to(dev()))
 
 
 # ------------------------------------------------------------------------------------------------------ greedy decode
