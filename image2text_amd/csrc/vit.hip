@@ -230,9 +230,11 @@ __global__ __launch_bounds__(256) void peer_lookup_bwd_kernel(const float* __res
                                                               const int* __restrict__ sv_unit, const int* __restrict__ sv_lr,
                                                               const float* __restrict__ sv_score, const float* __restrict__ sv_dot,
                                                               float* __restrict__ dS, bf16_t* __restrict__ dip, float* __restrict__ g_in,
-                                                              float* __restrict__ g_out, int nh, int nq, int k, int din, int dout_w) {
+                                                              float* __restrict__ g_out, int nh, int nq, int k, int din, int dout_w, int M) {
     __shared__ float dfw[PEER_MAXK], dt[PEER_MAXK];
-    const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (deterministic mode launches ONE workgroup that walks the rows in order: the table gradients are then summed in a fixed order)
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
     const float* g = dout + (size_t)row * dout_w;
     for (int h = 0; h < nh; ++h) {
         const size_t base = ((size_t)row * nh + h) * k;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void peer_lookup_bwd_kernel(const float* __res
             *reinterpret_cast<unsigned*>(dip + ((size_t)row * nh + h) * din + c) = pack_bf16x2(a0, a1);
         }
         __syncthreads();
+    }
     }
 }
 
@@ -360,15 +363,19 @@ __global__ __launch_bounds__(256) void lsh_embed_fwd_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void lsh_embed_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ rows, float* __restrict__ gtab,
                                                             long slot_stride, const long* __restrict__ tab_off, int n_cls, int nK, int n_proj,
-                                                            int dout) {
-    const int s = blockIdx.x % n_cls, tid = threadIdx.x;
-    const int* rr = rows + (size_t)blockIdx.x * nK * n_proj;
+                                                            int dout, int nblk) {
+    const int tid = threadIdx.x;
     const float inv = 1.0f / (float)n_proj;
-    for (int c = tid; c < dout; c += 256) {
-        const float g = dy[(size_t)blockIdx.x * dout + c] * inv;
-        for (int kk = 0; kk < nK; ++kk) {
-            float* t = gtab + (size_t)s * slot_stride + tab_off[kk];
-            for (int j = 0; j < n_proj; ++j) atomicAdd(t + (size_t)rr[kk * n_proj + j] * dout + c, g);
+    // (deterministic mode launches ONE workgroup that walks the (image, slot) rows in order; a column belongs to one thread throughout)
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int s = blk % n_cls;
+        const int* rr = rows + (size_t)blk * nK * n_proj;
+        for (int c = tid; c < dout; c += 256) {
+            const float g = dy[(size_t)blk * dout + c] * inv;
+            for (int kk = 0; kk < nK; ++kk) {
+                float* t = gtab + (size_t)s * slot_stride + tab_off[kk];
+                for (int j = 0; j < n_proj; ++j) atomicAdd(t + (size_t)rr[kk * n_proj + j] * dout + c, g);
+            }
         }
     }
 }
@@ -442,9 +449,9 @@ extern "C" int i2t_peer_lookup_bwd(void* stream, const float* dout, const void* 
     I2T_REQUIRE(dout && inp_proj && emb_in && emb_out && sv_unit && sv_lr && sv_score && sv_dot && dscores && dinp_proj && M > 0 && nhead > 0 &&
                     nq <= PEER_MAXQ && topk >= 1 && topk <= PEER_MAXK && din % 8 == 0 && dout_w % 4 == 0 && ALIGNED16(dout) && ALIGNED16(emb_out),
                 "i2t_peer_lookup_bwd: bad args");
-    hipLaunchKernelGGL(peer_lookup_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dout, (const bf16_t*)inp_proj, (const bf16_t*)emb_in,
-                       (const bf16_t*)emb_out, sv_unit, sv_lr, sv_score, sv_dot, dscores, (bf16_t*)dinp_proj, g_emb_in, g_emb_out, nhead, nq, topk,
-                       din, dout_w);
+    hipLaunchKernelGGL(peer_lookup_bwd_kernel, dim3(i2t_det() ? 1 : M), dim3(256), 0, (hipStream_t)stream, dout, (const bf16_t*)inp_proj,
+                       (const bf16_t*)emb_in, (const bf16_t*)emb_out, sv_unit, sv_lr, sv_score, sv_dot, dscores, (bf16_t*)dinp_proj, g_emb_in, g_emb_out,
+                       nhead, nq, topk, din, dout_w, M);
     I2T_CHECK_LAUNCH("i2t_peer_lookup_bwd");
     return I2T_OK;
 }
@@ -470,8 +477,8 @@ extern "C" int i2t_lsh_embed_fwd(void* stream, const float* z, const float* tabl
 extern "C" int i2t_lsh_embed_bwd(void* stream, const float* dy, const int* rows, float* g_tables, long slot_stride, const long* tab_off, int B,
                                  int n_cls, int nK, int n_proj, int dout) {
     I2T_REQUIRE(dy && rows && g_tables && tab_off && B > 0 && n_cls > 0 && nK > 0 && n_proj > 0, "i2t_lsh_embed_bwd: bad args");
-    hipLaunchKernelGGL(lsh_embed_bwd_kernel, dim3(B * n_cls), dim3(256), 0, (hipStream_t)stream, dy, rows, g_tables, slot_stride, tab_off, n_cls,
-                       nK, n_proj, dout);
+    hipLaunchKernelGGL(lsh_embed_bwd_kernel, dim3(i2t_det() ? 1 : B * n_cls), dim3(256), 0, (hipStream_t)stream, dy, rows, g_tables, slot_stride,
+                       tab_off, n_cls, nK, n_proj, dout, B * n_cls);
     I2T_CHECK_LAUNCH("i2t_lsh_embed_bwd");
     return I2T_OK;
 }

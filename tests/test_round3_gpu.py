@@ -208,7 +208,7 @@ def _two_backward_passes(wrapper, images, labels):
     return out
 
 
-@pytest.mark.parametrize('which', ['tiny', 'nano224', 'gpt2_lora'])
+@pytest.mark.parametrize('which', ['tiny', 'nano224', 'gpt2_lora', 'vit_peer', 'vit_lsh'])
 def test_deterministic_mode_makes_two_backward_passes_bit_equal(which, tmp_path, monkeypatch):
     """VERDICT r2 weak #2 / ADVICE r2: two backward passes of one step usually agree to 1e-7 but sometimes differ by 1e-3 at the bottom
     of a tower; the explanation given was fp32 atomics (order-dependent last bits) amplified by every bf16 re-quantisation of the
@@ -233,6 +233,15 @@ def test_deterministic_mode_makes_two_backward_passes_bit_equal(which, tmp_path,
                                         prepare_for_kbit_training=False, lora_spec=lora)
         cfg = tiny_config(dec_d=256, dec_heads=4).model_copy(update=dict(decoder_config=dcfg, use_cross_attn=True, use_soft_prompting=True))
         V, img, cap, B = 1000, 32, 24, 16
+    elif which.startswith('vit_'):          # PretrainedViT heads whose table gradients are scattered with atomics (csrc/vit.hip: PEER experts, LSH tables)
+        from image2text_amd.models.encoder import PretrainedViT
+        from test_vit_gpu import vit_model_config
+        monkeypatch.setenv('I2T_VIT_B16_CHECKPOINT', 'random')
+        monkeypatch.setattr(PretrainedViT, 'backbone_spec', dict(image_size=32, patch_size=16, num_layers=2, num_heads=12, hidden_dim=768, mlp_dim=256))
+        head = dict(peer_config=dict(num_units_sqrt=16, topk=4, nhead=2, query_dim=32), n_embd_out_vit=64) if which == 'vit_peer' else \
+            dict(lsh_config=dict(num_bins=(4, 8, 20), num_proj=32, learnable=False), n_embd_out_vit=128)
+        cfg, img, cap, B = vit_model_config(dict(n_cls=8, refine_base_model=False, **head)), 32, 16, 8
+        V = cfg.decoder_config.vocab_size
     elif which == 'nano224':
         cfg, img, cap, B = nano224_config(dropout=0.1), 224, 64, 8
         V = cfg.decoder_config.vocab_size
