@@ -71,7 +71,15 @@ class LlamaBlocks:
     # that touch it -- y = x W^T and dx = dy W -- run on the block-scaled e4m3 MFMA; W is quantised once per parameter version in
     # both orientations (per-output-row scales for the forward, per-input-row scales for the backward), activations per call
     def _fp8_on(self, names) -> bool:
-        return self.fp8 and all(not self.arena.trainable(n) for n in ([names] if isinstance(names, str) else names))
+        if not self.fp8:
+            return False
+        names = [names] if isinstance(names, str) else names
+        if all(not self.arena.trainable(n) for n in names):
+            return True
+        # a weight that trains (again): the optimizer writes it through the arena without moving its version counter, so an e4m3 image
+        # kept from an earlier frozen phase would be stale if the weight is frozen once more
+        self._sub_cache.pop(('fp8w', tuple(names), id(self.arena)), None)
+        return False
 
     def _fp8_weight(self, names, W):
         key = ('fp8w', tuple([names] if isinstance(names, str) else names), id(self.arena))
