@@ -529,6 +529,195 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnPtr Q, AttnPtr K,
     }
 }
 
+// ================================================================================================== single-tile backward
+// Tq <= 64 and Tk <= 64 (the decoder: causal self-attention over a caption, cross-attention onto 64 memory rows): ONE workgroup per
+// (sequence, head) produces dK, dV AND dQ.  The tiled pair above evaluates every (query, key) pair twice -- S, dP, the exponential and
+// the dropout hash once in the dQ kernel and once in the dK/dV kernel -- and hands delta over through HBM.  Here the dK/dV
+// orientation's pass is the only one: its dS tile goes to LDS as bf16 [key][query] (one ds_write_b64 per lane and 16 x 16 block), and
+// after ONE barrier wave w contracts dQ^T[d][its 16 queries] = K^T[d][key] . dS^T[key][q] over the keys, both operands as transposed
+// LDS reads in the same permuted key order.  16 x 16 blocks wholly above the causal diagonal are skipped (6 of 16 at T = 64).
+template <bool DROP, bool EVEN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void attn_bwd1_kernel(AttnPtr Q, AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse,
+                                                        bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, bf16_t* __restrict__ dK, long dk_bs,
+                                                        int dk_rs, bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int TqMax, int TkMax,
+                                                        int causal, unsigned drop_key, unsigned drop_thr, float drop_scale, VarLen vl,
+                                                        unsigned od_key, unsigned od_thr, float od_scale) {
+    // two tiles: Q and dO for the first pass; after it K takes Q's place and dS^T takes dO's (20.5 KiB: 7 workgroups per CU by LDS --
+    // with four tiles resident only 3 fit, and a workgroup's life is a chain of dependent memory round trips that needs company)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * 64 * 4];
+    unsigned char* q_lds = smem;
+    unsigned char* do_lds = smem + TILE_BYTES;
+    unsigned char* k_lds = smem;
+    unsigned char* ds_lds = smem + TILE_BYTES;
+    float* lse_lds = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    float* dl_lds = lse_lds + 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    int tile_, h, b;
+    attn_block_coords(1, H, vl.nseq, tile_, h, b);
+    int Tq = TqMax, Tk = TkMax;
+    size_t qoff = (size_t)b * Q.bs, koff = (size_t)b * K.bs, voff = (size_t)b * V.bs, dooff = (size_t)b * dO.bs, ooff = (size_t)b * O.bs;
+    size_t dqoff = (size_t)b * dq_bs, dkoff = (size_t)b * dk_bs, dvoff = (size_t)b * dv_bs;
+    size_t stat_base = ((size_t)b * H + h) * TqMax;
+    if (vl.cu_q) {
+        const int s0 = vl.cu_q[b];
+        Tq = vl.cu_q[b + 1] - s0;
+        qoff = (size_t)s0 * Q.rs; dooff = (size_t)s0 * dO.rs; ooff = (size_t)s0 * O.rs; dqoff = (size_t)s0 * dq_rs;
+        stat_base = (size_t)h * vl.total_q + s0;
+    }
+    if (vl.cu_k) {
+        const int s0 = vl.cu_k[b];
+        Tk = vl.cu_k[b + 1] - s0;
+        koff = (size_t)s0 * K.rs; voff = (size_t)s0 * V.rs; dkoff = (size_t)s0 * dk_rs; dvoff = (size_t)s0 * dv_rs;
+    }
+    if (Tq <= 0 || Tk <= 0) return;                  // workgroup-uniform
+    const bf16_t* qb = Q.p + qoff + h * 64;
+    const bf16_t* kb = K.p + koff + h * 64;
+    const bf16_t* vb = V.p + voff + h * 64;
+    const bf16_t* dob = dO.p + dooff + h * 64;
+    const bf16_t* ob = O.p + ooff + h * 64;
+    const int shift = Tk - Tq;
+    const int r0 = w * 16;                           // this wave's 16 keys (first pass) and 16 queries (second pass)
+    stage_tile(q_lds, qb, Q.rs, 0, Tq, tid);
+    stage_tile(do_lds, dob, dO.rs, 0, Tq, tid);
+    TileRegs kr;                                     // the whole K tile for the second pass: in flight during the first
+    tile_load(kr, kb, K.rs, 0, Tk, tid);
+    {   // delta[q] = sum_d dO[q][d] O[q][d] and lse for the wave's 16 query rows (zeros past Tq)
+        const bf16x8 df0 = global_row_frag(dob, dO.rs, r0, Tq, 0, lane), df1 = global_row_frag(dob, dO.rs, r0, Tq, 1, lane);
+        const bf16x8 of0 = global_row_frag(ob, O.rs, r0, Tq, 0, lane), of1 = global_row_frag(ob, O.rs, r0, Tq, 1, lane);
+        float sdl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sdl += (float)df0[e] * (float)of0[e] + (float)df1[e] * (float)of1[e];
+        sdl = quad_sum(sdl);
+        if (g == 0) {
+            dl_lds[r0 + li] = sdl;
+            lse_lds[r0 + li] = lse[stat_base + min(r0 + li, Tq - 1)] * LOG2E;
+        }
+    }
+    const int key = r0 + li;                         // this lane's key column
+    const bf16x8 kf0 = global_row_frag(kb, K.rs, r0, Tk, 0, lane), kf1 = global_row_frag(kb, K.rs, r0, Tk, 1, lane);
+    const bf16x8 vf0 = global_row_frag(vb, V.rs, r0, Tk, 0, lane), vf1 = global_row_frag(vb, V.rs, r0, Tk, 1, lane);
+    f32x4 adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) adk[dt] = adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dscale = DROP ? drop_scale : 1.f;
+    __syncthreads();
+    {
+        const bool wave_on = r0 < Tk;
+        const int nqj = min(4, (Tq - 1) / 16 + 1);
+        const bool full = 63 < Tq && r0 + 15 < Tk && (!causal || r0 + 15 <= shift);
+        f32x4 p[4], ds[4];
+        u32x2 dsp[4];
+#pragma unroll
+        for (int qj = 0; qj < 4; ++qj) {
+            p[qj] = ds[qj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (block past the last query, or wholly above the causal diagonal: its lowest key is invisible to its highest query)
+            if (wave_on && qj < nqj && !(causal && r0 > qj * 16 + 15 + shift)) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(q_lds, qj * 16, 0, lane), kf0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(q_lds, qj * 16, 1, lane), kf1, a, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(do_lds, qj * 16, 0, lane), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_row_frag(do_lds, qj * 16, 1, lane), vf1, dp, 0, 0, 0);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_lds + qj * 16 + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_lds + qj * 16 + 4 * g);
+                bool keep4[4] = {true, true, true, true};
+                if constexpr (DROP) {      // (as in attn_bwd_dkv_kernel: one hash per lane, its words shared inside the lane quad)
+                    const unsigned rb = ((unsigned)b * H + h) * TqMax;
+                    if constexpr (EVEN) {
+                        const int j = li & 3;
+                        const int qm = min(qj * 16 + 4 * g + j, Tq - 1);
+                        const int mine = (int)dropout_hash(drop_key, ((rb + qm) * (unsigned)TkMax + (unsigned)key) >> 2);
+                        const unsigned sh = 8u * (unsigned)j;
+                        keep4[0] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[1] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[2] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                        keep4[3] = (((unsigned)__builtin_amdgcn_mov_dpp(mine, 0xff, 0xf, 0xf, true) >> sh) & 0xffu) >= drop_thr;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            keep4[r] = dropout_keep(drop_key, (rb + min(qj * 16 + 4 * g + r, Tq - 1)) * (unsigned)TkMax + key, drop_thr);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qj * 16 + 4 * g + r;
+                    float pv = __builtin_amdgcn_exp2f(a[r] * (SCALE * LOG2E) - l4[r]);
+                    if (!full && !((q < Tq) && (key < Tk) && (!causal || key <= q + shift))) pv = 0.f;
+                    float pd = pv, dpr = dp[r];
+                    if constexpr (DROP) {
+                        pd = keep4[r] ? pv : 0.f;
+                        dpr = keep4[r] ? dpr : 0.f;
+                    }
+                    p[qj][r] = pd;
+                    ds[qj][r] = pv * fmaf(dpr, dscale, -d4[r]);
+                }
+            }
+            dsp[qj] = u32x2{pack_bf16x2(ds[qj][0], ds[qj][1]), pack_bf16x2(ds[qj][2], ds[qj][3])};
+        }
+        if (wave_on) {
+            const bf16x8 p0 = pack_frag(p[0], p[1]), p1 = pack_frag(p[2], p[3]);
+            const bf16x8 s0 = pack_frag(ds[0], ds[1]), s1 = pack_frag(ds[2], ds[3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 0, dt * 16, lane), p0, adv[dt], 0, 0, 0);
+                adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 0, dt * 16, lane), s0, adk[dt], 0, 0, 0);
+                if (nqj > 2) {
+                    adv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(do_lds, 1, dt * 16, lane), p1, adv[dt], 0, 0, 0);
+                    adk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(q_lds, 1, dt * 16, lane), s1, adk[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                             // every wave is done with Q and dO
+        tile_store(kr, k_lds, tid);
+#pragma unroll
+        for (int qj = 0; qj < 4; ++qj)               // dS^T[key][query]: this lane's 4 consecutive queries of its key row
+            *reinterpret_cast<u32x2*>(ds_lds + (r0 + li) * TS + (qj * 16 + 4 * g) * 2) = dsp[qj];
+    }
+    __syncthreads();
+    if (r0 < Tq) {      // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for the wave's 16 queries
+        f32x4 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int last_key = causal ? min(Tk - 1, r0 + 15 + shift) : Tk - 1;      // (keys beyond it hold zeros in dS anyway)
+        const bf16x8 b0 = tile_tr_frag(ds_lds, 0, r0, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(k_lds, 0, dt * 16, lane), b0, acc[dt], 0, 0, 0);
+        if (last_key >= 32) {
+            const bf16x8 b1 = tile_tr_frag(ds_lds, 1, r0, lane);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr_frag(k_lds, 1, dt * 16, lane), b1, acc[dt], 0, 0, 0);
+        }
+        const int qrow = r0 + li;
+        if (qrow < Tq) {
+            bf16_t* op = dQ + dqoff + (size_t)qrow * dq_rs + h * 64;
+            const unsigned grow = (unsigned)((vl.cu_q ? vl.cu_q[b] : b * TqMax) + qrow);
+            const float f = (od_thr ? (dropout_keep(od_key, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                acc[dt] *= f;
+                const u32x2 pk = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+                *reinterpret_cast<u32x2*>(op + dt * 16 + 4 * g) = pk;
+            }
+        }
+    }
+    if (key < Tk) {
+        bf16_t* pk_ = dK + dkoff + (size_t)key * dk_rs + h * 64;
+        bf16_t* pv_ = dV + dvoff + (size_t)key * dv_rs + h * 64;
+        const unsigned grow = (unsigned)((vl.cu_k ? vl.cu_k[b] : b * TkMax) + key);
+        const float fk = (od_thr ? (dropout_keep(od_key + 1u, grow, od_thr) ? od_scale : 0.f) : 1.f) * SCALE;
+        const float fv = (od_thr ? (dropout_keep(od_key + 2u, grow, od_thr) ? od_scale : 0.f) : 1.f) * dscale;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            adk[dt] *= fk;
+            adv[dt] *= fv;
+            const u32x2 a = {pack_bf16x2(adk[dt][0], adk[dt][1]), pack_bf16x2(adk[dt][2], adk[dt][3])};
+            const u32x2 c = {pack_bf16x2(adv[dt][0], adv[dt][1]), pack_bf16x2(adv[dt][2], adv[dt][3])};
+            *reinterpret_cast<u32x2*>(pk_ + dt * 16 + 4 * g) = a;
+            *reinterpret_cast<u32x2*>(pv_ + dt * 16 + 4 * g) = c;
+        }
+    }
+}
+
 // ================================================================================================== v2: resident operands
 // The kernels above pay per workgroup ITERATION (two barriers + a staged tile each): at T = 260 a (sequence, head) pair costs 5 x 5
 // of them for 3 % more work than T = 256, every wave re-reads the whole K and V tile from LDS for only 16 query rows (the LDS
@@ -1387,6 +1576,16 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                                 out_drop_key, out_drop_thr, out_drop_scale);
         I2T_CHECK_LAUNCH("i2t_attention_bwd(v2)");
         return I2T_OK;
+    }
+    {   // one tile of queries and keys (the decoder's attentions): the fused single-pass kernel (I2T_ATTN_BWD1=0: the tiled pair, for A/B runs)
+        const char* e1 = getenv("I2T_ATTN_BWD1");
+        if (Tq <= 64 && Tk <= 64 && !(e1 && e1[0] == '0')) {
+            ATTN_DISPATCH(attn_bwd1_kernel, drop_thr, Tk, dim3(H * B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs,
+                          (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl,
+                          out_drop_key, out_drop_thr, out_drop_scale);
+            I2T_CHECK_LAUNCH("i2t_attention_bwd(1)");
+            return I2T_OK;
+        }
     }
     ATTN_DISPATCH(attn_bwd_dq_kernel, drop_thr, Tk, dim3(((Tq + 63) / 64) * H * B), dim3(256), 0, s, Q, K, V, DO, Ow, lse, delta_ws,
                   (bf16_t*)dq, dq_bs, dq_rs, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, vl, out_drop_key, out_drop_thr,
