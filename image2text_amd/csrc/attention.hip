@@ -570,14 +570,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         Tk = vl.cu_k[b + 1] - s0;
         koff = (size_t)s0 * K.rs; voff = (size_t)s0 * V.rs; dkoff = (size_t)s0 * dk_rs; dvoff = (size_t)s0 * dv_rs;
     }
-    if (Tq <= 0 || Tk <= 0) return;                  // workgroup-uniform
+    if (Tk <= 0) return;                             // workgroup-uniform
+    const int r0 = w * 16;                           // this wave's 16 keys (first pass) and 16 queries (second pass)
+    if (Tq <= 0) {                                   // a packed sequence without a live query row (a caption with no label): its keys get zeros
+        if (r0 + li < Tk) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<u32x2*>(dK + dkoff + (size_t)(r0 + li) * dk_rs + h * 64 + dt * 16 + 4 * g) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2*>(dV + dvoff + (size_t)(r0 + li) * dv_rs + h * 64 + dt * 16 + 4 * g) = u32x2{0u, 0u};
+            }
+        }
+        return;
+    }
     const bf16_t* qb = Q.p + qoff + h * 64;
     const bf16_t* kb = K.p + koff + h * 64;
     const bf16_t* vb = V.p + voff + h * 64;
     const bf16_t* dob = dO.p + dooff + h * 64;
     const bf16_t* ob = O.p + ooff + h * 64;
     const int shift = Tk - Tq;
-    const int r0 = w * 16;                           // this wave's 16 keys (first pass) and 16 queries (second pass)
     stage_tile(q_lds, qb, Q.rs, 0, Tq, tid);
     stage_tile(do_lds, dob, dO.rs, 0, Tq, tid);
     TileRegs kr;                                     // the whole K tile for the second pass: in flight during the first

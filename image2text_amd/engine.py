@@ -51,6 +51,13 @@ GELU_KEEPS_DERIVATIVE = os.environ.get('I2T_GELU_DOUT', '1') != '0'
 NORMALISER_FOLDED = os.environ.get('I2T_FOLD_NORMALISER', '1') != '0'
 
 
+# leading dimension of every logits buffer: the vocabulary rounded up to this many columns.  64 bf16 columns = one 128-byte line, so a
+# row of 50257 logits starts on a line boundary (at 8 columns -- 16-byte alignment, the ABI's minimum -- every 256-column tile segment of
+# a row straddled two lines: the lm_head GEMM wrote 1.22x its bytes and the two gradient GEMMs fetched the logits' gradient 1.35x,
+# profiles/r04_gemm_traffic_by_shape.txt).  I2T_VOCAB_PAD=8 restores the old layout for A/B runs.
+VOCAB_PAD = int(os.environ.get('I2T_VOCAB_PAD', '64'))
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -309,7 +316,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         if ls is not None:
             # Llama-2 / Qwen2 blocks (engine_llama.LlamaBlocks): RMSNorm, rotary embedding, grouped K/V heads, SwiGLU; no learned
             # positions, no dropout, no cross-attention, no gradient normaliser; the parameters keep transformers' names
-            self.dec = SimpleNamespace(d=ls.d, H=ls.H, L=ls.L, V=ls.V, Vp=_round_up(ls.V, 8), block=ls.block, causal=True, ff=ls.ff,
+            self.dec = SimpleNamespace(d=ls.d, H=ls.H, L=ls.L, V=ls.V, Vp=_round_up(ls.V, VOCAB_PAD), block=ls.block, causal=True, ff=ls.ff,
                                        dropout=0.0, attn_dropout=0.0, fam=None, grad_norm=False, advpos=False, llama=ls,
                                        prefixed=bool(self.cfg.use_soft_prompting))
             self.dcfg = dcfg = SimpleNamespace(skip_alternate_cross_attn=False, advanced_pos_emb_gate_sizes=None, n_layer=ls.L,
@@ -320,7 +327,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         else:
             dac = dcfg.transformer_config.attn_config
             self.dec = SimpleNamespace(d=dac.n_embd, H=dac.n_head, L=dcfg.n_layer, V=dcfg.vocab_size,
-                                       Vp=_round_up(dcfg.vocab_size, 8), block=dcfg.block_size,
+                                       Vp=_round_up(dcfg.vocab_size, VOCAB_PAD), block=dcfg.block_size,
                                        causal=dcfg.transformer_config.is_causal,
                                        ff=int(_ff_mult(dcfg.transformer_config.rotator_config) * dac.n_embd),
                                        dropout=dac.dropout, attn_dropout=dac.attn_dropout, llama=None)

@@ -977,7 +977,8 @@ def test_attention_packed_varlen(ops, monkeypatch):
     mem = rnd(B, 24, 2 * d, dtype=BF16, seed=182)
     oc, lsec = torch.zeros(total, d, dtype=BF16, device=dev()), torch.zeros(H * total, device=dev())
     ops.attention_fwd(qkv[:, :d], mem[..., :d], mem[..., d:], oc, lsec, B, H, Tmax, 24, False, cu_q=cu, total_q=total)
-    dqc, dmem = torch.zeros(total, d, dtype=BF16, device=dev()), torch.zeros(B, 24, 2 * d, dtype=BF16, device=dev())
+    # (dmem starts as garbage: a sequence without query rows must still have zeros WRITTEN to its memory rows' gradient)
+    dqc, dmem = torch.zeros(total, d, dtype=BF16, device=dev()), torch.full((B, 24, 2 * d), 3.0, dtype=BF16, device=dev())
     ops.attention_bwd(qkv[:, :d], mem[..., :d], mem[..., d:], oc, do, lsec, torch.empty(H * total, device=dev()), dqc,
                       dmem[..., :d], dmem[..., d:], B, H, Tmax, 24, False, cu_q=cu, total_q=total)
     for b, n in enumerate(lens):
