@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void attn_bwd3_kernel(AttnPtr Q, AttnP
                                                            bf16_t* __restrict__ dQ, long dq_bs, int dq_rs, bf16_t* __restrict__ dK, long dk_bs,
                                                            int dk_rs, bf16_t* __restrict__ dV, long dv_bs, int dv_rs, int H, int Tq, int Tk,
                                                            unsigned drop_key, unsigned drop_thr, float drop_scale, unsigned od_key,
-                                                           unsigned od_thr, float od_scale) {
+                                                           unsigned od_thr, float od_scale, int od_q_seq) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * V2_MAXROWS * V2_RB + 2 * V2_MAXROWS * 4];
     unsigned char* q_lds = smem;
     unsigned char* do_lds = smem + V2_MAXROWS * V2_RB;
@@ -1466,7 +1466,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void attn_bwd3_kernel(AttnPtr Q, AttnP
     }
     __syncthreads();
     const float dscale = DROP ? drop_scale : 1.f;
-    const unsigned drow_base = ((unsigned)b * H + h) * (unsigned)Tq * (unsigned)Tk, grow_q = (unsigned)b * Tq, grow_k = (unsigned)b * Tk;
+    const unsigned drow_base = ((unsigned)b * H + h) * (unsigned)Tq * (unsigned)Tk, grow_q = (unsigned)b * (od_q_seq ? od_q_seq : Tq),      // (od_q_seq: the queries are the first Tq rows of od_q_seq-row sequences)
+                    grow_k = (unsigned)b * Tk;
     bf16_t* dqb = dQ + (size_t)b * dq_bs + h * 64;
     bf16_t* dkb = dK + (size_t)b * dk_bs + h * 64;
     bf16_t* dvb = dV + (size_t)b * dv_bs + h * 64;
@@ -1544,6 +1545,19 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
                                  int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
                                  const int* cu_q, const int* cu_k, int total_q, unsigned out_drop_key, unsigned out_drop_thr,
                                  float out_drop_scale) {
+    return i2t_attention_bwd_ex(stream, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, d_o, do_bs, do_rs, lse, delta_ws, dq, dq_bs, dq_rs,
+                                dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, B, H, Tq, Tk, causal, drop_key, drop_thr, drop_scale, cu_q, cu_k, total_q,
+                                out_drop_key, out_drop_thr, out_drop_scale, 0);
+}
+
+extern "C" int i2t_attention_bwd_ex(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                                    const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
+                                    const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws, void* dq,
+                                    long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs, void* dv, long dv_bs, int dv_rs,
+                                    int B, int H, int Tq, int Tk, int causal, unsigned drop_key, unsigned drop_thr, float drop_scale,
+                                    const int* cu_q, const int* cu_k, int total_q, unsigned out_drop_key, unsigned out_drop_thr,
+                                    float out_drop_scale, int out_drop_q_seq) {
+    if (out_drop_q_seq == Tq || !out_drop_thr) out_drop_q_seq = 0;
     I2T_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && lse && delta_ws, "i2t_attention_bwd: bad args");
     I2T_REQUIRE(!cu_q || total_q > 0, "i2t_attention_bwd: packed queries need total_q");
     I2T_REQUIRE(drop_thr == 0 || (double)B * H * Tq * Tk < 4294967296.0, "i2t_attention_bwd: dropout index overflows 32 bits");
@@ -1561,6 +1575,8 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
     // I2T_ATTN_BWD = 3 (default): the one-pass kernel | 2: the two-phase one (attn_bwd2) | 0: the tiled pair; I2T_ATTN_BWD2=0: as 0
     const char* be = getenv("I2T_ATTN_BWD");
     const int bmode = (getenv("I2T_ATTN_BWD2") && getenv("I2T_ATTN_BWD2")[0] == '0') ? 0 : (be ? atoi(be) : 3);
+    I2T_REQUIRE(!out_drop_q_seq || (bmode == 3 && v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS),
+                "i2t_attention_bwd_ex: out_drop_q_seq=%d is offered by the one-pass resident kernel only (dense, Tk <= %d)", out_drop_q_seq, V2_MAXROWS);
     if (bmode == 3 && v2_applies(Tq, Tk, causal, cu_q, cu_k, drop_thr) && Tq <= V2_MAXROWS) {
         // 9 waves whenever 8 would leave a wave with a third key block (I2T_ATTN_BWD3_WAVES = 8 | 9 forces one: A/B runs)
         static const char* we = getenv("I2T_ATTN_BWD3_WAVES");
@@ -1570,7 +1586,7 @@ extern "C" int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_r
         (void)nkb;
 #define B3_LAUNCH(D_, W_) hipLaunchKernelGGL((attn_bwd3_kernel<D_, W_>), dim3(H * B), dim3(64 * W_), 0, s, Q, K, V, DO, Ow, lse, (bf16_t*)dq, dq_bs, dq_rs, \
                                              (bf16_t*)dk, dk_bs, dk_rs, (bf16_t*)dv, dv_bs, dv_rs, H, Tq, Tk, drop_key, drop_thr, drop_scale,          \
-                                             out_drop_key, out_drop_thr, out_drop_scale)
+                                             out_drop_key, out_drop_thr, out_drop_scale, out_drop_q_seq)
         if (!drop_thr) { if (nine) B3_LAUNCH(false, 9); else B3_LAUNCH(false, 8); }
         else { if (nine) B3_LAUNCH(true, 9); else B3_LAUNCH(true, 8); }
 #undef B3_LAUNCH

@@ -84,11 +84,19 @@ static void launch_sum_over_batch(hipStream_t s, const float* x, long x_bs, floa
 }
 
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ src, float* __restrict__ y, long y_bs,
-                                                         int rows, int d) {
+                                                         int rows, int d, unsigned drop_key, unsigned drop_thr, float drop_scale) {
     const int d4 = d >> 2;
     const int b = blockIdx.y;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * d4; idx += (long)gridDim.x * 256)
-        reinterpret_cast<f32x4*>(y + (size_t)b * y_bs)[idx] = reinterpret_cast<const f32x4*>(src)[idx];
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * d4; idx += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(src)[idx];
+        if (drop_thr) {      // elementwise dropout of the tensor y heads a slab of: index = element offset in it
+            bool keep[4];
+            dropout_keep4(drop_key, (unsigned)((size_t)b * y_bs + 4 * (size_t)idx), drop_thr, keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * drop_scale : 0.f;
+        }
+        reinterpret_cast<f32x4*>(y + (size_t)b * y_bs)[idx] = v;
+    }
 }
 
 template <bool Y_BF16>
@@ -636,9 +644,15 @@ extern "C" int i2t_sum_over_batch(void* stream, const float* x, long x_batch_str
 }
 
 extern "C" int i2t_bcast_rows(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d) {
+    return i2t_bcast_rows_drop(stream, src, y, y_batch_stride, B, rows, d, 0u, 0u, 1.0f);
+}
+
+extern "C" int i2t_bcast_rows_drop(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d, unsigned drop_key,
+                                   unsigned drop_thr, float drop_scale) {
     I2T_REQUIRE(src && y && B > 0 && rows > 0 && d % 4 == 0 && y_batch_stride % 4 == 0, "i2t_bcast_rows: bad args");
+    I2T_REQUIRE(!drop_thr || (double)B * y_batch_stride < 4294967296.0, "i2t_bcast_rows_drop: dropout needs B * y_batch_stride < 2^32");
     hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for((long)rows * (d >> 2), 64), B), dim3(256), 0, (hipStream_t)stream, src,
-                       y, y_batch_stride, rows, d);
+                       y, y_batch_stride, rows, d, drop_key, drop_thr, drop_scale);
     I2T_CHECK_LAUNCH("i2t_bcast_rows");
     return I2T_OK;
 }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      int dx_accumulate, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int d, unsigned drop_key, unsigned drop_thr, float drop_scale,
-                                                     float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq, int blk0) {
+                                                     float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq, int blk0,
+                                                     unsigned dxm_key, unsigned dxm_thr, float dxm_scale) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     // dx_pre_sumsq: the dx this launch accumulates onto is still UN-normalised; its normaliser 1 / (||dx|| + 1e-6) -- the
     // gradient normaliser of the block boundary above, whose fp32 rescale pass this replaces -- is applied while adding
@@ -127,8 +128,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                 if (dx_accumulate) o += *dxp * pre;
-                *dxp = o;
                 ssq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+                if (dxm_thr) {     // the tower's lowest block: the embedding dropout's mask on the f32 gradient it hands to the embedding
+                    bool keepm[4];           // backward (idx = row * d + column, as i2t_dropout_apply mode 1); sum of squares and bf16 copy: unmasked
+                    dropout_keep4(dxm_key, (unsigned)row * (unsigned)d + 4u * (unsigned)c, dxm_thr, keepm);
+                    f32x4 om;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) om[e] = keepm[e] ? o[e] * dxm_scale : 0.f;
+                    *dxp = om;
+                } else {
+                    *dxp = o;
+                }
                 if (dx_bf16) {
                     if (drop_thr) {    // the bf16 copy feeds a dropped-out branch: its forward mask, idx = row * d + column
                         bool keep[4];
@@ -367,7 +377,7 @@ __device__ __forceinline__ void lnnd_combine(const float* st, int n, float& mean
 __global__ __launch_bounds__(256) void lnnd_apply_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ y, long y_bs, float* __restrict__ stats,
-                                                         int n) {
+                                                         int n, unsigned drop_key, unsigned drop_thr, float drop_scale, long drop_base) {
     const int b = blockIdx.x;
     float mean, rstd;
     lnnd_combine(stats + (size_t)b * STATS_STRIDE, n, mean, rstd);
@@ -382,6 +392,12 @@ __global__ __launch_bounds__(256) void lnnd_apply_kernel(const float* __restrict
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+        if (drop_thr) {      // elementwise dropout of the tensor y is a slab of (the embedding dropout, encoder.py:170): index = element offset in it
+            bool keep[4];
+            dropout_keep4(drop_key, (unsigned)((size_t)b * y_bs + drop_base + 4 * (size_t)c), drop_thr, keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * drop_scale : 0.f;
+        }
         yb[c] = o;
     }
     __syncthreads();   // every thread of block (b,0) has read the partials before they are overwritten
@@ -510,6 +526,16 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
                                  const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
                                  float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
                                  float drop_scale, float* sumsq_out, const float* dx_pre_sumsq) {
+    return i2t_layernorm_bwd_ex(stream, dy, dy_is_f32, x, gamma, mean, rstd, dx, dx_accumulate, dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr,
+                                drop_scale, sumsq_out, dx_pre_sumsq, 0u, 0u, 1.0f);
+}
+
+extern "C" int i2t_layernorm_bwd_ex(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
+                                    const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
+                                    float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
+                                    float drop_scale, float* sumsq_out, const float* dx_pre_sumsq, unsigned dx_mask_key,
+                                    unsigned dx_mask_thr, float dx_mask_scale) {
+    I2T_REQUIRE(!dx_mask_thr || ((long)M * d < (1L << 32) && d <= MAXC * 256), "i2t_layernorm_bwd_ex: the f32 mask needs M*d < 2^32 and d <= %d", MAXC * 256);
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
     I2T_REQUIRE(!dx_pre_sumsq || dx_accumulate, "i2t_layernorm_bwd: dx_pre_sumsq only applies when accumulating onto dx");
     I2T_REQUIRE(drop_thr == 0 || (dx_bf16 && (long)M * d < (1L << 32)), "i2t_layernorm_bwd: dropout needs dx_bf16 and M*d < 2^32");
@@ -535,10 +561,12 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
     for (int b0 = 0; b0 < grid; b0 += per) {
         if (dy_is_f32)
             hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0);
+                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0, dx_mask_key, dx_mask_thr,
+                               dx_mask_scale);
         else
             hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
-                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0);
+                               (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0, dx_mask_key, dx_mask_thr,
+                               dx_mask_scale);
     }
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;
@@ -547,12 +575,21 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
 extern "C" int i2t_layernorm_nd_fwd(void* stream, const float* x, const float* add, const float* gamma,
                                     const float* beta, float* y, long y_batch_stride, float* stats, int B, int rows,
                                     int d) {
+    return i2t_layernorm_nd_fwd_drop(stream, x, add, gamma, beta, y, y_batch_stride, stats, B, rows, d, 0u, 0u, 1.0f, 0);
+}
+
+extern "C" int i2t_layernorm_nd_fwd_drop(void* stream, const float* x, const float* add, const float* gamma,
+                                         const float* beta, float* y, long y_batch_stride, float* stats, int B, int rows,
+                                         int d, unsigned drop_key, unsigned drop_thr, float drop_scale, long drop_base) {
     I2T_REQUIRE(x && gamma && y && stats && B > 0, "i2t_layernorm_nd_fwd: bad args");
     const long n = (long)rows * d;
     I2T_REQUIRE(n % 4 == 0 && n < (1L << 30) && y_batch_stride % 4 == 0, "i2t_layernorm_nd_fwd: slab size %ld unsupported", n);
+    I2T_REQUIRE(!drop_thr || (drop_base >= 0 && drop_base % 4 == 0 && (double)B * y_batch_stride < 4294967296.0),
+                "i2t_layernorm_nd_fwd_drop: dropout needs drop_base %% 4 == 0 and B * y_batch_stride < 2^32");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lnnd_partial_kernel, dim3(B, NSPLIT), dim3(256), 0, s, x, add, stats, (int)n);
-    hipLaunchKernelGGL(lnnd_apply_kernel, dim3(B, NSPLIT), dim3(256), 0, s, x, add, gamma, beta, y, y_batch_stride, stats, (int)n);
+    hipLaunchKernelGGL(lnnd_apply_kernel, dim3(B, NSPLIT), dim3(256), 0, s, x, add, gamma, beta, y, y_batch_stride, stats, (int)n,
+                       drop_key, drop_thr, drop_scale, drop_base);
     I2T_CHECK_LAUNCH("i2t_layernorm_nd_fwd");
     return I2T_OK;
 }

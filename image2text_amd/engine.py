@@ -49,6 +49,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 GELU_KEEPS_DERIVATIVE = os.environ.get('I2T_GELU_DOUT', '1') != '0'
 # I2T_FOLD_NORMALISER=0: every block runs its own grad_normalize pass over the incoming gradient (A/B runs)
 NORMALISER_FOLDED = os.environ.get('I2T_FOLD_NORMALISER', '1') != '0'
+# the embedding dropouts applied by the producers of the embedded rows (forward) and by the lowest block's last LayerNorm backward
+# (backward) instead of by passes of their own (I2T_EMB_DROP_FUSED=0: the passes, for A/B runs)
+EMB_DROP_FUSED = os.environ.get('I2T_EMB_DROP_FUSED', '1') not in ('', '0')
 
 
 # leading dimension of every logits buffer: the vocabulary rounded up to this many columns.  64 bf16 columns = one 128-byte line, so a
@@ -565,7 +568,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         return dx_out
 
     def block_bwd(self, pfx: str, sv, dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16: bool, vl=None, sumsq_out=None,
-                  dx_pre=None, dxb_sumsq=None, last_bf16_drop=None):
+                  dx_pre=None, dxb_sumsq=None, last_bf16_drop=None, dx_mask=None):
         """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the block output; dxb already normalised, dx too unless dx_pre (1 float:
         sum(dx^2)) is given -- then the first LayerNorm backward that accumulates onto dx applies 1 / (||dx|| + 1e-6) on the fly
         (the normaliser's fp32 rescale pass is not run).  On return dx (and dxb when emit_last_bf16) hold the gradient w.r.t. the
@@ -652,7 +655,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         # (emit_last_bf16 with last_bf16_drop: the bf16 copy is the NEXT block's incoming gradient, already masked for ITS mlp.c_proj)
         ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx, a.Gt(f'{pfx}.ln_1.weight'),
                           a.Gt(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, dx_bf16=dxb if emit_last_bf16 else None,
-                          bf16_drop=last_bf16_drop if emit_last_bf16 else None, sumsq_out=sumsq_out)
+                          bf16_drop=last_bf16_drop if emit_last_bf16 else None, sumsq_out=sumsq_out,
+                          dx_mask=dx_mask)      # (the tower's lowest block: the embedding dropout's backward, applied to the dx it stores)
 
     # ---- the encoder's LAST block, CLS rows only.  The encoder output is ln_f of the first ncls rows (encoder.py:172-173); the
     # patch rows of the last block feed nothing, forward or backward.  K and V still come from every row; the queries, the
@@ -704,12 +708,16 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         dao = self._empty(B, ncls, d, dtype=BF16)
         self._linear_bwd(dxb, Mc, d, d, sv.ao.view(Mc, d), f'{pfx}.attn.c_proj.weight', bias(f'{pfx}.attn.c_proj.bias'),
                          dx_out=dao.view(Mc, d))
+        # the forward GEMM's per-token q|k|v multipliers: applied by the attention backward on its way out where the resident-operand
+        # kernel runs (it knows that the queries are the first ncls rows of T-row sequences), by a pass over dqkv elsewhere
+        fused_mask = dr['qkv'] is not None and ops.attention_bwd_takes_q_seq(ncls, T, dr['sdpa'])
         dqkv = self._empty(B, T, 3 * d, dtype=BF16)
         dqkv[:, ncls:, :d].zero_()                                              # dq of the patch rows: zero (no query ran there); the rest is written below
         q3 = sv.qkv.view(B, T, 3 * d)
         ops.attention_bwd(q3[:, :ncls, :d], q3[..., d:2 * d], q3[..., 2 * d:], sv.ao, dao, sv.lse, self._empty(H * Mc),
-                          dqkv[:, :ncls, :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, ncls, T, False, drop=dr['sdpa'])
-        if dr['qkv'] is not None:
+                          dqkv[:, :ncls, :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], B, H, ncls, T, False, drop=dr['sdpa'],
+                          out_drop=dr['qkv'] if fused_mask else None, out_drop_q_seq=T)
+        if dr['qkv'] is not None and not fused_mask:
             ops.dropout_apply(dqkv, M, 3 * d, dr['qkv'])                         # full-row index space, as in the forward GEMM
         dln1 = self._empty(M, d, dtype=BF16)
         self._linear_bwd(dqkv.view(M, 3 * d), M, 3 * d, d, sv.ln1, f'{pfx}.attn.c_attn.weight', bias(f'{pfx}.attn.c_attn.bias'),
@@ -719,7 +727,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                           a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, sumsq_out=self._ws[1:2])
 
     def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None, presummed_slot=None,
-                    normalize: bool = True):
+                    normalize: bool = True, lowest_dx_mask=None):
         """presummed_slot: index into self._ws that already holds sum(dx^2) of the incoming gradient (None: reduce it here).
         Inside the loop every block's last LayerNorm backward leaves that sum for the block below (two alternating floats).
         normalize=False (Hugging Face GPT-2 blocks have no normalize_gradients): the same launches with the 'sum' pinned to the
@@ -732,7 +740,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             for l in reversed(range(len(saves))):
                 ops.grad_normalize(dx, self._unit_sq, dxb, bf16_drop=saves[l].dr['mlp'], presummed=True, keep_f32=True)
                 self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=False,
-                               vl=vl, dx_pre=self._unit_sq)
+                               vl=vl, dx_pre=self._unit_sq, dx_mask=lowest_dx_mask if l == 0 else None)
             return
         fold = NORMALISER_FOLDED and not any(getattr(sv, 'lo', None) for sv in saves)      # (LoRA's mlp.c_proj backward reads a normalised dxb)
         folded = False          # dxb already holds this block's incoming gradient (raw, masked): written by the block above
@@ -749,7 +757,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             hand_down = fold and l > 0
             self.block_bwd(f'{prefix}transformer.h.{l}', saves[l], dx, dxb, B, T, d, H, ff, causal, S, dmem, emit_last_bf16=hand_down,
                            vl=vl, sumsq_out=nxt, dx_pre=cur, dxb_sumsq=cur if folded else None,
-                           last_bf16_drop=saves[l - 1].dr['mlp'] if hand_down else None)
+                           last_bf16_drop=saves[l - 1].dr['mlp'] if hand_down else None, dx_mask=lowest_dx_mask if l == 0 else None)
             slot, presummed, folded = 1 - slot, True, hand_down
 
     # ------------------------------------------------------------------------------------------------ encoder
@@ -780,11 +788,13 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         y1, st1, st2 = self._empty(B, e.P2, d), self._empty(B, ops.LNND_STATS_STRIDE), self._empty(B, ops.LNND_STATS_STRIDE)
         ops.layernorm_nd_fwd(proj, None, g, bta, y1, e.P2 * d, st1, B, e.P2, d)
         x = self._empty(B, T, d)
-        ops.layernorm_nd_fwd(y1, wpe, g, bta, x[:, e.ncls:], T * d, st2, B, e.P2, d)
-        ops.bcast_rows(a.P(f'{self.ep}cls_token'), x, T * d, B, e.ncls, d)
         plan = self.enc_drop
         emb_drop = plan.get(0, 'emb') if plan is not None else None
-        if emb_drop is not None:
+        # the embedding dropout (encoder.py:170) is applied by the two producers of x while they write it (elementwise mask over [B, T, d])
+        fuse_emb = emb_drop is not None and EMB_DROP_FUSED and int(emb_drop[0]) == 1 and B * T * d < 2 ** 32
+        ops.layernorm_nd_fwd(y1, wpe, g, bta, x[:, e.ncls:], T * d, st2, B, e.P2, d, drop=emb_drop if fuse_emb else None, drop_base=e.ncls * d)
+        ops.bcast_rows(a.P(f'{self.ep}cls_token'), x, T * d, B, e.ncls, d, drop=emb_drop if fuse_emb else None)
+        if emb_drop is not None and not fuse_emb:
             ops.dropout_apply(x, B * T, d, emb_drop)
         saves, cur_x, perm = [], x.view(B * T, d), None
         for l in range(e.L - 1 if self.cls_only_last else e.L):
@@ -840,9 +850,15 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             ops.layernorm_bwd(denc, ctx.cls, gf, ctx.mf, ctx.rf, dcls, a.G(f'{self.ep}transformer.ln_f.weight'),
                               a.G(f'{self.ep}transformer.ln_f.bias'), Mc, d)
         dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
+        # the embedding dropout's backward: a mask on the gradient the lowest block hands down -- applied by that block's last LayerNorm
+        # backward while it stores dx (dense nanoGPT blocks), by a pass over dx elsewhere
+        emb_mask = ctx.emb_drop if (ctx.emb_drop is not None and EMB_DROP_FUSED and int(ctx.emb_drop[0]) == 1 and B * T * d < 2 ** 32) else None
+        masked = False
         if self.cls_only_last:
             self.block_bwd_cls(f'{self.ep}transformer.h.{e.L - 1}', ctx.saves[-1], dcls, dx, B, T, d, e.H, e.ff, e.ncls)
-            self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, presummed_slot=1)
+            masked = emb_mask is not None and e.L > 1
+            self._blocks_bwd(self.ep, ctx.saves[:-1], dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, presummed_slot=1,
+                             lowest_dx_mask=emb_mask if masked else None)
         elif e.fam is not None:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
             dxf, dperm = dx.view(B * T, d), None
@@ -851,8 +867,9 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
             dx = self.materialize(dxf, dperm).view(B, T, d)
         else:
             ops.copy_rows(dcls, e.ncls * d, dx, T * d, B, e.ncls, d)
-            self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None)
-        if ctx.emb_drop is not None:
+            masked = emb_mask is not None and e.L > 0
+            self._blocks_bwd(self.ep, ctx.saves, dx.view(B * T, d), B, T, d, e.H, e.ff, e.causal, 0, None, lowest_dx_mask=emb_mask if masked else None)
+        if ctx.emb_drop is not None and not masked:
             ops.dropout_apply(dx, B * T, d, ctx.emb_drop)
         ops.sum_over_batch(dx, T * d, a.G(f'{self.ep}cls_token'), B, e.ncls, d, accumulate=True)
         g = a.P(f'{self.ep}ln_input.weight')
@@ -1106,6 +1123,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         dx = self._empty(M, d)
         ops.layernorm_bwd(dh, ctx.xl, a.P(f'{self.dp}transformer.ln_f.weight'), ctx.mf, ctx.rf, dx,
                           a.G(f'{self.dp}transformer.ln_f.weight'), a.G(f'{self.dp}transformer.ln_f.bias'), M, d)
+        masked = False            # (the embedding dropout's backward already applied by the lowest block)
         if dc.fam is not None:
             dperm = None
             for l in reversed(range(dc.L)):
@@ -1122,8 +1140,10 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                 self.block_bwd(f'{self.dp}transformer.h.{l}', ctx.saves[l], dx, dxb, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem,
                                emit_last_bf16=False, vl=ctx.vl)
         else:
-            self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl)
-        if ctx.emb_drop is not None:
+            emb_mask = ctx.emb_drop if (ctx.emb_drop is not None and EMB_DROP_FUSED and int(ctx.emb_drop[0]) == 1 and M * d < 2 ** 32 and dc.L > 0) else None
+            self._blocks_bwd(self.dp, ctx.saves, dx, B, T, d, dc.H, dc.ff, dc.causal, ctx.S, dmem, ctx.vl, lowest_dx_mask=emb_mask)
+            masked = emb_mask is not None
+        if ctx.emb_drop is not None and not masked:
             ops.dropout_apply(dx, M, d, ctx.emb_drop)
         if ctx.ids is not None:
             dwpe = None if dc.advpos else a.G(f'{self.dp}transformer.wpe.weight')

@@ -23,10 +23,13 @@ SIGNATURES = {
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_fwd_eps': [P, P, P, P, P, I, P, P, I, I, F],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],
+    'i2t_layernorm_bwd_ex': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P, U, U, F],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
+    'i2t_layernorm_nd_fwd_drop': [P, P, P, P, P, P, L, P, I, I, I, U, U, F, L],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],
     'i2t_attention_fwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, I, I, I, I, I, U, U, F, P, P, I],
     'i2t_attention_bwd': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I, U, U, F, P, P, I, U, U, F],
+    'i2t_attention_bwd_ex': [P, P, L, I, P, L, I, P, L, I, P, L, I, P, L, I, P, P, P, L, I, P, L, I, P, L, I, I, I, I, I, I, U, U, F, P, P, I, U, U, F, I],
     'i2t_embed_fwd': [P, P, P, P, P, I, I, I, I, I, P],
     'i2t_embed_bwd': [P, P, P, P, P, I, I, I, I, I, P],
     'i2t_ce_fwd': [P, P, I, P, P, F, I64, P, P, I, I],
@@ -51,6 +54,7 @@ SIGNATURES = {
     'i2t_adamw_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_snradam_step': [P, P, P, P, P, P, L, P, P, P, I, F, F, F, I, F],
     'i2t_bcast_rows': [P, P, P, L, I, I, I],
+    'i2t_bcast_rows_drop': [P, P, P, L, I, I, I, U, U, F],
     'i2t_sum_over_batch': [P, P, L, P, I, I, I, I],
     'i2t_copy_rows': [P, P, L, P, L, I, I, I, I],
     'i2t_add_f32': [P, P, P, L],

@@ -201,23 +201,27 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=None):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None, bf16_drop=None,
-                  sumsq_out=None, dx_pre_sumsq=None):
-    """bf16_drop = (1, key, thr, scale): elementwise dropout mask applied to the bf16 copy only (see include/i2t.h)."""
+                  sumsq_out=None, dx_pre_sumsq=None, dx_mask=None):
+    """bf16_drop = (1, key, thr, scale): elementwise dropout mask applied to the bf16 copy only; dx_mask = (1, key, thr, scale): the
+    same kind of mask on the f32 dx this call stores (see include/i2t.h::i2t_layernorm_bwd_ex)."""
     _need_cuda(dy, x, dx)
-    assert bf16_drop is None or int(bf16_drop[0]) == 1
-    _l.check(_lib().i2t_layernorm_bwd(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
-                                      int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d, *_drop(bf16_drop)[1:],
-                                      _p(sumsq_out), _p(dx_pre_sumsq)), 'i2t_layernorm_bwd')
+    assert (bf16_drop is None or int(bf16_drop[0]) == 1) and (dx_mask is None or int(dx_mask[0]) == 1)
+    _l.check(_lib().i2t_layernorm_bwd_ex(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
+                                         int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d, *_drop(bf16_drop)[1:],
+                                         _p(sumsq_out), _p(dx_pre_sumsq), *_drop(dx_mask)[1:]), 'i2t_layernorm_bwd_ex')
     return dx
 
 
 LNND_STATS_STRIDE = 34
 
 
-def layernorm_nd_fwd(x, add, gamma, beta, y, y_batch_stride, stats, B, rows, d):
+def layernorm_nd_fwd(x, add, gamma, beta, y, y_batch_stride, stats, B, rows, d, drop=None, drop_base=0):
+    """drop = (1, key, thr, scale) + drop_base: the elementwise dropout of the tensor y is a slab of, applied while writing
+    (include/i2t.h::i2t_layernorm_nd_fwd_drop)"""
     _need_cuda(x, y, stats)
-    _l.check(_lib().i2t_layernorm_nd_fwd(_stream(), _p(x), _p(add), _p(gamma), _p(beta), _p(y), y_batch_stride, _p(stats), B,
-                                         rows, d), 'i2t_layernorm_nd_fwd')
+    assert drop is None or int(drop[0]) == 1
+    _l.check(_lib().i2t_layernorm_nd_fwd_drop(_stream(), _p(x), _p(add), _p(gamma), _p(beta), _p(y), y_batch_stride, _p(stats), B,
+                                              rows, d, *_drop(drop)[1:], int(drop_base)), 'i2t_layernorm_nd_fwd_drop')
     return y
 
 
@@ -246,15 +250,24 @@ def attention_fwd(q, k, v, o, lse, B, H, Tq, Tk, causal, drop=None, cu_q=None, c
 
 
 def attention_bwd(q, k, v, o, do, lse, delta_ws, dq, dk, dv, B, H, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0,
-                  out_drop=None):
-    """out_drop = (2, key, thr, scale): the forward's per-token q/k/v multipliers applied to dq/dk/dv on the way out."""
+                  out_drop=None, out_drop_q_seq=0):
+    """out_drop = (2, key, thr, scale): the forward's per-token q/k/v multipliers applied to dq/dk/dv on the way out;
+    out_drop_q_seq: the queries are the first Tq rows of sequences of that many rows (i2t_attention_bwd_ex)."""
     _need_cuda(q, k, v, o, do, dq, dk, dv)
     qb, qr = _bs_rs(q); kb, kr = _bs_rs(k); vb, vr = _bs_rs(v); ob, orr = _bs_rs(o); gb, gr = _bs_rs(do)
     dqb, dqr = _bs_rs(dq); dkb, dkr = _bs_rs(dk); dvb, dvr = _bs_rs(dv)
-    _l.check(_lib().i2t_attention_bwd(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
-                                      _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
-                                      int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q), *_drop(out_drop)[1:]),
-             'i2t_attention_bwd')
+    _l.check(_lib().i2t_attention_bwd_ex(_stream(), _p(q), qb, qr, _p(k), kb, kr, _p(v), vb, vr, _p(o), ob, orr, _p(do), gb, gr,
+                                         _p(lse), _p(delta_ws), _p(dq), dqb, dqr, _p(dk), dkb, dkr, _p(dv), dvb, dvr, B, H, Tq, Tk,
+                                         int(causal), *_drop(drop)[1:], _p(cu_q), _p(cu_k), int(total_q), *_drop(out_drop)[1:],
+                                         int(out_drop_q_seq)), 'i2t_attention_bwd_ex')
+
+
+def attention_bwd_takes_q_seq(Tq: int, Tk: int, drop) -> bool:
+    """whether a dense, non-causal attention_bwd of these sizes runs on the one-pass resident-operand kernel, the only one that takes
+    out_drop_q_seq (the rule of csrc/attention.hip::v2_applies + the default I2T_ATTN_BWD mode; the C side refuses loudly otherwise)"""
+    if os.environ.get('I2T_ATTN_V2', '1')[:1] == '0' or os.environ.get('I2T_ATTN_BWD2', '1')[:1] == '0' or os.environ.get('I2T_ATTN_BWD', '3') != '3':
+        return False
+    return 64 <= Tq <= 288 and Tk <= 288 and (drop is None or Tk % 4 == 0)
 
 
 def gq_attention_fwd(q, k, v, o, lse, B, H, Hkv, hd, Tq, Tk, causal, drop=None, cu_q=None, cu_k=None, total_q=0, split=0):
@@ -604,8 +617,9 @@ def snradam_step(p, g, m, v, p_bf16, n, seg_end, seg_lr, seg_wd, nseg, beta1, be
              'i2t_snradam_step')
 
 
-def bcast_rows(src, y, y_batch_stride, B, rows, d):
-    _l.check(_lib().i2t_bcast_rows(_stream(), _p(src), _p(y), y_batch_stride, B, rows, d), 'i2t_bcast_rows')
+def bcast_rows(src, y, y_batch_stride, B, rows, d, drop=None):
+    assert drop is None or int(drop[0]) == 1
+    _l.check(_lib().i2t_bcast_rows_drop(_stream(), _p(src), _p(y), y_batch_stride, B, rows, d, *_drop(drop)[1:]), 'i2t_bcast_rows_drop')
 
 
 def sum_over_batch(x, x_batch_stride, dst, B, rows, d, accumulate=False):

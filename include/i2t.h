@@ -139,6 +139,14 @@ int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* 
                       const float* mean, const float* rstd,
                       float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
                       unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out, const float* dx_pre_sumsq);
+/* dx_mask_* (nullable by thr = 0): an elementwise dropout mask (index row * d + column, i2t_dropout_apply mode 1) applied to the f32 dx
+ * this call stores -- the embedding dropout's backward (decoder.py:243, encoder.py:170) folded into the lowest block's last LayerNorm
+ * backward; sumsq_out and the bf16 copy see the unmasked value */
+int i2t_layernorm_bwd_ex(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
+                         const float* mean, const float* rstd,
+                         float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
+                         unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out, const float* dx_pre_sumsq,
+                         unsigned dx_mask_key, unsigned dx_mask_thr, float dx_mask_scale);
 /* dx_pre_sumsq (bwd, nullable, needs dx_accumulate): the dx accumulated onto is still un-normalised -- its old value is
  * multiplied by 1 / (sqrt(*dx_pre_sumsq) + 1e-6) while adding (the gradient normaliser of i2t_grad_normalize flag 2).
  * sumsq_out (bwd, nullable): += sum of squares of the f32 dx written by this call (after accumulation) -- lets the
@@ -157,6 +165,11 @@ int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, const float* 
 #define I2T_LNND_STATS_STRIDE 34
 int i2t_layernorm_nd_fwd(void* stream, const float* x, const float* add, const float* gamma, const float* beta,
                          float* y, long y_batch_stride, float* stats, int B, int rows, int d);
+/* the same with the elementwise dropout of the tensor that y is a slab of (the embedding dropout of encoder.py:170 applied by the producer of
+ * the patch rows): element (b, i) of y is dropped by the decision of index b * y_batch_stride + drop_base + i (i2t_dropout_apply mode 1's rule) */
+int i2t_layernorm_nd_fwd_drop(void* stream, const float* x, const float* add, const float* gamma, const float* beta,
+                              float* y, long y_batch_stride, float* stats, int B, int rows, int d,
+                              unsigned drop_key, unsigned drop_thr, float drop_scale, long drop_base);
 int i2t_layernorm_nd_bwd(void* stream, const float* dy, long dy_batch_stride, const float* x, const float* add,
                          const float* gamma, const float* stats, float* dx, float* dgamma, float* dbeta,
                          float* dadd, int B, int rows, int d);
@@ -189,6 +202,17 @@ int i2t_attention_bwd(void* stream, const void* q, long q_bs, int q_rs, const vo
 /* out_drop_* (bwd): the per-token q/k/v multipliers of the fused c_attn output (i2t_gemm_bf16 drop_mode 2) applied to
  * dq / dk / dv on the way out: row r of dq is scaled by keep(key, r), of dk by keep(key + 1, r), of dv by keep(key + 2, r);
  * r = token index (b*T + t, or the packed row).  out_drop_thr 0 = off. */
+/* the same with out_drop_q_seq != 0: the Tq query rows are the FIRST rows of sequences of out_drop_q_seq rows (the encoder's last
+ * block computes its CLS rows only, layers.py:465 over encoder.py:172-173's slice), so row r of dq is token b*out_drop_q_seq + t in the
+ * index space of the multipliers; 0 = Tq.  Offered by the dense resident-operand kernel only. */
+int i2t_attention_bwd_ex(void* stream, const void* q, long q_bs, int q_rs, const void* k, long k_bs, int k_rs,
+                         const void* v, long v_bs, int v_rs, const void* o, long o_bs, int o_rs,
+                         const void* d_o, long do_bs, int do_rs, const float* lse, float* delta_ws,
+                         void* dq, long dq_bs, int dq_rs, void* dk, long dk_bs, int dk_rs,
+                         void* dv, long dv_bs, int dv_rs, int B, int H, int Tq, int Tk, int causal,
+                         unsigned drop_key, unsigned drop_thr, float drop_scale,
+                         const int* cu_q, const int* cu_k, int total_q,
+                         unsigned out_drop_key, unsigned out_drop_thr, float out_drop_scale, int out_drop_q_seq);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Token + position embedding (decoder.py:231-243): x[b][t] = wte[ids[b][t]] + wpe[t + pos_offset]  (f32)
@@ -313,6 +337,9 @@ int i2t_snradam_step(void* stream, float* p, const float* g, float* m, float* v,
                      float beta1, float beta2, float eps, int step, float grad_scale);
 /* y[b][r][:] = src[r][:] for r < rows (broadcast a (rows,d) f32 block into a strided batch buffer) */
 int i2t_bcast_rows(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d);
+/* ... with the same elementwise dropout on the rows it writes (index b * y_batch_stride + i: they head their slab) */
+int i2t_bcast_rows_drop(void* stream, const float* src, float* y, long y_batch_stride, int B, int rows, int d,
+                        unsigned drop_key, unsigned drop_thr, float drop_scale);
 /* dst[r][:] (+)= sum_b x[b][r][:] */
 int i2t_sum_over_batch(void* stream, const float* x, long x_batch_stride, float* dst, int B, int rows, int d,
                        int accumulate);
