@@ -958,6 +958,57 @@ def test_fused_backward_dropout_outputs(ops):
     check('attention_bwd token multipliers', g1.view(B * T, 3, dd), ref, 1e-6, 1 / 128)
 
 
+def test_round4_fused_dropout_sites(ops):
+    """The dropout passes folded into their neighbours in round 4, each against the pass it replaces: (a) attention_bwd's per-token
+    multipliers when the queries are the FIRST rows of longer sequences (the encoder's CLS-only last block: out_drop_q_seq), (b) the
+    embedding dropout applied by layernorm_nd_fwd / bcast_rows while they write their slabs of x, (c) its backward as a mask on the
+    f32 dx that layernorm_bwd stores (sum of squares and bf16 copy unmasked)."""
+    from image2text_amd import rng
+    key, thr = rng.site_key(777, 5), rng.threshold(0.1)
+    sc = rng.scale(thr)
+    # (a) B x T rows of q|k|v, queries = rows [0, ncls) of every sequence
+    B, H, T, ncls = 3, 4, 260, 64
+    dd = 64 * H
+    qkv = rnd(B, T, 3 * dd, dtype=BF16, seed=401)
+    do = rnd(B, ncls, dd, dtype=BF16, seed=402)
+    q, k, v = qkv[:, :ncls, :dd], qkv[..., dd:2 * dd], qkv[..., 2 * dd:]
+    o, lse = torch.empty(B, ncls, dd, dtype=BF16, device=dev()), torch.empty(B, H, ncls, device=dev())
+    ops.attention_fwd(q, k, v, o, lse, B, H, ncls, T, False)
+    assert ops.attention_bwd_takes_q_seq(ncls, T, None)
+    g0, g1 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    for gq, od in ((g0, None), (g1, (2, key, thr, sc))):
+        ops.attention_bwd(q, k, v, o, do, lse, torch.empty(B, H, ncls, device=dev()), gq[:, :ncls, :dd], gq[..., dd:2 * dd], gq[..., 2 * dd:],
+                          B, H, ncls, T, False, out_drop=od, out_drop_q_seq=T)
+    ref = g0.clone()
+    ops.dropout_apply(ref, B * T, 3 * dd, (2, key, thr, sc))                  # the pass it replaces: token row b * T + t, thirds q | k | v
+    check('attention_bwd multipliers, queries as the first rows', g1, ref, 1e-6, 1 / 128)
+    assert torch.equal(g1 == 0, ref == 0)
+    # (b) x[B, T, d] = [cls rows | LayerNormND(patch rows)] with the elementwise mask over the whole tensor
+    Bx, P2, d = 5, 12, 64
+    Tx = 4 + P2
+    src, add, gam, bet, cls = rnd(Bx, P2, d, seed=403), rnd(P2, d, seed=404), rnd(P2, d, seed=405), rnd(P2, d, seed=406), rnd(4, d, seed=407)
+    x0, x1 = torch.empty(Bx, Tx, d, device=dev()), torch.empty(Bx, Tx, d, device=dev())
+    st0, st1 = torch.empty(Bx, ops.LNND_STATS_STRIDE, device=dev()), torch.empty(Bx, ops.LNND_STATS_STRIDE, device=dev())
+    ops.layernorm_nd_fwd(src, add, gam, bet, x0[:, 4:], Tx * d, st0, Bx, P2, d)
+    ops.bcast_rows(cls, x0, Tx * d, Bx, 4, d)
+    ops.dropout_apply(x0, Bx * Tx, d, (1, key, thr, sc))
+    ops.layernorm_nd_fwd(src, add, gam, bet, x1[:, 4:], Tx * d, st1, Bx, P2, d, drop=(1, key, thr, sc), drop_base=4 * d)
+    ops.bcast_rows(cls, x1, Tx * d, Bx, 4, d, drop=(1, key, thr, sc))
+    assert torch.equal(x0, x1)
+    # (c) the mask on the stored f32 dx
+    M, dl = 300, 768
+    xx, gm, dy, prev = rnd(M, dl, seed=408), rnd(dl, seed=409), rnd(M, dl, seed=410), rnd(M, dl, seed=411)
+    mean, rstd = xx.mean(-1), (xx.var(-1, unbiased=False) + 1e-5).rsqrt()
+    d0, d1 = prev.clone(), prev.clone()
+    b0, b1 = torch.empty(M, dl, dtype=BF16, device=dev()), torch.empty(M, dl, dtype=BF16, device=dev())
+    s0, s1 = torch.zeros(1, device=dev()), torch.zeros(1, device=dev())
+    ops.layernorm_bwd(dy, xx, gm, mean, rstd, d0, None, None, M, dl, dx_accumulate=True, dx_bf16=b0, sumsq_out=s0)
+    ops.dropout_apply(d0, M, dl, (1, key, thr, sc))
+    ops.layernorm_bwd(dy, xx, gm, mean, rstd, d1, None, None, M, dl, dx_accumulate=True, dx_bf16=b1, sumsq_out=s1, dx_mask=(1, key, thr, sc))
+    assert torch.equal(d0, d1) and torch.equal(b0, b1)
+    assert abs(float(s0) - float(s1)) <= 1e-5 * float(s0)
+
+
 def test_attention_packed_varlen(ops, monkeypatch):
     """Packed variable-length self-attention (causal) and packed-query cross-attention == per-sequence dense calls (bit for bit:
     both sides on the tiled kernels -- a dense 64-row call would otherwise take the resident-operand kernels, whose summation
