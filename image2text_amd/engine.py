@@ -58,7 +58,7 @@ EMB_DROP_FUSED = os.environ.get('I2T_EMB_DROP_FUSED', '1') not in ('', '0')
 # row of 50257 logits starts on a line boundary (at 8 columns -- 16-byte alignment, the ABI's minimum -- every 256-column tile segment of
 # a row straddled two lines: the lm_head GEMM wrote 1.22x its bytes and the two gradient GEMMs fetched the logits' gradient 1.35x,
 # profiles/r04_gemm_traffic_by_shape.txt).  I2T_VOCAB_PAD=8 restores the old layout for A/B runs.
-VOCAB_PAD = int(os.environ.get('I2T_VOCAB_PAD', '64'))
+VOCAB_PAD = max(8, int(os.environ.get('I2T_VOCAB_PAD', '64')) // 8 * 8)          # (a multiple of 8: the ABI's 16-byte row alignment)
 
 
 def _round_up(x: int, m: int) -> int:
