@@ -69,11 +69,21 @@ class GemmTimer:
                    ('+drop' if kw.get('drop') is not None else '')
             self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + (c_bytes + extra) * M * N, (M, N, K, kind)))
             return r
+        def timed_top2(a, b, top2, M, N, K):          # the greedy step's lm_head (segment maxima instead of the logits: 16 B per 64 columns)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = self.orig_top2(a, b, top2, M, N, K)
+            e1.record(torch.cuda.current_stream())
+            self.records.append((e0, e1, 2.0 * M * N * K, 2.0 * (M * K + N * K) + 16.0 * M * ((N + 63) // 64), (M, N, K, 'A.B^T top2')))
+            return r
         self.ops.gemm = timed
+        self.orig_top2 = self.ops.gemm_top2
+        self.ops.gemm_top2 = timed_top2
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
+        self.ops.gemm_top2 = self.orig_top2
 
     def breakdown(self):
         """Per (shape, layout, epilogue) table: launches, avg us, TFLOP/s, algorithmic TB/s."""
@@ -494,7 +504,7 @@ def main():
                                       'launches': dec_attn['launches'], 'avg_launch_us': round(dec_attn['avg_us'], 2),
                                       'decode_attention_ms_per_run': round(dec_attn['total_ms'], 2), 'captions': Bd, 'new_tokens': 64}
         if dec_gemm is not None and dec_gemm['launches']:
-            out['decode_gemm_roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel / gemm_bf16_kernel (every i2t_gemm_bf16 launch of the same eager run: '
+            out['decode_gemm_roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_kernel / gemm_bf16_kernel (every i2t_gemm_bf16 / i2t_gemm_bf16_top2 launch of the same eager run: '
                                            'encoder forward of the captions + 64 decode steps at M = captions rows)',
                                            'achieved': round(dec_gemm['tflops'], 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                            'frac': round(dec_gemm['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,

@@ -267,6 +267,101 @@ __global__ __launch_bounds__(BAN_THREADS) void ngram_ban_argmax_kernel(const voi
     }
 }
 
+// The same token choice from the lm_head's SEGMENT maxima (i2t_gemm_bf16_top2: the two largest logits of every 64-column segment of a
+// row, value descending / column ascending) instead of the logits themselves: a segment whose best column is not banned contributes
+// it, one whose best is banned contributes its second, and one whose two best are BOTH banned (rare: two continuations of repeated
+// n-grams among 64 neighbouring token ids, both ahead of everything else there) is re-evaluated exactly here -- 64 dot products of
+// the hidden row with the head's rows, banned columns left out.  One caption per workgroup.
+constexpr int T2_THREADS = 256, T2_MAX_REDO = 64;
+__global__ __launch_bounds__(T2_THREADS) void top2_ngram_argmax_kernel(const f32x4* __restrict__ top2, int nseg, const bf16_t* __restrict__ hid,
+                                                                        int ld_h, const bf16_t* __restrict__ W, int ldw, int d,
+                                                                        int64_t* __restrict__ ids, int ids_ld, const int* __restrict__ len_ptr,
+                                                                        const int* __restrict__ ngram_sizes, int n_sizes, int V) {
+    __shared__ int banned[MAX_BANNED];
+    __shared__ int n_banned, n_redo;
+    __shared__ int redo[T2_MAX_REDO];
+    __shared__ float rv[T2_THREADS / 64];
+    __shared__ int ri[T2_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = *len_ptr;
+    int64_t* row = ids + (size_t)b * ids_ld;
+    if (tid == 0) n_banned = n_redo = 0;
+    __syncthreads();
+    for (int si = 0; si < n_sizes; ++si) {                  // (as ngram_ban_argmax_kernel)
+        const int n = ngram_sizes[si];
+        if (n < 1 || len + 1 < n) continue;
+        for (int i = tid; i <= len - n; i += T2_THREADS) {
+            bool same = true;
+            for (int j = 0; j < n - 1; ++j) same = same && (row[i + j] == row[len - n + 1 + j]);
+            if (same) {
+                int slot = atomicAdd(&n_banned, 1);
+                if (slot < MAX_BANNED) banned[slot] = (int)row[i + n - 1];
+            }
+        }
+    }
+    __syncthreads();
+    const int nb = min(n_banned, MAX_BANNED);
+    auto is_banned = [&](int c) {
+        bool hit = false;
+        for (int k = 0; k < nb; ++k) hit = hit || (banned[k] == c);
+        return hit;
+    };
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    auto offer = [&](float v, int c) {
+        if (v > best || (v == best && c < bi)) {
+            best = v;
+            bi = c;
+        }
+    };
+    for (int sgm = tid; sgm < nseg; sgm += T2_THREADS) {
+        const f32x4 t = top2[(size_t)b * nseg + sgm];
+        const int i1 = __float_as_int(t[1]), i2 = __float_as_int(t[3]);
+        if (!(t[0] > -INFINITY)) continue;                  // nothing valid in the segment
+        if (!is_banned(i1)) {
+            offer(t[0], i1);
+        } else if (t[2] > -INFINITY && !is_banned(i2)) {
+            offer(t[2], i2);
+        } else if (t[2] > -INFINITY) {                      // both leaders banned: what is left of the segment is unknown
+            const int slot = atomicAdd(&n_redo, 1);
+            if (slot < T2_MAX_REDO) redo[slot] = sgm;
+        }
+    }
+    __syncthreads();
+    const int nr = min(n_redo, T2_MAX_REDO);
+    for (int r = 0; r < nr; ++r) {                          // exact re-evaluation of a segment, one column per thread of wave 0
+        if (tid < 64) {
+            const int c = redo[r] * 64 + tid;
+            if (c < V && !is_banned(c)) {
+                const bf16_t* wr = W + (size_t)c * ldw;
+                const bf16_t* hr = hid + (size_t)b * ld_h;
+                float acc = 0.f;
+                for (int k = 0; k < d; k += 8) {
+                    const u32x4 wv = *reinterpret_cast<const u32x4*>(wr + k), hv = *reinterpret_cast<const u32x4*>(hr + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += bf16lo(wv[e]) * bf16lo(hv[e]) + bf16hi(wv[e]) * bf16hi(hv[e]);
+                }
+                offer(acc, c);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        offer(ov, oi);
+    }
+    if ((tid & 63) == 0) {
+        rv[tid >> 6] = best;
+        ri[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < T2_THREADS / 64; ++k) offer(rv[k], ri[k]);
+        row[len] = bi;
+    }
+}
+
 __global__ void advance_kernel(int* counters, int n, int delta) {
     if ((int)threadIdx.x < n) counters[threadIdx.x] += delta;
 }
@@ -322,6 +417,18 @@ extern "C" int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, in
         hipLaunchKernelGGL(ngram_ban_argmax_kernel<false>, dim3(B), dim3(BAN_THREADS), 0, (hipStream_t)stream, logits, ld, ids,
                            ids_ld, len_ptr, ngram_sizes, n_sizes, V, margin_out);
     I2T_CHECK_LAUNCH("i2t_ngram_ban_argmax");
+    return I2T_OK;
+}
+
+extern "C" int i2t_top2_ngram_argmax(void* stream, const float* top2, int nseg, const void* hidden, int ld_hidden, const void* w_head,
+                                     int ld_w, int d, int64_t* ids, int ids_ld, int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V) {
+    I2T_REQUIRE(top2 && hidden && w_head && ids && len_ptr && B > 0 && V > 0 && nseg == (V + 63) / 64 && (n_sizes == 0 || ngram_sizes),
+                "i2t_top2_ngram_argmax: bad args (nseg must be ceil(V / 64))");
+    I2T_REQUIRE(d % 8 == 0 && (ld_hidden & 7) == 0 && (ld_w & 7) == 0 && ALIGNED16(top2) && ALIGNED16(hidden) && ALIGNED16(w_head),
+                "i2t_top2_ngram_argmax: hidden / head rows must be 16-byte aligned, d %% 8 == 0");
+    hipLaunchKernelGGL(top2_ngram_argmax_kernel, dim3(B), dim3(T2_THREADS), 0, (hipStream_t)stream, (const f32x4*)top2, nseg,
+                       (const bf16_t*)hidden, ld_hidden, (const bf16_t*)w_head, ld_w, d, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, V);
+    I2T_CHECK_LAUNCH("i2t_top2_ngram_argmax");
     return I2T_OK;
 }
 

@@ -1331,6 +1331,47 @@ struct G2 {
     }
 };
 
+// Epilogue class 12 (i2t_gemm_bf16_top2: the lm_head of a greedy decode step).  The output tile is NOT stored: every 64-column segment
+// of a row leaves its two largest values and their columns -- C[row][segment] = {v1, column1, v2, column2}, value descending, the lower
+// column first on ties (torch.argmax's rule) -- 16 bytes instead of 256.  The 823 MB of fp32 logits a 4096-caption step wrote and
+// the n-gram-ban / argmax kernel read back become 51 MB; i2t_top2_ngram_argmax (decode.hip) merges the segments.
+__device__ __forceinline__ void top2_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int mbase, int nbase, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int seg = nbase >> 6;
+    if (seg >= p.ldc) return;                          // wave-uniform: a segment wholly past N
+    f32x4* out = reinterpret_cast<f32x4*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v1 = -INFINITY, v2 = -INFINITY;
+        int i1 = 0x7fffffff, i2 = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {              // a lane's columns in ascending order: strict > keeps the first of equals
+                const int col = nbase + 16 * j + 4 * g + r;
+                const float v = col < p.N ? acc[i][j][r] : -INFINITY;
+                if (v > v1) {
+                    v2 = v1; i2 = i1; v1 = v; i1 = col;
+                } else if (v > v2) {
+                    v2 = v; i2 = col;
+                }
+            }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {           // the four lanes that hold a row's other columns
+            const float ov1 = __shfl_xor(v1, o, 64), ov2 = __shfl_xor(v2, o, 64);
+            const int oi1 = __shfl_xor(i1, o, 64), oi2 = __shfl_xor(i2, o, 64);
+            const bool of = ov1 > v1 || (ov1 == v1 && oi1 < i1);                   // the other pair holds the best
+            const float l1 = of ? v1 : ov1, w2 = of ? ov2 : v2;                    // loser's best against winner's second
+            const int li1 = of ? i1 : oi1, wi2 = of ? oi2 : i2;
+            const bool ls = l1 > w2 || (l1 == w2 && li1 < wi2);
+            v1 = of ? ov1 : v1; i1 = of ? oi1 : i1;
+            v2 = ls ? l1 : w2; i2 = ls ? li1 : wi2;
+        }
+        const int m = mbase + 16 * i + li;
+        if (g == 0 && m < p.M) out[(size_t)m * p.ldc + seg] = f32x4{v1, __int_as_float(i1), v2, __int_as_float(i2)};
+    }
+}
+
 // The kernel's own argument block (GemmParams is the only argument: offset 0 of the kernarg segment), through a pointer the
 // compiler cannot connect to the argument `p`: loads through it are scalar loads issued where they are used.
 __device__ __forceinline__ const GemmParams* epilogue_params() {
@@ -1413,6 +1454,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
             xattn_epilogue(*epilogue_params(), acc, m0 >> 8, n0, g.wr, g.wc, lane_e, smem + 8 * G2_UNIT + (g.wave_off << 2));
+        } else if constexpr (EPI == 12) {       // the two largest of every 64-column row segment instead of the tile (greedy decode's lm_head)
+            int lane_e = tid & 63;
+            asm volatile("" : "+v"(lane_e));
+            top2_epilogue(*epilogue_params(), acc, m0 + g.wr * 128, n0 + g.wc * 64, lane_e);
         } else if constexpr (EPI == 6) {        // split-K partial: fp32 atomics, one wave-instruction = 4 rows x 64 contiguous bytes
             int lane_e = tid & 63;
             asm volatile("" : "+v"(lane_e));
@@ -2203,6 +2248,26 @@ extern "C" int i2t_gemm_bf16_ex(void* stream, const void* A, int lda, int a_kmaj
         else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, block, 0, s, p);
     }
     I2T_CHECK_LAUNCH("i2t_gemm_bf16");
+    return I2T_OK;
+}
+
+extern "C" int i2t_gemm_bf16_top2(void* stream, const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* top2, int nseg) {
+    I2T_REQUIRE(A && B && top2 && M > 0 && N > 0 && K > 0 && nseg == (N + 63) / 64, "i2t_gemm_bf16_top2: bad args (nseg must be ceil(N / 64))");
+    I2T_REQUIRE(K % 128 == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && ALIGNED16(A) && ALIGNED16(B) && ALIGNED16(top2),
+                "i2t_gemm_bf16_top2: K=%d must be a multiple of 128, operands 16-byte aligned with leading dimensions %% 8 == 0", K);
+    I2T_REQUIRE((size_t)256 * lda * 2 < (1ull << 32) && (size_t)256 * ldb * 2 < (1ull << 32), "i2t_gemm_bf16_top2: rows too long");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = top2;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = nseg;
+    p.alpha = 1.0f; p.c_is_f32 = 1;
+    { static const char* e = getenv("I2T_G256_GN"); static const int gn = e ? atoi(e) : 8; p.g2_gn = gn > 0 ? gn : 8; }
+    const int n_cu = g256_cus();
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+    p.g2_splits = 1; p.g2_nk = (((K + 63) >> 6) + 1) & ~1;
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<false, false, 12>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), 0, (hipStream_t)stream, p);
+    I2T_CHECK_LAUNCH("i2t_gemm_bf16_top2");
     return I2T_OK;
 }
 

@@ -30,6 +30,7 @@ from .engine import BF16, F32, HotPath
 
 
 ENC_CHUNK = int(os.environ.get('I2T_DECODE_ENC_CHUNK', '4096'))      # images per encoder pass inside generate()
+TOP2_HEAD = os.environ.get('I2T_DECODE_TOP2', '1') not in ('', '0')    # greedy steps: lm_head + argmax through segment maxima (ops.gemm_top2)
 
 
 class Sampling(NamedTuple):
@@ -201,7 +202,7 @@ class GreedyDecoder:
                 if self.eng.cross_inputs and (self.eng.dec_cross[l] or not self.eng.dcfg.skip_alternate_cross_attn)]
 
     # ------------------------------------------------------------------------------------------------ one token
-    def _step(self, st, with_head: bool, sampling: Optional[Sampling] = None):
+    def _step(self, st, with_head: bool, sampling: Optional[Sampling] = None, top2: bool = False):
         """Consume the token at ids[:, pos]; when with_head also choose ids[:, len] (argmax after the n-gram ban, or a draw from
         the filtered distribution when ``sampling`` is given); then advance pos and len."""
         eng, a, dc = self.eng, self.eng.arena, self.eng.dec
@@ -235,6 +236,13 @@ class GreedyDecoder:
                 ops.rmsnorm_fwd(st.x, a.P(dp + dc.llama.norm_f + '.weight'), st.hid, None, B, d, dc.llama.eps)
             else:
                 ops.layernorm_fwd(st.x, a.P(f'{dp}transformer.ln_f.weight'), a.P(f'{dp}transformer.ln_f.bias'), st.hid, None, None, B, d)
+            if top2 and sampling is None:
+                # greedy, nobody asked for margins: the lm_head leaves the two largest logits of every 64-column segment of a row
+                # instead of the row (51 MB instead of 823 MB written and read back at 4096 captions), the ban + argmax merges them
+                ops.gemm_top2(st.hid, a.W(eng.n_head), st.top2, B, dc.V, d)
+                ops.top2_ngram_argmax(st.top2, st.hid, a.W(eng.n_head), st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, d)
+                ops.advance(st.counters, 1)
+                return
             ops.gemm(st.hid, a.W(eng.n_head), st.logits, B, dc.V, d, workspace=st.ws)
             if sampling is None:
                 ops.ngram_ban_argmax(st.logits, dc.Vp, st.ids, st.ids_ld, len_ptr, st.ngrams, st.ngrams.numel(), B, dc.V, st.margin)
@@ -314,13 +322,13 @@ class GreedyDecoder:
             ops.swiglu_fwd(st.gu, st.h, B, ff)
             ops.gemm(st.h, v.Wdn, st.x, B, d, ff, residual=st.x, workspace=st.ws)
 
-    def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None):
+    def _capture(self, st, with_head: bool, sampling: Optional[Sampling] = None, top2: bool = False):
         side = torch.cuda.Stream(device=st.arena.device)
         side.wait_stream(torch.cuda.current_stream())
         g = ops.Graph()
         with torch.cuda.stream(side):
             g.begin()
-            self._step(st, with_head, sampling)
+            self._step(st, with_head, sampling, top2)
             g.end()
         torch.cuda.current_stream().wait_stream(side)
         return g
@@ -398,8 +406,12 @@ class GreedyDecoder:
                                        dtype=torch.int32))
             if return_dists != (st.dist is not None):         # captured sampling steps bake the dist pointer (or its absence)
                 st.dist = torch.zeros(B, dc.V, dtype=F32, device=a.device) if return_dists else None
-                st.graphs = {k: g for k, g in st.graphs.items() if k in (None, 'greedy')}
-        full_key = 'greedy' if sampling is None else sampling.key()
+                st.graphs = {k: g for k, g in st.graphs.items() if k in (None, 'greedy', 'greedy_top2')}
+        # greedy without margins: the head in its segment-maxima form (d % 128 == 0: the persistent GEMM kernel's K rule; I2T_DECODE_TOP2=0: the logits form)
+        top2 = sampling is None and not return_margins and TOP2_HEAD and dc.d % 128 == 0
+        if top2 and getattr(st, 'top2', None) is None:
+            st.top2 = torch.zeros(B, (dc.V + 63) // 64, 4, dtype=F32, device=a.device)
+        full_key = ('greedy_top2' if top2 else 'greedy') if sampling is None else sampling.key()
 
         def reset():
             st.ids.zero_()
@@ -410,17 +422,17 @@ class GreedyDecoder:
         dists = torch.zeros(max_new_tokens, B, dc.V, dtype=F32, device=a.device) if return_dists else None
         if use_graph and (full_key not in st.graphs or None not in st.graphs):
             # warm up eagerly once (code objects must be loaded before capture), then capture the step kinds that are missing
-            self._step(st, True, sampling)
+            self._step(st, True, sampling, top2)
             self._step(st, False)
             if full_key not in st.graphs:
-                st.graphs[full_key] = self._capture(st, True, sampling)
+                st.graphs[full_key] = self._capture(st, True, sampling, top2)
             if None not in st.graphs:
                 st.graphs[None] = self._capture(st, False)
             reset()
         for _ in range(P - 1):                                  # prompt tokens before the last: fill the cache only
             st.graphs[None].launch() if use_graph else self._step(st, False)
         for i in range(max_new_tokens):
-            st.graphs[full_key].launch() if use_graph else self._step(st, True, sampling)
+            st.graphs[full_key].launch() if use_graph else self._step(st, True, sampling, top2)
             if return_margins:
                 margins[i].copy_(st.margin)
             if return_dists:

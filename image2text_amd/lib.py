@@ -61,6 +61,8 @@ SIGNATURES = {
     'i2t_decode_attention': [P, P, I, P, P, L, I, L, P, I, P, I, I, I, I],
     'i2t_kv_append': [P, P, I, P, P, L, I, P, I, I],
     'i2t_ngram_ban_argmax': [P, P, I, I, P, I, P, P, I, I, I, P],
+    'i2t_gemm_bf16_top2': [P, P, I, P, I, I, I, I, P, I],
+    'i2t_top2_ngram_argmax': [P, P, I, P, I, P, I, I, P, I, P, P, I, I, I],
     'i2t_sample_token': [P, P, I, P, I, P, P, I, I, I, F, I, F, P, P, I],
     'i2t_embed_step': [P, P, I, P, P, P, P, I, I, I, I],
     'i2t_advance': [P, P, I, I],

@@ -652,6 +652,21 @@ def ngram_ban_argmax(logits, ld, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, 
                                          _p(ngram_sizes), n_sizes, B, V, _p(margin_out)), 'i2t_ngram_ban_argmax')
 
 
+def gemm_top2(a, b, top2, M, N, K):
+    """the two largest of every 64-column segment of a . b^T, not the product (include/i2t.h::i2t_gemm_bf16_top2); top2 f32 [M, ceil(N/64), 4]"""
+    _need_cuda(a, b, top2)
+    assert a.dtype == BF16 and b.dtype == BF16 and top2.dtype == F32 and top2.is_contiguous() and top2.shape[-2] == (N + 63) // 64
+    _l.check(_lib().i2t_gemm_bf16_top2(_stream(), _p(a), a.stride(0), _p(b), b.stride(0), M, N, K, _p(top2), (N + 63) // 64), 'i2t_gemm_bf16_top2')
+    return top2
+
+
+def top2_ngram_argmax(top2, hidden, w_head, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, V, d):
+    """n-gram ban + argmax over gemm_top2's segments (include/i2t.h::i2t_top2_ngram_argmax)"""
+    _need_cuda(top2, hidden, w_head, ids)
+    _l.check(_lib().i2t_top2_ngram_argmax(_stream(), _p(top2), (V + 63) // 64, _p(hidden), hidden.stride(0), _p(w_head), w_head.stride(0), d,
+                                          _p(ids), ids_ld, _p(len_ptr), _p(ngram_sizes), n_sizes, B, V), 'i2t_top2_ngram_argmax')
+
+
 def sample_token(logits, ld, ids, ids_ld, len_ptr, ngram_sizes, n_sizes, B, V, temperature, top_k, nucleus_p, seed, dist_out=None):
     """One sampling step (include/i2t.h::i2t_sample_token); top_k None/0 = no crop, nucleus_p None = no cut."""
     _need_cuda(logits, ids, seed)

@@ -368,6 +368,15 @@ int i2t_kv_append(void* stream, const void* qkv, int qkv_rs, void* kcache, void*
                   int cache_rs, const int* pos_ptr, int B, int d);
 int i2t_ngram_ban_argmax(void* stream, const void* logits, int ld, int logits_is_f32, int64_t* ids, int ids_ld,
                          int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V, float* margin_out);
+/* The greedy step's lm_head without its logits (vision_encoder_decoder.py:143-180 with top_k = 1): i2t_gemm_bf16_top2 runs
+ * logits = A [M][lda] . B^T (B = the head's rows [N][ldb], bf16, K % 128 == 0) on the persistent GEMM kernel and leaves, for every
+ * 64-column segment of a row, its two largest values and their columns -- top2[M][nseg][4] = {v1, column1 (int bits), v2, column2},
+ * value descending, lower column first on ties, nseg = ceil(N / 64); i2t_top2_ngram_argmax then applies the n-gram ban and takes the
+ * argmax over the segments (a segment whose two leaders are both banned is re-evaluated from `hidden` and `w_head`), writing the token
+ * at ids[b][*len_ptr] as i2t_ngram_ban_argmax does.  No margin output: callers that want margins use the logits form. */
+int i2t_gemm_bf16_top2(void* stream, const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* top2, int nseg);
+int i2t_top2_ngram_argmax(void* stream, const float* top2, int nseg, const void* hidden, int ld_hidden, const void* w_head, int ld_w, int d,
+                          int64_t* ids, int ids_ld, int* len_ptr, const int* ngram_sizes, int n_sizes, int B, int V);
 int i2t_embed_step(void* stream, const int64_t* ids, int ids_ld, const int* len_ptr, const float* wte,
                    const float* wpe, float* x, int B, int d, int pos_offset, int vocab);
 /* One sampling step of generate() for B captions (reference models/vision_encoder_decoder.py:150-180, the non-greedy modes; the

@@ -270,7 +270,8 @@ def _decode_vs_forward(tag, m, images, gold, steps):
     dec = GreedyDecoder(m)
     worst = 0.0
     for t in steps:
-        dec.generate(images, torch.from_numpy(gold[:, :t + 1]).to(dev()), 1, use_graph=(t % 2 == 0))
+        # (return_margins: the step in its logits form -- without it the greedy head leaves only the segment maxima of the row)
+        dec.generate(images, torch.from_numpy(gold[:, :t + 1]).to(dev()), 1, use_graph=(t % 2 == 0), return_margins=True)
         lg = dec._state.logits[:, :V].float()
         err = (lg - full[:, t]).abs()
         tol = logits_tol(full[:, t].cpu().numpy())

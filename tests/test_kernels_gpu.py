@@ -958,6 +958,58 @@ def test_fused_backward_dropout_outputs(ops):
     check('attention_bwd token multipliers', g1.view(B * T, 3, dd), ref, 1e-6, 1 / 128)
 
 
+def test_top2_head_chooses_the_tokens_of_the_logits_form(ops):
+    """Greedy decode's lm_head in its segment-maxima form (i2t_gemm_bf16_top2 + i2t_top2_ngram_argmax) against the logits form
+    (i2t_gemm_bf16 into fp32 logits + i2t_ngram_ban_argmax): the same token for every caption -- with repeated n-grams in the history
+    (bans), with the best AND the second-best column of one segment banned (the exact re-evaluation path), with duplicated head rows
+    (ties: the lower column wins) and with a vocabulary that ends inside a segment."""
+    B, d, V, L = 300, 256, 1000 + 37, 24
+    Vp = (V + 63) // 64 * 64
+    hid = rnd(B, d, dtype=BF16, seed=501)
+    W = (rnd(V, d, seed=502) * 0.2).to(BF16)
+    W[700] = W[70]                                            # exact ties between columns 70 and 700
+    g = torch.Generator().manual_seed(503)
+    ids = torch.randint(0, V, (B, L + 1), generator=g).to(dev())
+    ln = 17
+    logits = torch.zeros(B, Vp, device=dev())
+    ops.gemm(hid, W, logits, B, V, d)
+    ngr = torch.tensor([2, 3], dtype=torch.int32, device=dev())
+    top1 = logits[:, :V].argmax(-1)
+    # rows 0..99: the un-banned winner follows an earlier copy of the current last token -> banned by the 2-gram rule
+    for b in range(100):
+        ids[b, 5] = ids[b, ln - 1]
+        ids[b, 6] = top1[b]
+    # rows 100..149: the segment's runner-up is banned too (a second earlier copy of the last token, followed by it)
+    for b in range(100, 150):
+        seg = int(top1[b]) // 64
+        l2 = logits[b, seg * 64:min(V, seg * 64 + 64)].clone()
+        l2[int(top1[b]) - seg * 64] = float('-inf')
+        ids[b, 5], ids[b, 6] = ids[b, ln - 1], top1[b]
+        ids[b, 9], ids[b, 10] = ids[b, ln - 1], seg * 64 + int(l2.argmax())
+    lens = torch.tensor([ln], dtype=torch.int32, device=dev())
+    ref_ids, got_ids = ids.clone(), ids.clone()
+    ops.ngram_ban_argmax(logits, Vp, ref_ids, L + 1, lens, ngr, 2, B, V, torch.empty(B, device=dev()))
+    top2 = torch.zeros(B, (V + 63) // 64, 4, device=dev())
+    ops.gemm_top2(hid, W, top2, B, V, d)
+    # the segments against the logits themselves
+    lg = torch.full((B, Vp), float('-inf'), device=dev())
+    lg[:, :V] = logits[:, :V]
+    segs = lg.view(B, -1, 64)
+    v, i = segs.sort(dim=-1, descending=True, stable=True)
+    assert torch.equal(top2[..., 0], v[..., 0]) and torch.equal(top2[..., 2], v[..., 1])
+    cols = i + (torch.arange(segs.shape[1], device=dev()) * 64)[None, :, None]
+    assert torch.equal(top2[..., 1].contiguous().view(torch.int32), cols[..., 0].int())
+    ops.top2_ngram_argmax(top2, hid, W, got_ids, L + 1, lens, ngr, 2, B, V, d)
+    same = got_ids[:, ln] == ref_ids[:, ln]
+    if not bool(same.all()):      # the re-evaluated segments sum in another order: a different token only at a (near-)tie
+        bad = (~same).nonzero().flatten()
+        assert bool((bad >= 100).all() and (bad < 150).all())
+        gap = (logits[bad, got_ids[bad, ln]] - logits[bad, ref_ids[bad, ln]]).abs()
+        assert float(gap.max()) <= 1e-4 * float(logits.abs().max())
+    assert torch.equal(got_ids[:, :ln], ids[:, :ln]) and bool((ref_ids[:100, ln] != top1[:100]).all())
+    assert int((got_ids[:, ln] == 700).sum()) == 0 or int((ref_ids[:, ln] == 700).sum()) > 0
+
+
 def test_round4_fused_dropout_sites(ops):
     """The dropout passes folded into their neighbours in round 4, each against the pass it replaces: (a) attention_bwd's per-token
     multipliers when the queries are the FIRST rows of longer sequences (the encoder's CLS-only last block: out_drop_q_seq), (b) the
