@@ -61,6 +61,12 @@ EMB_DROP_FUSED = os.environ.get('I2T_EMB_DROP_FUSED', '1') not in ('', '0')
 VOCAB_PAD = max(8, int(os.environ.get('I2T_VOCAB_PAD', '64')) // 8 * 8)          # (a multiple of 8: the ABI's 16-byte row alignment)
 
 
+# every parameter of 4096 elements or more starts on a multiple of this many elements of the flat arenas: 64 = a 128-byte line of the bf16 shadow and two of the
+# fp32 parameter / gradient arenas (8 -- 16 bytes, the kernels' minimum -- left the gradient GEMMs' 64-byte atomic rows and the optimizer's
+# segments straddling lines).  I2T_ARENA_ALIGN=8: the old layout, for A/B runs.
+ARENA_ALIGN = max(8, int(os.environ.get('I2T_ARENA_ALIGN', '64')) // 8 * 8)
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -194,6 +200,8 @@ class ParamArena:
         self.params: Dict[str, torch.nn.Parameter] = {}
         off = 0
         for name, p, numel, shape in _arena_order(list(module.named_parameters())):          # (tied parameters appear once)
+            if numel >= 4096:                      # matrices start on a line; the small entries between them (biases, norms, the MoE
+                off = _round_up(off, ARENA_ALIGN)  # family's per-expert pieces, whose kernels rely on their packing) keep the 16-byte rule
             self.entries[name] = (off, numel, shape)
             if p is not None:
                 self.params[name] = p
@@ -258,7 +266,7 @@ class ParamArena:
         for n in names:
             o, numel, _ = self.entries[n]
             if end is not None and o != end:
-                raise I2TError(f'arena entries {names} are not adjacent')
+                raise I2TError(f'arena entries {names} are not adjacent (a member whose size is not a multiple of {ARENA_ALIGN} elements? I2T_ARENA_ALIGN=8 relaxes it)')
             if numel % 8 and n != names[-1]:
                 raise I2TError(f'arena entry {n} ({numel} elements) breaks the 8-element alignment of a fused view')
             end = o + numel
