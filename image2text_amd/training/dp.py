@@ -176,6 +176,7 @@ class DataParallelGrads:
         self.overlap = overlap
         self.comm = None                # RcclComm, created with the first exchange on a GPU arena (see _transport)
         self._comm_tried = False
+        self._fb_group = None
         self._pending = []              # (work, tensor view, finishing step or None)
         self._reduced_upto = None       # arena offset from which the current window's gradients are already in flight/reduced
         self._reserved = False
@@ -242,18 +243,35 @@ class DataParallelGrads:
 
     def _reduce(self, t: torch.Tensor, async_op: bool):
         """Start the mean over ranks of ``t`` in place.  Returns (work, post): ``post`` (or None) finishes the mean after ``work.wait()``."""
-        backend = dist.get_backend(self.group)
         comm = self._transport(t)
         if comm is not None:
             return comm.all_reduce_mean_async(t), None
+        group = self._cuda_group() if t.is_cuda else self.group
+        backend = dist.get_backend(group)
         if os.environ.get('I2T_DP_WIRE', 'f32') == 'bf16':
             # the bf16 wire form on torch.distributed (what csrc/comm.cpp does around ncclAllReduce: round, sum in bf16, widen x 1/world)
             wire = t.to(torch.bfloat16)
-            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
             return work, (lambda: t.copy_(wire.to(torch.float32) / self.world))
         if backend == 'nccl':
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), (lambda: t.div_(self.world))
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op), None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op), (lambda: t.div_(self.world))
+
+    def _cuda_group(self):
+        """The group a GPU arena is reduced over when the package's own communicator is not in use: the control group if it is an NCCL
+        (= RCCL) one, else an NCCL group over the same ranks created here, once and collectively (every rank reaches its first fallback
+        exchange together, having agreed that the communicator is unavailable) -- a gloo all-reduce of a GPU arena would stage 647 MB
+        through the host on every step.  If that group cannot be made either, the control group (slow, correct)."""
+        if self._fb_group is None:
+            self._fb_group = self.group
+            if dist.get_backend(self.group) != 'nccl':
+                try:
+                    ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+                    self._fb_group = dist.new_group(ranks=ranks, backend='nccl')
+                except Exception as e:
+                    import warnings
+                    warnings.warn(f'image2text_amd: no NCCL group for the fallback exchange ({e}); reducing GPU gradients over {dist.get_backend(self.group)}')
+        return self._fb_group
 
     def _drain(self):
         """Wait for every collective in flight, finish its mean, release the CU reservation, close the window."""
@@ -281,7 +299,7 @@ class DataParallelGrads:
         lo, hi = self._split(arena)
         if hi <= lo:
             return
-        if arena.g32.is_cuda and RCCL_CUS > 0 and (self._transport(arena.g32) is not None or dist.get_backend(self.group) == 'nccl'):
+        if arena.g32.is_cuda and RCCL_CUS > 0 and (self._transport(arena.g32) is not None or dist.get_backend(self._cuda_group()) == 'nccl'):
             from .. import ops
             ops.gemm_reserve_cus(RCCL_CUS)          # the encoder backward's GEMMs leave room for the collective
             self._reserved = True

@@ -39,7 +39,12 @@ def main():
     configure_rccl_env()
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
-    dist.init_process_group('nccl', device_id=dev)
+    # I2T_DP_SELFCHECK_PG=gloo: torch.distributed as the control plane only (what bench.py and train_loop do) -- the package's own RCCL
+    # communicator is then the only one the process creates; I2T_DP_COMM=torch on top of it: the exchange falls back to a torch NCCL group
+    if os.environ.get('I2T_DP_SELFCHECK_PG', 'nccl') == 'gloo':
+        dist.init_process_group('gloo')
+    else:
+        dist.init_process_group('nccl', device_id=dev)
     from image2text_amd import ops
     from image2text_amd.configs.trainer import TrainerWrapperConfig
     from image2text_amd.synth import det_init_, fake_tokenizer, nano224_config, synthetic_batch
@@ -137,6 +142,16 @@ def main():
         print('DP_SELFCHECK accumulation mismatch, worst entries:', worst, 'max |g| =', float(acc0.abs().max()), flush=True)
     assert err2 <= max(4 * floor, TOL), f'accumulation window: {err2:.3e} (noise floor {floor:.3e})'
     # transport: the package's own RCCL communicator behind the C ABI (i2t_comm_*), fp32 on the wire; its bf16 wire form rounds once
+    if os.environ.get('I2T_DP_COMM', 'rccl') == 'torch':      # the fallback transport was asked for: a torch NCCL group even under a gloo control plane
+        assert dp1.comm is None
+        fb = dp1._cuda_group()
+        print(f'DP_SELFCHECK transport=torch-{dist.get_backend(fb)}', flush=True)
+        assert dist.get_backend(fb) == 'nccl'
+        print(f'DP_SELFCHECK deterministic={int(TOL == 0.0)} tol={TOL}', flush=True)
+        print(f'DP_SELFCHECK_OK floor={floor:.2e} hooked={err:.2e} accumulate={err2:.2e} nchannels={os.environ.get("NCCL_MAX_NCHANNELS")}', flush=True)
+        dp1.close()
+        dist.destroy_process_group()
+        return
     assert dp1.comm is not None, 'the C-ABI RCCL communicator was not created (torch.distributed fallback in use)'
     t = torch.randn(1 << 16, device=dev)
     want32, want16 = t.clone(), t.bfloat16().float()
