@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int d, unsigned drop_key, unsigned drop_thr, float drop_scale,
                                                      float* __restrict__ sumsq_out, const float* __restrict__ dx_pre_sumsq, int blk0,
-                                                     unsigned dxm_key, unsigned dxm_thr, float dxm_scale) {
+                                                     unsigned dxm_key, unsigned dxm_thr, float dxm_scale, int acc_period, int acc_rows) {
     __shared__ float red[2][4][MAXC * 256];   // [gamma|beta][wave][column]  (32 KiB)
     // dx_pre_sumsq: the dx this launch accumulates onto is still UN-normalised; its normaliser 1 / (||dx|| + 1e-6) -- the
     // gradient normaliser of the block boundary above, whose fp32 rescale pass this replaces -- is applied while adding
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-                if (dx_accumulate) o += *dxp * pre;
+                if (dx_accumulate && (acc_period == 0 || row % acc_period < acc_rows)) o += *dxp * pre;      // (acc_period: only the first acc_rows rows of every period hold a value)
                 ssq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
                 if (dxm_thr) {     // the tower's lowest block: the embedding dropout's mask on the f32 gradient it hands to the embedding
                     bool keepm[4];           // backward (idx = row * d + column, as i2t_dropout_apply mode 1); sum of squares and bf16 copy: unmasked
@@ -527,14 +527,16 @@ extern "C" int i2t_layernorm_bwd(void* stream, const void* dy, int dy_is_f32, co
                                  float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
                                  float drop_scale, float* sumsq_out, const float* dx_pre_sumsq) {
     return i2t_layernorm_bwd_ex(stream, dy, dy_is_f32, x, gamma, mean, rstd, dx, dx_accumulate, dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr,
-                                drop_scale, sumsq_out, dx_pre_sumsq, 0u, 0u, 1.0f);
+                                drop_scale, sumsq_out, dx_pre_sumsq, 0u, 0u, 1.0f, 0, 0);
 }
 
 extern "C" int i2t_layernorm_bwd_ex(void* stream, const void* dy, int dy_is_f32, const float* x, const float* gamma,
                                     const float* mean, const float* rstd, float* dx, int dx_accumulate, void* dx_bf16,
                                     float* dgamma, float* dbeta, int M, int d, unsigned drop_key, unsigned drop_thr,
                                     float drop_scale, float* sumsq_out, const float* dx_pre_sumsq, unsigned dx_mask_key,
-                                    unsigned dx_mask_thr, float dx_mask_scale) {
+                                    unsigned dx_mask_thr, float dx_mask_scale, int acc_period, int acc_rows) {
+    I2T_REQUIRE(acc_period == 0 || (dx_accumulate && acc_rows >= 0 && acc_rows <= acc_period && d <= MAXC * 256),
+                "i2t_layernorm_bwd_ex: acc_period=%d acc_rows=%d (needs dx_accumulate, 0 <= acc_rows <= acc_period)", acc_period, acc_rows);
     I2T_REQUIRE(!dx_mask_thr || ((long)M * d < (1L << 32) && d <= MAXC * 256), "i2t_layernorm_bwd_ex: the f32 mask needs M*d < 2^32 and d <= %d", MAXC * 256);
     I2T_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0, "i2t_layernorm_bwd: bad args");
     I2T_REQUIRE(!dx_pre_sumsq || dx_accumulate, "i2t_layernorm_bwd: dx_pre_sumsq only applies when accumulating onto dx");
@@ -562,11 +564,11 @@ extern "C" int i2t_layernorm_bwd_ex(void* stream, const void* dy, int dy_is_f32,
         if (dy_is_f32)
             hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
                                (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0, dx_mask_key, dx_mask_thr,
-                               dx_mask_scale);
+                               dx_mask_scale, acc_period, acc_rows);
         else
             hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(per), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dx_accumulate,
                                (bf16_t*)dx_bf16, dgamma, dbeta, M, d, drop_key, drop_thr, drop_scale, sumsq_out, dx_pre_sumsq, b0, dx_mask_key, dx_mask_thr,
-                               dx_mask_scale);
+                               dx_mask_scale, acc_period, acc_rows);
     }
     I2T_CHECK_LAUNCH("i2t_layernorm_bwd");
     return I2T_OK;

@@ -697,7 +697,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         return x3, (sv if save else None)
 
     def block_bwd_cls(self, pfx: str, sv, dcls, dx_full, B, T, d, H, ff, ncls):
-        """dcls fp32 [B*ncls, d]: gradient w.r.t. the block's CLS-row output.  dx_full fp32 [B, T, d], zero on entry: receives the
+        """dcls fp32 [B*ncls, d]: gradient w.r.t. the block's CLS-row output.  dx_full fp32 [B, T, d] (its contents on entry do not matter): receives the
         gradient w.r.t. the block input (every row: K and V saw them all)."""
         a = self.arena
         M, Mc = B * T, B * ncls
@@ -732,7 +732,8 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
                          dx_out=dln1)
         ops.copy_rows(dcls, ncls * d, dx_full, T * d, B, ncls, d)               # residual path of the CLS rows
         ops.layernorm_bwd(dln1, sv.x, a.P(f'{pfx}.ln_1.weight'), sv.m1, sv.r1, dx_full.view(M, d), a.G(f'{pfx}.ln_1.weight'),
-                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, sumsq_out=self._ws[1:2])
+                          a.G(f'{pfx}.ln_1.bias'), M, d, dx_accumulate=True, sumsq_out=self._ws[1:2],
+                          acc_period=T, acc_rows=ncls)      # only the CLS rows of dx_full hold a value: the patch rows are written, not added onto
 
     def _blocks_bwd(self, prefix: str, saves: List, dx, B, T, d, H, ff, causal, S, dmem, vl=None, presummed_slot=None,
                     normalize: bool = True, lowest_dx_mask=None):
@@ -857,7 +858,7 @@ class HotPath(FamilyBlocks, LlamaBlocks, LoraAdapters, ViTEncoder):
         else:
             ops.layernorm_bwd(denc, ctx.cls, gf, ctx.mf, ctx.rf, dcls, a.G(f'{self.ep}transformer.ln_f.weight'),
                               a.G(f'{self.ep}transformer.ln_f.bias'), Mc, d)
-        dx = torch.zeros(B, T, d, dtype=F32, device=a.device)
+        dx = torch.empty(B, T, d, dtype=F32, device=a.device) if self.cls_only_last else torch.zeros(B, T, d, dtype=F32, device=a.device)
         # the embedding dropout's backward: a mask on the gradient the lowest block hands down -- applied by that block's last LayerNorm
         # backward while it stores dx (dense nanoGPT blocks), by a pass over dx elsewhere
         emb_mask = ctx.emb_drop if (ctx.emb_drop is not None and EMB_DROP_FUSED and int(ctx.emb_drop[0]) == 1 and B * T * d < 2 ** 32) else None

@@ -23,7 +23,7 @@ SIGNATURES = {
     'i2t_layernorm_fwd': [P, P, P, P, P, I, P, P, I, I],
     'i2t_layernorm_fwd_eps': [P, P, P, P, P, I, P, P, I, I, F],
     'i2t_layernorm_bwd': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P],
-    'i2t_layernorm_bwd_ex': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P, U, U, F],
+    'i2t_layernorm_bwd_ex': [P, P, I, P, P, P, P, P, I, P, P, P, I, I, U, U, F, P, P, U, U, F, I, I],
     'i2t_layernorm_nd_fwd': [P, P, P, P, P, P, L, P, I, I, I],
     'i2t_layernorm_nd_fwd_drop': [P, P, P, P, P, P, L, P, I, I, I, U, U, F, L],
     'i2t_layernorm_nd_bwd': [P, P, L, P, P, P, P, P, P, P, P, I, I, I],

@@ -201,14 +201,15 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=None):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, d, dx_accumulate=False, dx_bf16=None, bf16_drop=None,
-                  sumsq_out=None, dx_pre_sumsq=None, dx_mask=None):
+                  sumsq_out=None, dx_pre_sumsq=None, dx_mask=None, acc_period=0, acc_rows=0):
     """bf16_drop = (1, key, thr, scale): elementwise dropout mask applied to the bf16 copy only; dx_mask = (1, key, thr, scale): the
-    same kind of mask on the f32 dx this call stores (see include/i2t.h::i2t_layernorm_bwd_ex)."""
+    same kind of mask on the f32 dx this call stores; acc_period / acc_rows: accumulate onto the first acc_rows rows of every period only
+    (see include/i2t.h::i2t_layernorm_bwd_ex)."""
     _need_cuda(dy, x, dx)
     assert (bf16_drop is None or int(bf16_drop[0]) == 1) and (dx_mask is None or int(dx_mask[0]) == 1)
     _l.check(_lib().i2t_layernorm_bwd_ex(_stream(), _p(dy), int(dy.dtype == F32), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
                                          int(dx_accumulate), _p(dx_bf16), _p(dgamma), _p(dbeta), M, d, *_drop(bf16_drop)[1:],
-                                         _p(sumsq_out), _p(dx_pre_sumsq), *_drop(dx_mask)[1:]), 'i2t_layernorm_bwd_ex')
+                                         _p(sumsq_out), _p(dx_pre_sumsq), *_drop(dx_mask)[1:], int(acc_period), int(acc_rows)), 'i2t_layernorm_bwd_ex')
     return dx
 
 

@@ -146,7 +146,10 @@ int i2t_layernorm_bwd_ex(void* stream, const void* dy, int dy_is_f32, const floa
                          const float* mean, const float* rstd,
                          float* dx, int dx_accumulate, void* dx_bf16, float* dgamma, float* dbeta, int M, int d,
                          unsigned drop_key, unsigned drop_thr, float drop_scale, float* sumsq_out, const float* dx_pre_sumsq,
-                         unsigned dx_mask_key, unsigned dx_mask_thr, float dx_mask_scale);
+                         unsigned dx_mask_key, unsigned dx_mask_thr, float dx_mask_scale, int acc_period, int acc_rows);
+/* acc_period / acc_rows (0 = every row): with dx_accumulate, only rows r with r % acc_period < acc_rows are added onto -- the others
+ * are written.  The encoder's CLS-only last block (encoder.py:172-173): dx holds the CLS rows' residual gradient and nothing else, so
+ * the zero fill of the patch rows and its read-back are not needed. */
 /* dx_pre_sumsq (bwd, nullable, needs dx_accumulate): the dx accumulated onto is still un-normalised -- its old value is
  * multiplied by 1 / (sqrt(*dx_pre_sumsq) + 1e-6) while adding (the gradient normaliser of i2t_grad_normalize flag 2).
  * sumsq_out (bwd, nullable): += sum of squares of the f32 dx written by this call (after accumulation) -- lets the
