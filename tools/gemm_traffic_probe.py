@@ -34,11 +34,13 @@ def main():
     marker = torch.zeros(1, device=dev)
     order = []
     for (M, N, K, ak, bk, f32, epi) in SHAPES:
-        def mat(r, c, scale):          # leading dimension padded to a multiple of 8 elements (the ABI's operand rule)
-            return (torch.randn(r, (c + 7) // 8 * 8, device=dev, generator=g) * scale).to(BF16)[:, :c]
+        PAD = int(os.environ.get('I2T_PROBE_PAD', '64'))      # leading dimensions: 64 elements = a 128-byte line (the engine's VOCAB_PAD); 8 = the ABI's minimum
+
+        def mat(r, c, scale):
+            return (torch.randn(r, (c + PAD - 1) // PAD * PAD, device=dev, generator=g) * scale).to(BF16)[:, :c]
         a = mat(K, M, 0.5) if ak else mat(M, K, 0.5)
         b = mat(K, N, 0.05) if bk else mat(N, K, 0.05)
-        Np = (N + 7) // 8 * 8
+        Np = (N + PAD - 1) // PAD * PAD
         out = torch.zeros(M, Np, dtype=F32 if f32 else BF16, device=dev)
         kw = dict(a_kmajor=bool(ak), b_kmajor=bool(bk))
         extra = 0
